@@ -1,0 +1,349 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes/numpy front-end of the CPU oracle (oracle/*.c).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product package never does (a test enforces
+that no file under ``aerial_gym_simulator_amd/`` mentions ``oracle``).
+
+All arrays are numpy float32/int32/uint8, C-contiguous, in the REFERENCE's AoS
+layout ([N, C] rows, quaternions xyzw).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+MAX_MOTORS = 8
+
+CTRL = {
+    "no_control": 0,
+    "position": 1,
+    "velocity": 2,
+    "attitude": 3,
+    "rates": 4,
+    "acceleration": 5,
+    "velocity_steering": 6,
+    "fully_actuated": 7,
+}
+
+
+class OrcRobotParams(C.Structure):
+    _fields_ = [
+        ("num_motors", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("controller", C.c_int32),
+        ("root_link_mode", C.c_int32),
+        ("dt", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("mass", C.c_float),
+        ("inertia", C.c_float * 9),
+        ("inertia_inv", C.c_float * 9),
+        ("alloc", C.c_float * (6 * MAX_MOTORS)),
+        ("alloc_pinv", C.c_float * (MAX_MOTORS * 6)),
+        ("wrench_map", C.c_float * (6 * MAX_MOTORS)),
+        ("motor_dir", C.c_float * MAX_MOTORS),
+        ("cq", C.c_float),
+        ("use_rps", C.c_int32),
+        ("use_discrete_approximation", C.c_int32),
+        ("integration_rk4", C.c_int32),
+        ("min_thrust", C.c_float),
+        ("max_thrust", C.c_float),
+        ("max_rate", C.c_float),
+        ("max_yaw_rate", C.c_float),
+        ("lin_drag_linear", C.c_float * 3),
+        ("lin_drag_quadratic", C.c_float * 3),
+        ("ang_drag_linear", C.c_float * 3),
+        ("ang_drag_quadratic", C.c_float * 3),
+        ("linear_damping", C.c_float),
+        ("angular_damping", C.c_float),
+        ("max_linear_velocity", C.c_float),
+        ("max_angular_velocity", C.c_float),
+        ("collision_radius", C.c_float),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/*.c with gcc (oracle/Makefile).  Building the checker is not using it."""
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_dynamics.c", "oracle_raycast.c", "oracle_types.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "oracle arrays must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_params(d):
+    """Build an OrcRobotParams from a plain dict (see robot_model.params_dict in the tests)."""
+    P = OrcRobotParams()
+    M = int(d["num_motors"])
+    P.num_motors = M
+    P.num_actions = int(d["num_actions"])
+    ctrl = d["controller"]
+    P.controller = CTRL[ctrl] if isinstance(ctrl, str) else int(ctrl)
+    P.root_link_mode = int(d.get("root_link_mode", 0))
+    P.dt = float(d["dt"])
+    P.gravity[:] = [float(x) for x in d["gravity"]]
+    P.mass = float(d["mass"])
+    J = np.asarray(d["inertia"], dtype=np.float32).reshape(9)
+    P.inertia[:] = J.tolist()
+    Ji = np.asarray(d.get("inertia_inv", np.linalg.inv(J.reshape(3, 3).astype(np.float64))), dtype=np.float32).reshape(9)
+    P.inertia_inv[:] = Ji.tolist()
+    A = np.asarray(d["alloc"], dtype=np.float32).reshape(6, M)
+    Ap = np.asarray(d["alloc_pinv"], dtype=np.float32).reshape(M, 6)
+    W = np.asarray(d.get("wrench_map", A), dtype=np.float32).reshape(6, M)
+    for name, mat in (("alloc", A), ("alloc_pinv", Ap), ("wrench_map", W)):
+        buf = getattr(P, name)
+        flat = mat.reshape(-1)
+        for i in range(flat.size):
+            buf[i] = float(flat[i])
+    md = np.asarray(d["motor_dir"], dtype=np.float32).reshape(M)
+    for i in range(M):
+        P.motor_dir[i] = float(md[i])
+    P.cq = float(d["cq"])
+    P.use_rps = int(d["use_rps"])
+    P.use_discrete_approximation = int(d["use_discrete_approximation"])
+    P.integration_rk4 = int(d.get("integration_rk4", 1))
+    P.min_thrust = float(d["min_thrust"])
+    P.max_thrust = float(d["max_thrust"])
+    P.max_rate = float(d["max_rate"])
+    P.max_yaw_rate = float(d.get("max_yaw_rate", np.pi / 3.0))
+    for name in ("lin_drag_linear", "lin_drag_quadratic", "ang_drag_linear", "ang_drag_quadratic"):
+        getattr(P, name)[:] = [float(x) for x in d.get(name, [0.0, 0.0, 0.0])]
+    P.linear_damping = float(d.get("linear_damping", 0.0))
+    P.angular_damping = float(d.get("angular_damping", 0.0))
+    P.max_linear_velocity = float(d.get("max_linear_velocity", 100.0))
+    P.max_angular_velocity = float(d.get("max_angular_velocity", 100.0))
+    P.collision_radius = float(d.get("collision_radius", 0.0))
+    return P
+
+
+class SubstepOut:
+    __slots__ = ("euler", "qveh", "vveh", "vbody", "wbody", "wrench_cmd", "body_wrench", "action_clipped")
+
+
+def substep(P, state, action, thrust, kT, tau_inc, tau_dec, Kp, Kv, KR, Kw, disturb=None,
+            disturb_max=None, integrate=True):
+    """One physics sub-step in place on ``state`` [N,13] and ``thrust`` [N,M]."""
+    n = state.shape[0]
+    M, A = P.num_motors, P.num_actions
+    assert state.dtype == np.float32 and state.shape == (n, 13)
+    assert thrust.dtype == np.float32 and thrust.shape == (n, M)
+    out = SubstepOut()
+    out.euler = np.zeros((n, 3), np.float32)
+    out.qveh = np.zeros((n, 4), np.float32)
+    out.vveh = np.zeros((n, 3), np.float32)
+    out.vbody = np.zeros((n, 3), np.float32)
+    out.wbody = np.zeros((n, 3), np.float32)
+    out.wrench_cmd = np.zeros((n, 6), np.float32)
+    out.body_wrench = np.zeros((n, 6), np.float32)
+    out.action_clipped = np.zeros((n, A), np.float32)
+    action = _f(action).reshape(n, A)
+    dm = _f(disturb_max) if disturb_max is not None else None
+    ds = _f(disturb) if disturb is not None else None
+    lib().orc_substep(
+        C.byref(P), n, _p(state), _p(action), _p(out.action_clipped), _p(thrust), _p(_f(kT)),
+        _p(_f(tau_inc)), _p(_f(tau_dec)), _p(_f(Kp)), _p(_f(Kv)), _p(_f(KR)), _p(_f(Kw)),
+        _p(ds), _p(dm), _p(out.euler), _p(out.qveh), _p(out.vveh), _p(out.vbody), _p(out.wbody),
+        _p(out.wrench_cmd), _p(out.body_wrench), int(bool(integrate)),
+    )
+    return out
+
+
+def update_states(state):
+    n = state.shape[0]
+    euler = np.zeros((n, 3), np.float32)
+    qveh = np.zeros((n, 4), np.float32)
+    vveh = np.zeros((n, 3), np.float32)
+    vbody = np.zeros((n, 3), np.float32)
+    wbody = np.zeros((n, 3), np.float32)
+    lib().orc_update_states(n, _p(_f(state)), _p(euler), _p(qveh), _p(vveh), _p(vbody), _p(wbody))
+    return euler, qveh, vveh, vbody, wbody
+
+
+def integrate(P, state, body_wrench):
+    lib().orc_integrate(C.byref(P), state.shape[0], _p(state), _p(_f(body_wrench)))
+
+
+def collide_sphere_boxes(radius, state, boxes, crashes):
+    n, nb = boxes.shape[0], boxes.shape[1]
+    lib().orc_collide_sphere_boxes(n, nb, C.c_float(radius), _p(_f(state)), _p(_f(boxes)), _p(crashes))
+
+
+def reward_position(state, qveh, wbody, target, crashes):
+    n = state.shape[0]
+    reward = np.zeros(n, np.float32)
+    lib().orc_reward_position(n, _p(_f(state)), _p(_f(qveh)), _p(_f(wbody)), _p(_f(target)), _p(crashes), _p(reward))
+    return reward
+
+
+def obs_position(state, vbody, wbody, target):
+    n = state.shape[0]
+    obs = np.zeros((n, 13), np.float32)
+    lib().orc_obs_position(n, _p(_f(state)), _p(_f(vbody)), _p(_f(wbody)), _p(_f(target)), _p(obs))
+    return obs
+
+
+def reward_navigation(state, qveh, target, action, prev_action, curriculum_progress, rp, pos_err,
+                      prev_pos_err, crashes):
+    n = state.shape[0]
+    reward = np.zeros(n, np.float32)
+    action = _f(action)
+    lib().orc_reward_navigation(
+        n, _p(_f(state)), _p(_f(qveh)), _p(_f(target)), _p(action), _p(_f(prev_action)),
+        action.shape[1], C.c_float(curriculum_progress), _p(_f(rp)), _p(pos_err), _p(prev_pos_err),
+        _p(crashes), _p(reward),
+    )
+    return reward
+
+
+def reset_robot_state(mask, u01, min_state, max_state, bounds_min, bounds_max, state):
+    lib().orc_reset_robot_state(
+        state.shape[0], _p(mask), _p(_f(u01)), _p(_f(min_state)), _p(_f(max_state)),
+        _p(_f(bounds_min)), _p(_f(bounds_max)), _p(state),
+    )
+
+
+def quat_from_euler(e):
+    e = _f(e)
+    q = np.zeros((e.shape[0], 4), np.float32)
+    lib().orc_quat_from_euler(e.shape[0], _p(e), _p(q))
+    return q
+
+
+def quat_mul(a, b):
+    a, b = _f(a), _f(b)
+    o = np.zeros_like(a)
+    lib().orc_quat_mul(a.shape[0], _p(a), _p(b), _p(o))
+    return o
+
+
+def tf_apply(q, t, v):
+    q, t, v = _f(q), _f(t), _f(v)
+    o = np.zeros_like(v)
+    lib().orc_tf_apply(v.shape[0], _p(q), _p(t), _p(v), _p(o))
+    return o
+
+
+# ----------------------------------------------------------------------------- ray-cast
+def scene_transform(tri_local, tri_asset, asset_state):
+    n, nt = tri_local.shape[0], tri_local.shape[1]
+    na = asset_state.shape[1]
+    out = np.zeros((n, nt, 9), np.float32)
+    ta = np.ascontiguousarray(tri_asset, dtype=np.int32)
+    lib().orc_scene_transform(n, nt, na, _p(_f(tri_local)), _p(ta), _p(_f(asset_state)), _p(out))
+    return out
+
+
+def sensor_pose(state, local_pos, local_quat, frame_quat):
+    n, ns = local_pos.shape[0], local_pos.shape[1]
+    pos = np.zeros((n, ns, 3), np.float32)
+    quat = np.zeros((n, ns, 4), np.float32)
+    lib().orc_sensor_pose(n, ns, _p(_f(state)), _p(_f(local_pos)), _p(_f(local_quat)), _p(_f(frame_quat)), _p(pos), _p(quat))
+    return pos, quat
+
+
+def camera_kinv(width, height, hfov_deg):
+    """{K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]} of warp_cam.py:31-64 (float32)."""
+    import math
+
+    W, H = width, height
+    u0, v0 = W / 2, H / 2
+    hfov = math.radians(hfov_deg)
+    f = W / 2 * 1 / math.tan(hfov / 2)
+    vfov = 2 * math.atan(H / (2 * f))
+    au = u0 / math.tan(hfov / 2)
+    av = v0 / math.tan(vfov / 2)
+    return np.array([1.0 / au, -u0 / au, 1.0 / av, -v0 / av], dtype=np.float32), int(u0), int(v0)
+
+
+MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3}
+
+
+def raycast_camera(width, height, kinv, far_plane, c_x, c_y, mode, cam_pos, cam_quat, tris, tri_seg,
+                   want_seg=True, use_bvh=False):
+    n, ns = cam_pos.shape[0], cam_pos.shape[1]
+    nt = tris.shape[1]
+    m = MODE[mode] if isinstance(mode, str) else mode
+    shape = (n, ns, height, width) if m <= 1 else (n, ns, height, width, 3)
+    pixels = np.zeros(shape, np.float32)
+    seg = np.zeros((n, ns, height, width), np.int32) if want_seg else None
+    ts = np.ascontiguousarray(tri_seg, dtype=np.int32)
+    lib().orc_raycast_camera(
+        n, ns, width, height, _p(_f(kinv)), C.c_float(far_plane), c_x, c_y, m, _p(_f(cam_pos)),
+        _p(_f(cam_quat)), _p(_f(tris)), _p(ts), nt, int(use_bvh), _p(pixels), _p(seg),
+    )
+    return pixels, seg
+
+
+def lidar_ray_table(height, width, hfov_min_deg, hfov_max_deg, vfov_min_deg, vfov_max_deg):
+    """warp_lidar.py:40-64: az from +max to min over W, el from +max to min over H, normalised."""
+    import math
+
+    hmin, hmax = math.radians(hfov_min_deg), math.radians(hfov_max_deg)
+    vmin, vmax = math.radians(vfov_min_deg), math.radians(vfov_max_deg)
+    rv = np.zeros((height, width, 3), np.float32)
+    for i in range(height):
+        for j in range(width):
+            az = hmax - (hmax - hmin) * (j / (width - 1))
+            el = vmax - (vmax - vmin) * (i / (height - 1))
+            rv[i, j, 0] = math.cos(az) * math.cos(el)
+            rv[i, j, 1] = math.sin(az) * math.cos(el)
+            rv[i, j, 2] = math.sin(el)
+    nrm = np.sqrt((rv * rv).sum(axis=2, keepdims=True, dtype=np.float32)).astype(np.float32)
+    return (rv / nrm).astype(np.float32)
+
+
+def raycast_lidar(ray_vectors, far_plane, mode, pos, quat, tris, tri_seg, want_seg=True, use_bvh=False):
+    n, ns = pos.shape[0], pos.shape[1]
+    height, width = ray_vectors.shape[0], ray_vectors.shape[1]
+    nt = tris.shape[1]
+    m = MODE[mode] if isinstance(mode, str) else mode
+    shape = (n, ns, height, width) if m == 0 else (n, ns, height, width, 3)
+    pixels = np.zeros(shape, np.float32)
+    seg = np.zeros((n, ns, height, width), np.int32) if want_seg else None
+    ts = np.ascontiguousarray(tri_seg, dtype=np.int32)
+    lib().orc_raycast_lidar(
+        n, ns, width, height, _p(_f(ray_vectors)), C.c_float(far_plane), m, _p(_f(pos)), _p(_f(quat)),
+        _p(_f(tris)), _p(ts), nt, int(use_bvh), _p(pixels), _p(seg),
+    )
+    return pixels, seg
+
+
+def sensor_postprocess(pixels, min_range, max_range, far_oor, near_oor, normalize, z_normal=None,
+                       u_dropout=None, std_a=0.0, std_b=0.0, std_c=0.0, mean_offset=0.0,
+                       dropout_prob=0.0):
+    assert pixels.dtype == np.float32 and pixels.flags["C_CONTIGUOUS"]
+    zn = _f(z_normal) if z_normal is not None else None
+    ud = _f(u_dropout) if u_dropout is not None else None
+    lib().orc_sensor_postprocess(
+        C.c_size_t(pixels.size), _p(pixels), _p(zn), _p(ud), C.c_float(std_a), C.c_float(std_b),
+        C.c_float(std_c), C.c_float(mean_offset), C.c_float(dropout_prob), C.c_float(min_range),
+        C.c_float(max_range), C.c_float(far_oor), C.c_float(near_oor), int(bool(normalize)),
+    )
+    return pixels

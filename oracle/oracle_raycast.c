@@ -1,0 +1,441 @@
+/*
+ * TEST INFRASTRUCTURE -- CPU oracle, ray-cast half.
+ *
+ * The reference's camera / LiDAR kernels (sensors/warp/warp_kernels/ *.py) are
+ * restated line by line.  What they CALL -- wp.Mesh / wp.mesh_query_ray /
+ * wp.quat_rotate / wp.normalize / wp.transform_vector -- lives in the
+ * third-party dependency warp-lang==1.0.0 (reference setup.py:18), which is
+ * not vendored under /root/reference and not installable here.  Those are
+ * restated from Warp's published source (warp/native/{mesh.h,intersect.h,
+ * quat.h,vec.h}).  The reference ships no test, fixture or golden vector for
+ * this path: ** parity unpinned **.  Known-answer tests (analytic ray/box
+ * depths, tests/test_oracle_raycast.py) pin the restatement geometrically.
+ *
+ * Semantics of the closest-hit query (== wp.mesh_query_ray up to exact ties):
+ *   over ALL triangles f of the env's mesh, Woop watertight test
+ *   (intersect_ray_tri_woop, incl. its double-precision fallback when an edge
+ *   function is exactly 0); accept 0 <= t < max_t; keep the smallest t, and on
+ *   an exact tie the SMALLEST face index (Warp keeps whichever its BVH visits
+ *   first; we make the answer traversal-order independent so that any BVH is a
+ *   pure accelerator and the result can be bit-exact across implementations).
+ *
+ * Brute force over triangles here; an (optional) median-split BVH with a
+ * conservative box test accelerates the cpu_baseline timing and must return
+ * identical bits (tests check that).
+ */
+#include "oracle_types.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NO_HIT_RAY_VAL 1000.0f /* warp_camera_kernels.py:3 */
+#define NO_HIT_SEG_VAL (-2)    /* warp_camera_kernels.py:4 */
+
+typedef struct { float x, y, z; } v3;
+
+static float v3_dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+/* warp vec.h normalize(): a / length(a), zero vector if length == 0 */
+static v3 v3_normalize(v3 a) {
+  float l = sqrtf(v3_dot(a, a));
+  v3 r = {0.0f, 0.0f, 0.0f};
+  if (l > 0.0f) { r.x = a.x / l; r.y = a.y / l; r.z = a.z / l; }
+  return r;
+}
+
+/* warp quat.h quat_rotate(q, x):
+ *   c = 2 w^2 - 1 ; d = 2 (q.xyz . x)
+ *   x c + q.xyz d + (q.xyz X x) w 2                                        */
+static v3 wp_quat_rotate(const float q[4], v3 x) {
+  float c = 2.0f * q[3] * q[3] - 1.0f;
+  float d = 2.0f * (q[0] * x.x + q[1] * x.y + q[2] * x.z);
+  v3 r;
+  r.x = x.x * c + q[0] * d + (q[1] * x.z - q[2] * x.y) * q[3] * 2.0f;
+  r.y = x.y * c + q[1] * d + (q[2] * x.x - q[0] * x.z) * q[3] * 2.0f;
+  r.z = x.z * c + q[2] * d + (q[0] * x.y - q[1] * x.x) * q[3] * 2.0f;
+  return r;
+}
+
+/* warp intersect.h diff_product(): a*b - c*d with FMA error compensation */
+static float diff_product(float a, float b, float c, float d) {
+  float cd = c * d;
+  float diff = fmaf(a, b, -cd);
+  float error = fmaf(-c, d, cd);
+  return diff + error;
+}
+
+static float xorf(float x, uint32_t m) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u ^= m;
+  memcpy(&x, &u, 4);
+  return x;
+}
+
+static uint32_t sign_mask(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return u & 0x80000000u;
+}
+
+typedef struct {
+  int kx, ky, kz;
+  float Sx, Sy, Sz;
+} RayShear;
+
+static void ray_shear(v3 d, RayShear *s) {
+  float dir[3] = {d.x, d.y, d.z};
+  float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  /* warp max_dim(): x if x>y&&x>z... (first strict maximum in x,y,z order) */
+  int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  int kx = kz + 1; if (kx == 3) kx = 0;
+  int ky = kx + 1; if (ky == 3) ky = 0;
+  if (dir[kz] < 0.0f) { int t = kx; kx = ky; ky = t; }
+  s->kx = kx; s->ky = ky; s->kz = kz;
+  s->Sx = dir[kx] / dir[kz];
+  s->Sy = dir[ky] / dir[kz];
+  s->Sz = 1.0f / dir[kz];
+}
+
+/* warp intersect.h intersect_ray_tri_woop(), returning only t */
+static int ray_tri_woop(v3 p, const RayShear *s, const float *tri, float *t_out) {
+  float A[3] = {tri[0] - p.x, tri[1] - p.y, tri[2] - p.z};
+  float B[3] = {tri[3] - p.x, tri[4] - p.y, tri[5] - p.z};
+  float C[3] = {tri[6] - p.x, tri[7] - p.y, tri[8] - p.z};
+  int kx = s->kx, ky = s->ky, kz = s->kz;
+  float Ax = A[kx] - s->Sx * A[kz];
+  float Ay = A[ky] - s->Sy * A[kz];
+  float Bx = B[kx] - s->Sx * B[kz];
+  float By = B[ky] - s->Sy * B[kz];
+  float Cx = C[kx] - s->Sx * C[kz];
+  float Cy = C[ky] - s->Sy * C[kz];
+  float U = diff_product(Cx, By, Cy, Bx);
+  float V = diff_product(Ax, Cy, Ay, Cx);
+  float W = diff_product(Bx, Ay, By, Ax);
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+    U = (float)(CxBy - CyBx);
+    double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+    V = (float)(AxCy - AyCx);
+    double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+    W = (float)(BxAy - ByAx);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
+  float det = U + V + W;
+  if (det == 0.0f) return 0;
+  float Az = s->Sz * A[kz], Bz = s->Sz * B[kz], Cz = s->Sz * C[kz];
+  float T = U * Az + V * Bz + W * Cz;
+  uint32_t ds = sign_mask(det);
+  if (xorf(T, ds) < 0.0f) return 0;
+  float rcp = 1.0f / det;
+  *t_out = T * rcp;
+  return 1;
+}
+
+/* ---------------- optional CPU BVH (median split), accelerator only -------- */
+typedef struct {
+  float lo[3], hi[3];
+  int left, right; /* internal: child node ids ; leaf: left = -1, right = face */
+} OrcBvhNode;
+
+typedef struct {
+  int n_nodes;
+  OrcBvhNode *nodes;
+} OrcBvh;
+
+static int bvh_build_rec(OrcBvh *b, const float *tris, int *faces, int n, float *cent) {
+  int id = b->n_nodes++;
+  OrcBvhNode *nd = &b->nodes[id];
+  for (int k = 0; k < 3; ++k) { nd->lo[k] = INFINITY; nd->hi[k] = -INFINITY; }
+  for (int i = 0; i < n; ++i) {
+    const float *t = tris + 9 * faces[i];
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 3; ++k) {
+        float c = t[3 * v + k];
+        if (c < nd->lo[k]) nd->lo[k] = c;
+        if (c > nd->hi[k]) nd->hi[k] = c;
+      }
+  }
+  if (n == 1) { nd->left = -1; nd->right = faces[0]; return id; }
+  float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float c = cent[3 * faces[i] + k];
+      if (c < clo[k]) clo[k] = c;
+      if (c > chi[k]) chi[k] = c;
+    }
+  int ax = 0;
+  if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+  if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+  float mid = 0.5f * (clo[ax] + chi[ax]);
+  int i = 0, j = n - 1;
+  while (i <= j) {
+    if (cent[3 * faces[i] + ax] < mid) ++i;
+    else { int t = faces[i]; faces[i] = faces[j]; faces[j] = t; --j; }
+  }
+  if (i == 0 || i == n) i = n / 2;
+  int l = bvh_build_rec(b, tris, faces, i, cent);
+  int r = bvh_build_rec(b, tris, faces + i, n - i, cent);
+  b->nodes[id].left = l;
+  b->nodes[id].right = r;
+  return id;
+}
+
+static void bvh_build(OrcBvh *b, const float *tris, int nt) {
+  b->n_nodes = 0;
+  b->nodes = (OrcBvhNode *)malloc(sizeof(OrcBvhNode) * (size_t)(2 * nt));
+  int *faces = (int *)malloc(sizeof(int) * (size_t)nt);
+  float *cent = (float *)malloc(sizeof(float) * 3 * (size_t)nt);
+  for (int f = 0; f < nt; ++f) {
+    faces[f] = f;
+    for (int k = 0; k < 3; ++k)
+      cent[3 * f + k] = (tris[9 * f + k] + tris[9 * f + 3 + k] + tris[9 * f + 6 + k]) / 3.0f;
+  }
+  bvh_build_rec(b, tris, faces, nt, cent);
+  free(faces);
+  free(cent);
+}
+
+/* conservative slab test against the box grown by eps (warp mesh.h uses 1e-3) */
+static int ray_box(v3 o, v3 rcp, const float lo[3], const float hi[3], float tmax) {
+  const float eps = 1.0e-3f;
+  float l1 = (lo[0] - eps - o.x) * rcp.x, l2 = (hi[0] + eps - o.x) * rcp.x;
+  float lmin = fminf(l1, l2), lmax = fmaxf(l1, l2);
+  l1 = (lo[1] - eps - o.y) * rcp.y; l2 = (hi[1] + eps - o.y) * rcp.y;
+  lmin = fmaxf(fminf(l1, l2), lmin); lmax = fminf(fmaxf(l1, l2), lmax);
+  l1 = (lo[2] - eps - o.z) * rcp.z; l2 = (hi[2] + eps - o.z) * rcp.z;
+  lmin = fmaxf(fminf(l1, l2), lmin); lmax = fminf(fmaxf(l1, l2), lmax);
+  /* 1.0000003 * lmax: Ize's robust-traversal padding */
+  return (lmax * 1.0000004f >= 0.0f) && (lmax * 1.0000004f >= lmin) && (lmin <= tmax);
+}
+
+static int closest_hit(v3 o, v3 d, float max_t, const float *tris, int nt, const OrcBvh *bvh,
+                       float *t_hit, int *f_hit) {
+  RayShear sh;
+  ray_shear(d, &sh);
+  float best = max_t;
+  int bf = -1;
+  if (!bvh) {
+    for (int f = 0; f < nt; ++f) {
+      float t;
+      if (ray_tri_woop(o, &sh, tris + 9 * f, &t))
+        if (t >= 0.0f && (t < best || (t == best && bf >= 0 && f < bf))) { best = t; bf = f; }
+    }
+  } else {
+    v3 rcp = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+      const OrcBvhNode *nd = &bvh->nodes[stack[--sp]];
+      if (!ray_box(o, rcp, nd->lo, nd->hi, best)) continue;
+      if (nd->left < 0) {
+        int f = nd->right;
+        float t;
+        if (ray_tri_woop(o, &sh, tris + 9 * f, &t))
+          if (t >= 0.0f && (t < best || (t == best && bf >= 0 && f < bf))) { best = t; bf = f; }
+      } else {
+        stack[sp++] = nd->left;
+        stack[sp++] = nd->right;
+      }
+    }
+  }
+  if (bf < 0) return 0;
+  *t_hit = best;
+  *f_hit = bf;
+  return 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* a21: WarpEnv.reset_idx vertex transform, warp_env_manager.py:40-54  */
+/*  v_world = tf_apply(q_asset, p_asset, v_local) for the triangle soup */
+/*  tri_local [N,T,9], tri_asset [T] (asset index of each triangle),    */
+/*  asset_state [N,K,13] -> tri_world [N,T,9]                           */
+/* ------------------------------------------------------------------ */
+static void tf_apply(const float q[4], const float t[3], const float v[3], float o[3]) {
+  /* utils/math.py:314-320, 375-376 */
+  float c1[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  float tt[3] = {c1[0] * 2.0f, c1[1] * 2.0f, c1[2] * 2.0f};
+  float c2[3] = {q[1] * tt[2] - q[2] * tt[1], q[2] * tt[0] - q[0] * tt[2], q[0] * tt[1] - q[1] * tt[0]};
+  for (int k = 0; k < 3; ++k) o[k] = (v[k] + q[3] * tt[k] + c2[k]) + t[k];
+}
+
+void orc_scene_transform(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset,
+                         const float *asset_state, float *tri_world) {
+  for (int i = 0; i < n; ++i)
+    for (int f = 0; f < nt; ++f) {
+      const float *as = asset_state + ((size_t)i * na + tri_asset[f]) * 13;
+      for (int v = 0; v < 3; ++v)
+        tf_apply(as + 3, as, tri_local + ((size_t)i * nt + f) * 9 + 3 * v,
+                 tri_world + ((size_t)i * nt + f) * 9 + 3 * v);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a22: WarpSensor.update pose composition, warp_sensor.py:177-187     */
+/* ------------------------------------------------------------------ */
+static void quat_mul(const float a[4], const float b[4], float o[4]) {
+  /* utils/math.py:243-263 */
+  float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3];
+  float x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+  float ww = (z1 + x1) * (x2 + y2);
+  float yy = (w1 - y1) * (w2 + z2);
+  float zz = (w1 + y1) * (w2 - z2);
+  float xx = ww + yy + zz;
+  float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+  o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+  o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+  o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+  o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+
+void orc_sensor_pose(int n, int ns, const float *state, const float *local_pos,
+                     const float *local_quat, const float *frame_quat, float *pos, float *quat) {
+  for (int i = 0; i < n; ++i)
+    for (int s = 0; s < ns; ++s) {
+      const float *p = state + 13 * i, *q = p + 3;
+      size_t k = (size_t)i * ns + s;
+      tf_apply(q, p, local_pos + 3 * k, pos + 3 * k);
+      float tmp[4];
+      quat_mul(local_quat + 4 * k, frame_quat, tmp);
+      quat_mul(q, tmp, quat + 4 * k);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* a23: camera kernels, warp_camera_kernels.py:176-282 (depth/range +- */
+/* segmentation) and :13-66,125-172 (pointcloud +- segmentation).      */
+/*  kinv = {K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]}        */
+/*  mode: 0 range, 1 depth, 2 pointcloud (sensor frame), 3 pointcloud  */
+/*        (world frame).  pixels: [N,S,H,W] or [N,S,H,W,3]             */
+/*  seg may be NULL.  tri_seg [N,T] int32 = int(velocities[idx[3f]][0])*/
+/* ------------------------------------------------------------------ */
+void orc_raycast_camera(int n, int ns, int width, int height, const float *kinv, float far_plane,
+                        int c_x, int c_y, int mode, const float *cam_pos, const float *cam_quat,
+                        const float *tris, const int32_t *tri_seg, int nt, int use_bvh,
+                        float *pixels, int32_t *seg) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; ++i) {
+    const float *etris = tris + (size_t)i * nt * 9;
+    OrcBvh bvh = {0, NULL};
+    if (use_bvh) bvh_build(&bvh, etris, nt);
+    for (int s = 0; s < ns; ++s) {
+      const float *cp = cam_pos + ((size_t)i * ns + s) * 3;
+      const float *cq = cam_quat + ((size_t)i * ns + s) * 4;
+      v3 ro = {cp[0], cp[1], cp[2]};
+      v3 uvp = {kinv[0] * (float)c_x + kinv[1], kinv[2] * (float)c_y + kinv[3], 1.0f};
+      if (mode >= 2) uvp = v3_normalize(uvp);
+      v3 rdp = v3_normalize(wp_quat_rotate(cq, uvp));
+      for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+          /* wp.transform_vector(K_inv, (x, y, 1)): K_inv*(x,y,1,0), columns added in order */
+          v3 uv = {kinv[0] * (float)x + kinv[1], kinv[2] * (float)y + kinv[3], 1.0f};
+          if (mode >= 2) uv = v3_normalize(uv);
+          v3 rd = v3_normalize(wp_quat_rotate(cq, uv));
+          float mult = 1.0f;
+          if (mode == 1) mult = v3_dot(rd, rdp);
+          float max_t = (mode <= 1) ? far_plane / mult : far_plane;
+          float dist = NO_HIT_RAY_VAL;
+          int32_t sv = NO_HIT_SEG_VAL;
+          float t;
+          int f;
+          if (closest_hit(ro, rd, max_t, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
+            dist = (mode <= 1) ? mult * t : t;
+            sv = tri_seg[(size_t)i * nt + f];
+          }
+          size_t px = (((size_t)i * ns + s) * height + y) * width + x;
+          if (mode <= 1) {
+            pixels[px] = dist;
+          } else if (mode == 3) {
+            pixels[3 * px + 0] = ro.x + dist * rd.x;
+            pixels[3 * px + 1] = ro.y + dist * rd.y;
+            pixels[3 * px + 2] = ro.z + dist * rd.z;
+          } else {
+            pixels[3 * px + 0] = dist * uv.x;
+            pixels[3 * px + 1] = dist * uv.y;
+            pixels[3 * px + 2] = dist * uv.z;
+          }
+          if (seg) seg[px] = sv;
+        }
+    }
+    if (use_bvh) free(bvh.nodes);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* a24: LiDAR kernels, warp_lidar_kernels.py:167-194,130-163,13-86     */
+/*  ray_vectors [H,W,3] (warp_lidar.py:40-64, see orc_lidar_ray_table) */
+/*  mode: 0 range, 2 pointcloud (sensor frame), 3 pointcloud (world)   */
+/*  (pointcloud+seg: the reference leaves seg uninitialised on a miss, */
+/*   warp_lidar_kernels.py:76-86; we write -2 like every other kernel) */
+/* ------------------------------------------------------------------ */
+void orc_raycast_lidar(int n, int ns, int width, int height, const float *ray_vectors,
+                       float far_plane, int mode, const float *pos, const float *quat,
+                       const float *tris, const int32_t *tri_seg, int nt, int use_bvh,
+                       float *pixels, int32_t *seg) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; ++i) {
+    const float *etris = tris + (size_t)i * nt * 9;
+    OrcBvh bvh = {0, NULL};
+    if (use_bvh) bvh_build(&bvh, etris, nt);
+    for (int s = 0; s < ns; ++s) {
+      const float *lp = pos + ((size_t)i * ns + s) * 3;
+      const float *lq = quat + ((size_t)i * ns + s) * 4;
+      v3 ro = {lp[0], lp[1], lp[2]};
+      for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+          const float *rv = ray_vectors + ((size_t)y * width + x) * 3;
+          v3 dir = {rv[0], rv[1], rv[2]};
+          dir = v3_normalize(dir);
+          v3 rd = v3_normalize(wp_quat_rotate(lq, dir));
+          float dist = NO_HIT_RAY_VAL;
+          int32_t sv = NO_HIT_SEG_VAL;
+          float t;
+          int f;
+          if (closest_hit(ro, rd, far_plane, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
+            dist = t;
+            sv = tri_seg[(size_t)i * nt + f];
+          }
+          size_t px = (((size_t)i * ns + s) * height + y) * width + x;
+          if (mode == 0) {
+            pixels[px] = dist;
+          } else if (mode == 3) {
+            pixels[3 * px + 0] = ro.x + dist * rd.x;
+            pixels[3 * px + 1] = ro.y + dist * rd.y;
+            pixels[3 * px + 2] = ro.z + dist * rd.z;
+          } else {
+            pixels[3 * px + 0] = dist * dir.x;
+            pixels[3 * px + 1] = dist * dir.y;
+            pixels[3 * px + 2] = dist * dir.z;
+          }
+          if (seg) seg[px] = sv;
+        }
+    }
+    if (use_bvh) free(bvh.nodes);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* a25: WarpSensor post-processing, warp_sensor.py:202-247, scalar     */
+/* (range / depth image) case.  z_normal / u_dropout are optional      */
+/* pre-drawn N(0,1) and U(0,1) images (torch owns the RNG).            */
+/* ------------------------------------------------------------------ */
+void orc_sensor_postprocess(size_t count, float *pixels, const float *z_normal,
+                            const float *u_dropout, float std_a, float std_b, float std_c,
+                            float mean_offset, float dropout_prob, float min_range, float max_range,
+                            float far_oor, float near_oor, int normalize) {
+  for (size_t k = 0; k < count; ++k) {
+    float p = pixels[k];
+    if (z_normal) {
+      /* apply_noise: Normal(mean = p - offset, std = a p^2 + b p + c) */
+      float sd = std_a * (p * p) + std_b * p + std_c;
+      p = (p - mean_offset) + sd * z_normal[k];
+      if (u_dropout && u_dropout[k] < dropout_prob) p = near_oor;
+    }
+    /* apply_range_limits: two sequential masked assignments */
+    if (p > max_range) p = far_oor;
+    if (p < min_range) p = near_oor;
+    if (normalize) p = p / max_range;
+    pixels[k] = p;
+  }
+}
