@@ -1,0 +1,66 @@
+"""Builds libaerialgym_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m aerial_gym_simulator_amd._build [--force]
+
+hipcc cross-compiles without a GPU.  The library links only against the HIP runtime;
+nothing from torch crosses the C ABI (include/aerial_gym_hip.h).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libaerialgym_hip.so")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+
+SOURCES = ["agx_api.cpp", "agx_dynamics.hip", "agx_scene.hip", "agx_raycast.hip"]
+# -ffp-contract=off: every + - * / sqrt is one IEEE operation (bit-exact predicates, see
+# DESIGN.md "numerics"); correctly rounded fp32 divide / sqrt is hipcc's default.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-Wno-comment"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "aerial_gym_hip.h"))
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            raise RuntimeError(f"missing source {path}")
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,207 @@
+"""ctypes binding of libaerialgym_hip.so -- the ONLY compute back-end of this package.
+
+There is deliberately no CPU / PyTorch fallback: if the library is missing or a tensor
+does not live on a HIP device, calls fail loudly (RuntimeError).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _build
+
+MAX_MOTORS = 8
+MAX_ACTIONS = 8
+MAX_SUBSTEPS = 32
+
+CTRL_IDS = {
+    "none": 0,
+    "position": 1,
+    "velocity": 2,
+    "attitude": 3,
+    "rates": 4,
+    "acceleration": 5,
+    "velocity_steering": 6,
+    "fully_actuated": 7,
+}
+
+
+class AgxRobotParams(C.Structure):
+    _fields_ = [
+        ("num_motors", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("controller", C.c_int32),
+        ("root_link_mode", C.c_int32),
+        ("dt", C.c_float),
+        ("gravity", C.c_float * 3),
+        ("mass", C.c_float),
+        ("inertia", C.c_float * 9),
+        ("inertia_inv", C.c_float * 9),
+        ("alloc", C.c_float * (6 * MAX_MOTORS)),
+        ("alloc_pinv", C.c_float * (MAX_MOTORS * 6)),
+        ("wrench_map", C.c_float * (6 * MAX_MOTORS)),
+        ("motor_dir", C.c_float * MAX_MOTORS),
+        ("cq", C.c_float),
+        ("use_rps", C.c_int32),
+        ("use_discrete_approximation", C.c_int32),
+        ("integration_rk4", C.c_int32),
+        ("min_thrust", C.c_float),
+        ("max_thrust", C.c_float),
+        ("max_rate", C.c_float),
+        ("max_yaw_rate", C.c_float),
+        ("lin_drag_linear", C.c_float * 3),
+        ("lin_drag_quadratic", C.c_float * 3),
+        ("ang_drag_linear", C.c_float * 3),
+        ("ang_drag_quadratic", C.c_float * 3),
+        ("linear_damping", C.c_float),
+        ("angular_damping", C.c_float),
+        ("max_linear_velocity", C.c_float),
+        ("max_angular_velocity", C.c_float),
+        ("collision_radius", C.c_float),
+    ]
+
+
+class AgxEnvBuffers(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p),
+        ("derived", C.c_void_p),
+        ("actions", C.c_void_p),
+        ("prev_actions", C.c_void_p),
+        ("motor_thrust", C.c_void_p),
+        ("motor_kT", C.c_void_p),
+        ("motor_tau_inc", C.c_void_p),
+        ("motor_tau_dec", C.c_void_p),
+        ("gains", C.c_void_p),
+        ("wrench_cmd", C.c_void_p),
+        ("crashes", C.c_void_p),
+        ("truncations", C.c_void_p),
+        ("sim_steps", C.c_void_p),
+        ("reset_mask", C.c_void_p),
+        ("reset_flag", C.c_void_p),
+        ("bounds_min", C.c_void_p),
+        ("bounds_max", C.c_void_p),
+        ("disturb", C.c_void_p),
+        ("disturb_max", C.c_float * 6),
+        ("boxes", C.c_void_p),
+        ("num_boxes", C.c_int32),
+    ]
+
+
+class AgxResetArgs(C.Structure):
+    _fields_ = [
+        ("u_bounds_lo", C.c_void_p),
+        ("u_bounds_hi", C.c_void_p),
+        ("u_state", C.c_void_p),
+        ("u_gains", C.c_void_p),
+        ("u_tau_inc", C.c_void_p),
+        ("u_tau_dec", C.c_void_p),
+        ("u_thrust", C.c_void_p),
+        ("u_kT", C.c_void_p),
+        ("lower_bound_min", C.c_float * 3),
+        ("lower_bound_max", C.c_float * 3),
+        ("upper_bound_min", C.c_float * 3),
+        ("upper_bound_max", C.c_float * 3),
+        ("min_state", C.c_float * 13),
+        ("max_state", C.c_float * 13),
+        ("gains_min", C.c_float * 12),
+        ("gains_max", C.c_float * 12),
+        ("tau_inc_min", C.c_float),
+        ("tau_inc_max", C.c_float),
+        ("tau_dec_min", C.c_float),
+        ("tau_dec_max", C.c_float),
+        ("kT_min", C.c_float),
+        ("kT_max", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "agx_last_error": (C.c_char_p, []),
+    "agx_abi_version": (C.c_int, []),
+    "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
+    "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),
+    "agx_controller_wrench": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, _P]),
+    "agx_reward_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "agx_obs_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P]),
+    "agx_reward_navigation": (
+        C.c_int,
+        [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.POINTER(C.c_float), C.c_float, _P, _P, C.c_int, C.c_int, _P, _P],
+    ),
+    "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
+    "agx_scene_transform": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "agx_bvh_nodes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
+    "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "agx_sensor_pose": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "agx_raycast_camera": (
+        C.c_int,
+        [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
+         C.c_int, _P, _P, _P],
+    ),
+    "agx_raycast_lidar": (
+        C.c_int,
+        [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P],
+    ),
+    "agx_sensor_postprocess": (
+        C.c_int,
+        [C.c_size_t, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+         C.c_float, C.c_int, _P],
+    ),
+    "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load the HIP library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found. Build it with `python -m aerial_gym_simulator_amd._build` "
+            "(needs hipcc); this package has no CPU or PyTorch fallback."
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
+        fn.restype = res
+        fn.argtypes = args
+    if lib.agx_abi_version() != 1:
+        raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = load().agx_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'agx call'} failed ({code}): {msg}")
+
+
+def dptr(t):
+    """Raw device pointer of a tensor that MUST live on a HIP device and be dense."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(
+            "aerial_gym_simulator_amd kernels need tensors on a HIP device (got %s): there is no CPU fallback" % t.device
+        )
+    if not t.is_contiguous():
+        raise RuntimeError("tensor handed to the HIP library must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

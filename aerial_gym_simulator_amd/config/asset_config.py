@@ -1,0 +1,72 @@
+"""Obstacle (asset) descriptions.
+
+Every obstacle the reference ships for `env_with_obstacles` is a single-link URDF box
+(resources/models/environment_assets/{panels,objects,walls}/*.urdf), so an asset type is
+described here by its box sizes + the placement ranges of
+aerial_gym/config/asset_config/env_object_config.py.  URDF/mesh ingestion is out of scope
+(SURVEY.md section 8 f3).
+"""
+import numpy as np
+
+_PI = float(np.pi)
+
+PANEL_SEMANTIC_ID = 20
+FRONT_WALL_SEMANTIC_ID, BACK_WALL_SEMANTIC_ID = 9, 10
+LEFT_WALL_SEMANTIC_ID, RIGHT_WALL_SEMANTIC_ID = 11, 12
+BOTTOM_WALL_SEMANTIC_ID, TOP_WALL_SEMANTIC_ID = 13, 14
+
+
+def _ratio(lo_xyz, hi_xyz, lo_rpy=(0.0, 0.0, 0.0), hi_rpy=(0.0, 0.0, 0.0)):
+    tail = [1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    return list(lo_xyz) + list(lo_rpy) + tail, list(hi_xyz) + list(hi_rpy) + tail
+
+
+class asset_state_params:
+    num_assets = 1
+    box_sizes = [[1.0, 1.0, 1.0]]  # one entry is picked per instance (uniformly, python `random`)
+    random_box_size_range = None   # or ([lo xyz], [hi xyz]): sizes drawn per instance
+    keep_in_env = False
+    semantic_id = -1               # < 0: assigned incrementally per instance (from 100)
+    min_state_ratio, max_state_ratio = _ratio([0.5] * 3, [0.5] * 3)
+    color = None
+
+
+class panel_asset_params(asset_state_params):  # env_object_config.py:65-120, panels/panel.urdf
+    num_assets = 3
+    box_sizes = [[0.1, 1.2, 3.0]]
+    keep_in_env = True
+    min_state_ratio, max_state_ratio = _ratio([0.3, 0.05, 0.05], [0.85, 0.95, 0.95], (0, 0, -_PI / 3), (0, 0, _PI / 3))
+    color = [170, 66, 66]
+
+
+class object_asset_params(asset_state_params):  # env_object_config.py:273-312, objects/*.urdf
+    num_assets = 35
+    box_sizes = [[0.1, 0.5, 0.5], [0.1, 1.0, 1.0], [0.1, 0.1, 2.0], [0.4, 0.4, 0.4]]
+    keep_in_env = False
+    min_state_ratio, max_state_ratio = _ratio([0.30, 0.05, 0.05], [0.85, 0.9, 0.9], (-_PI,) * 3, (_PI,) * 3)
+
+
+class random_box_asset_params(asset_state_params):
+    """Synthetic obstacle set of BASELINE config 3/4: 100 boxes,
+    every side U(0.1, 1.2) m, centre anywhere in the bounds, yaw U(-pi, pi)."""
+
+    num_assets = 100
+    box_sizes = None
+    random_box_size_range = ([0.1, 0.1, 0.1], [1.2, 1.2, 1.2])
+    keep_in_env = False
+    min_state_ratio, max_state_ratio = _ratio([0.0, 0.0, 0.0], [1.0, 1.0, 1.0], (0, 0, -_PI), (0, 0, _PI))
+
+
+def _wall(name, size, ratio_xyz, sem_id):
+    lo, hi = _ratio(ratio_xyz, ratio_xyz)
+    return type(name, (asset_state_params,), dict(num_assets=1, box_sizes=[size], keep_in_env=True, semantic_id=sem_id,
+                                                  min_state_ratio=lo, max_state_ratio=hi, color=[100, 200, 210]))
+
+
+# env_object_config.py:316-598 and walls/*.urdf
+left_wall = _wall("left_wall", [20.0, 0.2, 20.0], [0.5, 1.0, 0.5], LEFT_WALL_SEMANTIC_ID)
+right_wall = _wall("right_wall", [20.0, 0.2, 20.0], [0.5, 0.0, 0.5], RIGHT_WALL_SEMANTIC_ID)
+top_wall = _wall("top_wall", [20.0, 20.0, 0.2], [0.5, 0.5, 1.0], TOP_WALL_SEMANTIC_ID)
+bottom_wall = _wall("bottom_wall", [20.0, 20.0, 0.2], [0.5, 0.5, 0.0], BOTTOM_WALL_SEMANTIC_ID)
+front_wall = _wall("front_wall", [0.2, 20.0, 20.0], [1.0, 0.5, 0.5], FRONT_WALL_SEMANTIC_ID)
+back_wall = _wall("back_wall", [0.2, 20.0, 20.0], [0.0, 0.5, 0.5], BACK_WALL_SEMANTIC_ID)

@@ -1,0 +1,73 @@
+"""Environment configs (aerial_gym/config/env_config/{empty_env,env_with_obstacles}.py)."""
+from . import asset_config as A
+
+
+class EmptyEnvCfg:
+    class env:
+        num_envs = 3
+        num_env_actions = 0
+        env_spacing = 1.0
+        num_physics_steps_per_env_step_mean = 1
+        num_physics_steps_per_env_step_std = 0
+        render_viewer_every_n_steps = 10
+        collision_force_threshold = 0.010
+        manual_camera_trigger = False
+        reset_on_collision = True
+        create_ground_plane = False
+        sample_timestep_for_latency = True
+        perturb_observations = True
+        keep_same_env_for_num_episodes = 1
+        write_to_sim_at_every_timestep = False
+        use_warp = False
+        e_s = env_spacing
+        lower_bound_min = lower_bound_max = [-e_s, -e_s, -e_s]
+        upper_bound_min = upper_bound_max = [e_s, e_s, e_s]
+
+    class env_config:
+        include_asset_type = {}
+        asset_type_to_dict_map = {}
+
+
+_WALLS = {
+    "left_wall": A.left_wall,
+    "right_wall": A.right_wall,
+    "back_wall": A.back_wall,
+    "front_wall": A.front_wall,
+    "bottom_wall": A.bottom_wall,
+    "top_wall": A.top_wall,
+}
+
+
+class EnvWithObstaclesCfg:
+    class env:
+        num_envs = 64
+        num_env_actions = 4
+        env_spacing = 5.0
+        num_physics_steps_per_env_step_mean = 10
+        num_physics_steps_per_env_step_std = 0
+        render_viewer_every_n_steps = 1
+        reset_on_collision = True
+        collision_force_threshold = 0.05
+        create_ground_plane = False
+        sample_timestep_for_latency = True
+        perturb_observations = True
+        keep_same_env_for_num_episodes = 1
+        write_to_sim_at_every_timestep = False
+        use_warp = True
+        lower_bound_min, lower_bound_max = [-2.0, -4.0, -3.0], [-1.0, -2.5, -2.0]
+        upper_bound_min, upper_bound_max = [9.0, 2.5, 2.0], [10.0, 4.0, 3.0]
+
+    class env_config:
+        include_asset_type = dict({"panels": True, "objects": True}, **{k: True for k in _WALLS})
+        asset_type_to_dict_map = dict({"panels": A.panel_asset_params, "objects": A.object_asset_params}, **_WALLS)
+
+
+class EnvWithRandomBoxesCfg(EnvWithObstaclesCfg):
+    """BASELINE configs 3-5: 100 random boxes + the 6 wall slabs."""
+
+    class env(EnvWithObstaclesCfg.env):
+        pass
+
+    class env_config:
+        include_asset_type = dict({"boxes": True}, **{k: True for k in _WALLS})
+        asset_type_to_dict_map = dict({"boxes": A.random_box_asset_params}, **_WALLS)

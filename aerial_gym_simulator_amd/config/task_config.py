@@ -1,0 +1,93 @@
+"""Task configs (aerial_gym/config/task_config/{position_setpoint,navigation}_task_config.py)."""
+import torch
+
+
+class position_setpoint_task_config:
+    seed = 1
+    sim_name = "base_sim"
+    env_name = "empty_env"
+    robot_name = "base_quadrotor"
+    controller_name = "lee_attitude_control"
+    args = {}
+    num_envs = 4096
+    use_warp = False
+    headless = True
+    device = "cuda:0"
+    observation_space_dim = 13
+    privileged_observation_space_dim = 0
+    action_space_dim = 4
+    episode_len_steps = 500
+    return_state_before_reset = False
+    reward_parameters = {}  # the reference's table is unused by its compute_reward (hard-coded constants)
+
+
+class navigation_task_config:
+    seed = -1
+    sim_name = "base_sim"
+    env_name = "env_with_random_boxes"
+    robot_name = "base_quadrotor_with_camera_64x48"
+    controller_name = "lee_velocity_control"
+    args = {}
+    num_envs = 1024
+    use_warp = True
+    headless = True
+    device = "cuda:0"
+    # the reference packs 13 + 4 state/action entries + 64 VAE latents; the VAE encoder is a
+    # dense conv net outside the simulation hot path, so `use_vae = False` gives 17 + pooled depth
+    observation_space_dim = 13 + 4 + 64
+    privileged_observation_space_dim = 0
+    action_space_dim = 4
+    episode_len_steps = 100
+    return_state_before_reset = False
+    target_min_ratio = [0.90, 0.1, 0.1]
+    target_max_ratio = [0.94, 0.90, 0.90]
+
+    reward_parameters = {
+        "pos_reward_magnitude": 5.0,
+        "pos_reward_exponent": 1.0 / 3.5,
+        "very_close_to_goal_reward_magnitude": 5.0,
+        "very_close_to_goal_reward_exponent": 2.0,
+        "getting_closer_reward_multiplier": 10.0,
+        "x_action_diff_penalty_magnitude": 0.8,
+        "x_action_diff_penalty_exponent": 3.333,
+        "z_action_diff_penalty_magnitude": 0.8,
+        "z_action_diff_penalty_exponent": 5.0,
+        "yawrate_action_diff_penalty_magnitude": 0.8,
+        "yawrate_action_diff_penalty_exponent": 3.33,
+        "x_absolute_action_penalty_magnitude": 0.1,
+        "x_absolute_action_penalty_exponent": 0.3,
+        "z_absolute_action_penalty_magnitude": 1.5,
+        "z_absolute_action_penalty_exponent": 1.0,
+        "yawrate_absolute_action_penalty_magnitude": 1.5,
+        "yawrate_absolute_action_penalty_exponent": 2.0,
+        "collision_penalty": -100.0,
+    }
+    REWARD_PARAMETER_ORDER = tuple(reward_parameters.keys())
+
+    class vae_config:
+        use_vae = False
+        latent_dims = 64  # min-pooled 8x8 depth grid takes the latents' place (see navigation_task.py here)
+        image_res = (270, 480)
+        interpolation_mode = "nearest"
+        return_sampled_latent = True
+
+    class curriculum:
+        min_level = 15
+        max_level = 50
+        check_after_log_instances = 2048
+        increase_step = 2
+        decrease_step = 1
+        success_rate_for_increase = 0.7
+        success_rate_for_decrease = 0.6
+
+    @staticmethod
+    def action_transformation_function(action):
+        """navigation_task_config.py:87-117: (speed, inclination, yaw-rate) -> velocity command."""
+        a = torch.clamp(action, -1.0, 1.0)
+        max_speed, max_yawrate, max_inclination = 2.0, torch.pi / 3, torch.pi / 4
+        speed = a[:, 0] + 1.0
+        out = torch.zeros((a.shape[0], 4), device=a.device)
+        out[:, 0] = speed * torch.cos(max_inclination * a[:, 1]) * max_speed / 2.0
+        out[:, 2] = speed * torch.sin(max_inclination * a[:, 1]) * max_speed / 2.0
+        out[:, 3] = a[:, 2] * max_yawrate
+        return out

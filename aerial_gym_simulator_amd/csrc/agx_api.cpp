@@ -1,0 +1,19 @@
+// Error plumbing of the C ABI (no device code here).
+#include "agx_common.h"
+
+namespace agx {
+char *error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace agx
+
+extern "C" const char *agx_last_error(void) { return agx::error_buffer(); }
+extern "C" int agx_abi_version(void) { return AGX_ABI_VERSION; }

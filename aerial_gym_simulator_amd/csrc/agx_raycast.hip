@@ -1,0 +1,430 @@
+// Ray-cast depth / range / segmentation / point-cloud sensors for gfx950.
+//
+// Replaces the Warp kernels of aerial_gym/sensors/warp/warp_kernels/{warp_camera_kernels,
+// warp_lidar_kernels}.py and wp.mesh_query_ray.  Design (CDNA4-first, not a Warp port):
+//
+//   * one workgroup per (env, sensor); the env's BVH nodes (64 B each, both child boxes
+//     inline) and triangles (36 B each) are staged ONCE into LDS (<= 160 KiB / CU) with
+//     16-byte coalesced loads, so HBM sees each scene exactly once per frame;
+//   * a wavefront (64 lanes) owns an 8x8 pixel tile and walks the tree as ONE packet:
+//     every node fetch is a wave-uniform LDS broadcast, lanes vote with __ballot on which
+//     children to visit and in which order (majority near-first), and the packet's
+//     traversal stack lives in ONE VGPR spread over the 64 lanes (entry k in lane k,
+//     pushed with a lane-select v_cndmask, popped with v_readlane) -- no per-lane stacks, no scratch,
+//     no divergent control flow;
+//   * pixels are written [env, cam, y, x] with x fastest inside each 8-wide tile row
+//     (the reference's (x, y) thread order gives stride-W stores);
+//   * exactness: ray/triangle uses Warp's watertight Woop test incl. its fmaf-compensated
+//     edge functions and fp64 fallback; closest hit keeps the smallest (t, face) pair, so
+//     the result is independent of traversal order and bit-identical to a brute-force
+//     loop over all triangles (oracle/oracle_raycast.c).
+//
+// No MFMA: traversal is branchy gather work; the bound is LDS latency / VALU, with HBM
+// traffic = scene + image bytes (DESIGN.md "ray-cast roofline").
+#include "agx_common.h"
+#include "agx_device_math.h"
+
+namespace agx {
+
+constexpr int kRayThreads = 512;  // 8 waves per workgroup
+constexpr int kStackDepth = 64;
+constexpr float kNoHitRay = 1000.0f;  // warp_camera_kernels.py:3
+constexpr int kNoHitSeg = -2;         // warp_camera_kernels.py:4
+
+// warp quat.h quat_rotate
+AGX_DEV V3 wp_quat_rotate(Q4 q, V3 x) {
+  float c = 2.0f * q.w * q.w - 1.0f;
+  float d = 2.0f * (q.x * x.x + q.y * x.y + q.z * x.z);
+  return V3{x.x * c + q.x * d + (q.y * x.z - q.z * x.y) * q.w * 2.0f, x.y * c + q.y * d + (q.z * x.x - q.x * x.z) * q.w * 2.0f,
+            x.z * c + q.z * d + (q.x * x.y - q.y * x.x) * q.w * 2.0f};
+}
+// warp vec.h normalize
+AGX_DEV V3 wp_normalize(V3 a) {
+  float l = sqrtf(dot(a, a));
+  if (l > 0.0f) return V3{a.x / l, a.y / l, a.z / l};
+  return V3{0.0f, 0.0f, 0.0f};
+}
+// warp intersect.h diff_product
+AGX_DEV float diff_product(float a, float b, float c, float d) {
+  float cd = c * d;
+  float diff = fmaf(a, b, -cd);
+  float error = fmaf(-c, d, cd);
+  return diff + error;
+}
+
+struct Ray {
+  V3 o, d, rcp;
+  int kz;     // dominant axis
+  bool swap;  // d[kz] < 0 : kx/ky swapped
+  float Sx, Sy, Sz;
+  float best;
+  int face;
+  bool active;
+};
+
+AGX_DEV float pick(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
+  r.o = o;
+  r.d = d;
+  r.rcp = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+  int kx = kz == 2 ? 0 : kz + 1;
+  int ky = kx == 2 ? 0 : kx + 1;
+  float dz = pick(d, kz);
+  r.swap = dz < 0.0f;
+  if (r.swap) { int t = kx; kx = ky; ky = t; }
+  r.kz = kz;
+  r.Sx = pick(d, kx) / dz;
+  r.Sy = pick(d, ky) / dz;
+  r.Sz = 1.0f / dz;
+  r.best = max_t;
+  r.face = -1;
+  r.active = active;
+}
+
+// warp intersect.h intersect_ray_tri_woop (t only)
+AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
+  V3 A = a - r.o, B = b - r.o, C = c - r.o;
+  int kz = r.kz;
+  int kx = kz == 2 ? 0 : kz + 1;
+  int ky = kx == 2 ? 0 : kx + 1;
+  if (r.swap) { int t = kx; kx = ky; ky = t; }
+  float Akz = pick(A, kz), Bkz = pick(B, kz), Ckz = pick(C, kz);
+  float Ax = pick(A, kx) - r.Sx * Akz, Ay = pick(A, ky) - r.Sy * Akz;
+  float Bx = pick(B, kx) - r.Sx * Bkz, By = pick(B, ky) - r.Sy * Bkz;
+  float Cx = pick(C, kx) - r.Sx * Ckz, Cy = pick(C, ky) - r.Sy * Ckz;
+  float U = diff_product(Cx, By, Cy, Bx);
+  float V = diff_product(Ax, Cy, Ay, Cx);
+  float W = diff_product(Bx, Ay, By, Ax);
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+    U = (float)(CxBy - CyBx);
+    double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+    V = (float)(AxCy - AyCx);
+    double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+    W = (float)(BxAy - ByAx);
+  }
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  float det = U + V + W;
+  if (det == 0.0f) return false;
+  float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+  float T = U * Az + V * Bz + W * Cz;
+  uint32_t ds = __float_as_uint(det) & 0x80000000u;
+  if (__uint_as_float(__float_as_uint(T) ^ ds) < 0.0f) return false;
+  float rcp = 1.0f / det;
+  t_out = T * rcp;
+  return true;
+}
+
+AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want) {
+  if (!want) return;
+  const float *t = tris + (size_t)f * 9;
+  float th;
+  if (ray_tri(r, V3{t[0], t[1], t[2]}, V3{t[3], t[4], t[5]}, V3{t[6], t[7], t[8]}, th)) {
+    if (th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
+      r.best = th;
+      r.face = f;
+    }
+  }
+}
+
+// conservative slab test (boxes are already grown by kBoxEps at build time)
+AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tnear) {
+  float t0 = (lx - r.o.x) * r.rcp.x, t1 = (hx - r.o.x) * r.rcp.x;
+  float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
+  t0 = (ly - r.o.y) * r.rcp.y; t1 = (hy - r.o.y) * r.rcp.y;
+  tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+  t0 = (lz - r.o.z) * r.rcp.z; t1 = (hz - r.o.z) * r.rcp.z;
+  tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+  tmax *= 1.0000004f;
+  tnear = tmin;
+  return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+}
+
+// Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
+// holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
+AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  if (nt == 1) {
+    test_leaf(r, tris, 0, r.active);
+    return;
+  }
+  int sp = 0;
+  int node = 0;
+  int stack = 0;
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 16);
+    float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+    int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
+    float tl, tr;
+    bool hl = ray_box(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
+    bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+    if (cl < 0) {
+      if (ml) test_leaf(r, tris, ~cl, hl);
+      ml = 0;
+    }
+    if (cr < 0) {
+      if (mr) test_leaf(r, tris, ~cr, hr);
+      mr = 0;
+    }
+    int next = -1;
+    if (ml && mr) {
+      // majority vote on which child is nearer among lanes that hit both
+      unsigned long long both = __ballot(hl && hr);
+      unsigned long long lfirst = __ballot(hl && hr && tl <= tr);
+      bool left_first = both ? (2 * __popcll(lfirst) >= __popcll(both)) : (__popcll(ml) >= __popcll(mr));
+      next = left_first ? cl : cr;
+      int far = left_first ? cr : cl;
+      stack = (lane == (sp & (kStackDepth - 1))) ? far : stack;  // push: entry sp lives in lane sp
+      ++sp;
+    } else if (ml) {
+      next = cl;
+    } else if (mr) {
+      next = cr;
+    }
+    if (next < 0) {
+      if (sp == 0) break;
+      --sp;
+      next = __builtin_amdgcn_readlane(stack, sp & (kStackDepth - 1));
+    }
+    node = __builtin_amdgcn_readfirstlane(next);
+  }
+}
+
+struct CamArgs {
+  int n, ns, width, height;
+  float k00, k02, k11, k12;
+  float far_plane;
+  int c_x, c_y, mode;
+};
+
+struct LidarArgs {
+  int n, ns, width, height;
+  float far_plane;
+  int mode;
+};
+
+template <bool LIDAR, bool USE_LDS>
+__global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
+                                                          const float *__restrict__ sensor_pos,
+                                                          const float *__restrict__ sensor_quat,
+                                                          const float *__restrict__ tri_world,
+                                                          const int32_t *__restrict__ tri_seg,
+                                                          const float *__restrict__ nodes_g, int nt,
+                                                          float *__restrict__ pixels, int32_t *__restrict__ seg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = blockIdx.x, s = blockIdx.y;
+  const int ns = LIDAR ? LA.ns : CA.ns;
+  const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
+  const int mode = LIDAR ? LA.mode : CA.mode;
+  const float far_plane = LIDAR ? LA.far_plane : CA.far_plane;
+  const int n_nodes = nt - 1;
+  const float *g_nodes = nodes_g + (size_t)env * n_nodes * 16;
+  const float *g_tris = tri_world + (size_t)env * nt * 9;
+  const float *nodes = g_nodes, *tris = g_tris;
+  if (USE_LDS) {
+    float *l_nodes = reinterpret_cast<float *>(smem);
+    float *l_tris = l_nodes + (size_t)n_nodes * 16;
+    // 16-byte coalesced staging (node block is 64 B aligned, triangle block 4-float padded)
+    const float4 *src = reinterpret_cast<const float4 *>(g_nodes);
+    float4 *dst = reinterpret_cast<float4 *>(l_nodes);
+    for (int i = threadIdx.x; i < n_nodes * 4; i += kRayThreads) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nt * 9; i += kRayThreads) l_tris[i] = g_tris[i];
+    __syncthreads();
+    nodes = l_nodes;
+    tris = l_tris;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t sidx = (size_t)env * ns + s;
+  const V3 ro = V3{sensor_pos[sidx * 3], sensor_pos[sidx * 3 + 1], sensor_pos[sidx * 3 + 2]};
+  const Q4 sq = Q4{sensor_quat[sidx * 4], sensor_quat[sidx * 4 + 1], sensor_quat[sidx * 4 + 2], sensor_quat[sidx * 4 + 3]};
+  V3 rdp = V3{0, 0, 0};
+  if (!LIDAR) {
+    V3 uvp = V3{CA.k00 * (float)CA.c_x + CA.k02, CA.k11 * (float)CA.c_y + CA.k12, 1.0f};
+    if (mode >= AGX_RAY_POINTCLOUD) uvp = wp_normalize(uvp);
+    rdp = wp_normalize(wp_quat_rotate(sq, uvp));
+  }
+  const int tiles_x = (width + 7) >> 3, tiles_y = (height + 7) >> 3;
+  for (int tile = wave; tile < tiles_x * tiles_y; tile += kRayThreads / 64) {
+    const int x = (tile % tiles_x) * 8 + (lane & 7), y = (tile / tiles_x) * 8 + (lane >> 3);
+    const bool active = x < width && y < height;
+    V3 local = V3{0.0f, 0.0f, 1.0f};
+    if (active) {
+      if (LIDAR) {
+        const float *rv = ray_vectors + ((size_t)y * width + x) * 3;
+        local = wp_normalize(V3{rv[0], rv[1], rv[2]});
+      } else {
+        // wp.transform_vector(K_inv, (x, y, 1)) (warp_camera_kernels.py:199-200)
+        local = V3{CA.k00 * (float)x + CA.k02, CA.k11 * (float)y + CA.k12, 1.0f};
+        if (mode >= AGX_RAY_POINTCLOUD) local = wp_normalize(local);
+      }
+    }
+    V3 rd = wp_normalize(wp_quat_rotate(sq, local));
+    float mult = 1.0f;
+    if (!LIDAR && mode == AGX_RAY_DEPTH) mult = dot(rd, rdp);
+    float max_t = (!LIDAR && mode <= AGX_RAY_DEPTH) ? far_plane / mult : far_plane;
+    Ray r;
+    ray_setup(r, ro, rd, max_t, active);
+    traverse(r, nodes, tris, nt);
+    if (active) {
+      float dist = kNoHitRay;
+      int sv = kNoHitSeg;
+      if (r.face >= 0) {
+        dist = (!LIDAR && mode <= AGX_RAY_DEPTH) ? mult * r.best : r.best;
+        if (seg) sv = tri_seg[(size_t)env * nt + r.face];
+      }
+      const size_t px = ((sidx * height) + y) * width + x;
+      if (mode <= AGX_RAY_DEPTH) {
+        pixels[px] = dist;
+      } else if (mode == AGX_RAY_POINTCLOUD_WORLD) {
+        pixels[3 * px] = ro.x + dist * rd.x;
+        pixels[3 * px + 1] = ro.y + dist * rd.y;
+        pixels[3 * px + 2] = ro.z + dist * rd.z;
+      } else {
+        pixels[3 * px] = dist * local.x;
+        pixels[3 * px + 1] = dist * local.y;
+        pixels[3 * px + 2] = dist * local.z;
+      }
+      if (seg) seg[px] = sv;
+    }
+  }
+}
+
+// WarpSensor.update pose composition (warp_sensor.py:177-187)
+__global__ void __launch_bounds__(256) k_sensor_pose(AgxEnvBuffers B, int n, int ns, const float *__restrict__ local_pos,
+                                                      const float *__restrict__ local_quat, Q4 frame_quat,
+                                                      float *__restrict__ pos, float *__restrict__ quat) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * ns) return;
+  const int i = idx / ns;
+  const V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
+  const Q4 q = Q4{B.state[3 * n + i], B.state[4 * n + i], B.state[5 * n + i], B.state[6 * n + i]};
+  const float *lp = local_pos + (size_t)idx * 3, *lq = local_quat + (size_t)idx * 4;
+  V3 sp = tf_apply(q, p, V3{lp[0], lp[1], lp[2]});
+  Q4 sq = quat_mul(q, quat_mul(Q4{lq[0], lq[1], lq[2], lq[3]}, frame_quat));
+  pos[(size_t)idx * 3] = sp.x; pos[(size_t)idx * 3 + 1] = sp.y; pos[(size_t)idx * 3 + 2] = sp.z;
+  quat[(size_t)idx * 4] = sq.x; quat[(size_t)idx * 4 + 1] = sq.y; quat[(size_t)idx * 4 + 2] = sq.z; quat[(size_t)idx * 4 + 3] = sq.w;
+}
+
+// WarpSensor.apply_noise / apply_range_limits / normalize_observation (warp_sensor.py:202-247)
+__global__ void __launch_bounds__(256) k_sensor_postprocess(size_t count, float *__restrict__ pixels,
+                                                             const float *__restrict__ z_normal,
+                                                             const float *__restrict__ u_dropout, float std_a, float std_b,
+                                                             float std_c, float mean_offset, float dropout_prob,
+                                                             float min_range, float max_range, float far_oor, float near_oor,
+                                                             int normalize) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (size_t)gridDim.x * blockDim.x) {
+    float p = pixels[k];
+    if (z_normal) {
+      float sd = std_a * (p * p) + std_b * p + std_c;
+      p = (p - mean_offset) + sd * z_normal[k];
+      if (u_dropout && u_dropout[k] < dropout_prob) p = near_oor;
+    }
+    if (p > max_range) p = far_oor;
+    if (p < min_range) p = near_oor;
+    if (normalize) p = p / max_range;
+    pixels[k] = p;
+  }
+}
+
+// NavigationTask.post_image_reward_addition (navigation_task.py:351-357): per-env min of 10*img
+// with negative pixels replaced by 10.  One wave per env.
+__global__ void __launch_bounds__(256) k_image_min(int n, int ppe, const float *__restrict__ pixels, float *__restrict__ out) {
+  const int env = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (env >= n) return;
+  const int lane = threadIdx.x & 63;
+  float m = INFINITY;
+  for (int k = lane; k < ppe; k += 64) {
+    float v = 10.0f * pixels[(size_t)env * ppe + k];
+    if (v < 0.0f) v = 10.0f;
+    m = fminf(m, v);
+  }
+  for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+  if (lane == 0) out[env] = m;
+}
+
+static size_t ray_lds_bytes(int nt) {
+  return (size_t)(nt - 1) * 64 + (size_t)nt * 36 + 16;
+}
+
+template <bool LIDAR>
+static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *ray_vectors, const float *pos, const float *quat,
+                          const float *tri_world, const int32_t *tri_seg, const float *nodes, int nt, float *pixels,
+                          int32_t *seg, void *stream) {
+  const int n = LIDAR ? LA.n : CA.n, ns = LIDAR ? LA.ns : CA.ns;
+  size_t lds = ray_lds_bytes(nt);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_raycast<LIDAR, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(n, ns);
+  if (lds <= 160 * 1024) {
+    hipLaunchKernelGGL((k_raycast<LIDAR, true>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors, pos,
+                       quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+  } else {  // scene does not fit LDS: traverse from L2 / HBM
+    hipLaunchKernelGGL((k_raycast<LIDAR, false>), grid, dim3(kRayThreads), 0,
+                       (hipStream_t)stream, CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+  }
+  return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
+}
+
+}  // namespace agx
+
+using namespace agx;
+
+extern "C" int agx_sensor_pose(const AgxEnvBuffers *B, int n, int ns, const float *local_pos, const float *local_quat,
+                               const float *frame_quat, float *pos, float *quat, void *stream) {
+  AGX_REQUIRE(B && B->state && n > 0 && ns > 0, "bad arguments");
+  AGX_REQUIRE(local_pos && local_quat && frame_quat && pos && quat, "null buffer");
+  Q4 fq = Q4{frame_quat[0], frame_quat[1], frame_quat[2], frame_quat[3]};  // HOST pointer: 4 config scalars
+  hipLaunchKernelGGL(k_sensor_pose, dim3(blocks_for(n * ns, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, ns, local_pos,
+                     local_quat, fq, pos, quat);
+  return check_launch("agx_sensor_pose");
+}
+
+extern "C" int agx_raycast_camera(int n, int ns, int width, int height, const float *kinv, float far_plane, int c_x, int c_y,
+                                  int mode, const float *cam_pos, const float *cam_quat, const float *tri_world,
+                                  const int32_t *tri_seg, const float *nodes, int nt, float *pixels, int32_t *seg,
+                                  void *stream) {
+  AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
+  AGX_REQUIRE(mode >= AGX_RAY_RANGE && mode <= AGX_RAY_POINTCLOUD_WORLD, "bad mode %d", mode);
+  AGX_REQUIRE(kinv && cam_pos && cam_quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
+  AGX_REQUIRE(!seg || tri_seg, "segmentation output needs tri_seg");
+  CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode};  // kinv: HOST pointer
+  LidarArgs LA{};
+  return launch_raycast<false>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+}
+
+extern "C" int agx_raycast_lidar(int n, int ns, int width, int height, const float *ray_vectors, float far_plane, int mode,
+                                 const float *pos, const float *quat, const float *tri_world, const int32_t *tri_seg,
+                                 const float *nodes, int nt, float *pixels, int32_t *seg, void *stream) {
+  AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
+  AGX_REQUIRE(mode == AGX_RAY_RANGE || mode == AGX_RAY_POINTCLOUD || mode == AGX_RAY_POINTCLOUD_WORLD, "bad mode %d", mode);
+  AGX_REQUIRE(ray_vectors && pos && quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
+  AGX_REQUIRE(!seg || tri_seg, "segmentation output needs tri_seg");
+  CamArgs CA{};
+  LidarArgs LA{n, ns, width, height, far_plane, mode};
+  return launch_raycast<true>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+}
+
+extern "C" int agx_sensor_postprocess(size_t count, float *pixels, const float *z_normal, const float *u_dropout, float std_a,
+                                      float std_b, float std_c, float mean_offset, float dropout_prob, float min_range,
+                                      float max_range, float far_oor, float near_oor, int normalize, void *stream) {
+  AGX_REQUIRE(pixels && count > 0, "null buffer");
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(k_sensor_postprocess, dim3(blocks), dim3(256), 0, (hipStream_t)stream, count, pixels, z_normal, u_dropout,
+                     std_a, std_b, std_c, mean_offset, dropout_prob, min_range, max_range, far_oor, near_oor, normalize);
+  return check_launch("agx_sensor_postprocess");
+}
+
+extern "C" int agx_image_min(int n, int ppe, const float *pixels, float *min_pixel, void *stream) {
+  AGX_REQUIRE(n > 0 && ppe > 0 && pixels && min_pixel, "bad arguments");
+  hipLaunchKernelGGL(k_image_min, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, n, ppe, pixels, min_pixel);
+  return check_launch("agx_image_min");
+}

@@ -1,0 +1,271 @@
+// Scene kernels for gfx950: vertex transform at reset, obstacle OBBs for the collision
+// test, and an LBVH built per env entirely in LDS (one workgroup per env).
+//
+// These replace WarpEnv.reset_idx's tf_apply over all vertices + per-env wp.Mesh.refit()
+// (warp_env_manager.py:40-54) and the wp.Mesh BVH build (warp_env_manager.py:162-166).
+// Warp only REFITS the boxes of its initial topology after obstacles were moved; here the
+// tree is rebuilt from the new positions (Morton order), which keeps traversal tight.
+//
+// The BVH is a pure accelerator: the ray-cast result is defined over all triangles with
+// a (t, face-index) tie-break (see oracle/oracle_raycast.c), so any topology is valid as
+// long as node boxes are conservative -- they are grown by kBoxEps like Warp's 1e-3.
+#include "agx_common.h"
+#include "agx_device_math.h"
+
+namespace agx {
+
+constexpr float kBoxEps = 1.0e-3f;
+constexpr int kBvhThreads = 256;
+constexpr int kBvhMaxTris = 2048;
+
+__global__ void __launch_bounds__(256) k_scene_transform(int n, int nt, int na, const float *__restrict__ tri_local,
+                                                          const int32_t *__restrict__ tri_asset,
+                                                          const float *__restrict__ asset_state,
+                                                          const uint8_t *__restrict__ mask, float *__restrict__ tri_world) {
+  const int env = blockIdx.y;
+  if (mask && !mask[env]) return;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nt) return;
+  const float *as = asset_state + ((size_t)env * na + tri_asset[f]) * 13;
+  const V3 t = V3{as[0], as[1], as[2]};
+  const Q4 q = Q4{as[3], as[4], as[5], as[6]};
+  const float *src = tri_local + ((size_t)env * nt + f) * 9;
+  float *dst = tri_world + ((size_t)env * nt + f) * 9;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    V3 w = tf_apply(q, t, V3{src[3 * v], src[3 * v + 1], src[3 * v + 2]});
+    dst[3 * v] = w.x; dst[3 * v + 1] = w.y; dst[3 * v + 2] = w.z;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const float *__restrict__ asset_state,
+                                                            const float *__restrict__ half_extents,
+                                                            const uint8_t *__restrict__ mask, float *__restrict__ boxes) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y;
+  if (env >= n) return;
+  if (mask && !mask[env]) return;
+  const float *as = asset_state + ((size_t)env * na + k) * 13;
+  const float *he = half_extents + ((size_t)env * na + k) * 3;
+  float *bx = boxes + (size_t)k * 10 * n + env;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) bx[(size_t)c * n] = as[c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bx[(size_t)(7 + c) * n] = he[c];
+}
+
+// ------------------------------------------------------------------------------------ LBVH
+AGX_DEV uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+AGX_DEV int delta_keys(const unsigned long long *keys, int nt, int i, int j) {
+  if (j < 0 || j >= nt) return -1;
+  return __clzll(keys[i] ^ keys[j]);  // keys are unique (the triangle index is in the low word)
+}
+
+// Node record written to HBM (16 floats):
+//   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
+//   [8..10] lo_right [11] 0                     [12..14] hi_right [15] 0
+// child >= 0: internal node index, child < 0: leaf holding triangle ~child.
+__global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int nt, int npad, const float *__restrict__ tri_world,
+                                                            const uint8_t *__restrict__ mask, float *__restrict__ nodes) {
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
+  float *box = reinterpret_cast<float *>(keys + npad);                              // [(2nt-1)][6] internal then leaves
+  int *parent = reinterpret_cast<int *>(box + (size_t)(2 * nt - 1) * 6);           // [2nt-1]
+  int *child = parent + (2 * nt - 1);                                               // [nt-1][2]
+  int *counter = child + 2 * (nt - 1);                                              // [nt-1]
+  float *red = reinterpret_cast<float *>(counter + (nt - 1));                       // [6][kBvhThreads]
+  const int tid = threadIdx.x;
+  const float *tris = tri_world + (size_t)env * nt * 9;
+
+  // --- centroid bounds
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int f = tid; f < nt; f += kBvhThreads) {
+    const float *t = tris + (size_t)f * 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float cen = (t[c] + t[3 + c] + t[6 + c]) * (1.0f / 3.0f);
+      lo[c] = fminf(lo[c], cen);
+      hi[c] = fmaxf(hi[c], cen);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    red[c * kBvhThreads + tid] = lo[c];
+    red[(3 + c) * kBvhThreads + tid] = hi[c];
+  }
+  __syncthreads();
+  for (int s = kBvhThreads / 2; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        red[c * kBvhThreads + tid] = fminf(red[c * kBvhThreads + tid], red[c * kBvhThreads + tid + s]);
+        red[(3 + c) * kBvhThreads + tid] = fmaxf(red[(3 + c) * kBvhThreads + tid], red[(3 + c) * kBvhThreads + tid + s]);
+      }
+    }
+    __syncthreads();
+  }
+  float blo[3], inv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    blo[c] = red[c * kBvhThreads];
+    float ext = red[(3 + c) * kBvhThreads] - blo[c];
+    inv[c] = ext > 0.0f ? 1023.0f / ext : 0.0f;
+  }
+  // --- Morton keys (30-bit code | triangle index)
+  for (int f = tid; f < npad; f += kBvhThreads) {
+    unsigned long long key = ~0ull;
+    if (f < nt) {
+      const float *t = tris + (size_t)f * 9;
+      uint32_t code = 0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float cen = (t[c] + t[3 + c] + t[6 + c]) * (1.0f / 3.0f);
+        float qv = fminf(fmaxf((cen - blo[c]) * inv[c], 0.0f), 1023.0f);
+        code |= expand_bits10((uint32_t)qv) << (2 - c);
+      }
+      key = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)f;
+    }
+    keys[f] = key;
+  }
+  __syncthreads();
+  // --- bitonic sort in LDS
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += kBvhThreads) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = keys[i], b = keys[ixj];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // --- Karras 2012 radix tree: internal nodes 0..nt-2, leaves nt-1+i (i = sorted position)
+  const int n_int = nt - 1;
+  for (int i = tid; i < n_int; i += kBvhThreads) {
+    int d = (delta_keys(keys, nt, i, i + 1) - delta_keys(keys, nt, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta_keys(keys, nt, i, i - d);
+    int lmax = 2;
+    while (delta_keys(keys, nt, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+      if (delta_keys(keys, nt, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta_keys(keys, nt, i, j);
+    int s = 0;
+    int t = l;
+    do {
+      t = (t + 1) >> 1;
+      if (delta_keys(keys, nt, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + min(d, 0);
+    int left = (min(i, j) == gamma) ? (n_int + gamma) : gamma;
+    int right = (max(i, j) == gamma + 1) ? (n_int + gamma + 1) : (gamma + 1);
+    child[2 * i] = left;
+    child[2 * i + 1] = right;
+    parent[left] = i;
+    parent[right] = i;
+    counter[i] = 0;
+  }
+  if (tid == 0) parent[0] = -1;
+  // --- leaf boxes (grown by kBoxEps)
+  for (int i = tid; i < nt; i += kBvhThreads) {
+    int f = (int)(uint32_t)(keys[i] & 0xFFFFFFFFull);
+    const float *t = tris + (size_t)f * 9;
+    float *b = box + (size_t)(n_int + i) * 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      b[c] = fminf(fminf(t[c], t[3 + c]), t[6 + c]) - kBoxEps;
+      b[3 + c] = fmaxf(fmaxf(t[c], t[3 + c]), t[6 + c]) + kBoxEps;
+    }
+  }
+  __syncthreads();
+  // --- bottom-up box propagation: the second arriver at a node merges its children
+  for (int i = tid; i < nt; i += kBvhThreads) {
+    int node = parent[n_int + i];
+    while (node >= 0) {
+      __threadfence_block();
+      if (atomicAdd(&counter[node], 1) == 0) break;
+      const float *a = box + (size_t)child[2 * node] * 6, *b = box + (size_t)child[2 * node + 1] * 6;
+      float *o = box + (size_t)node * 6;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o[c] = fminf(a[c], b[c]);
+        o[3 + c] = fmaxf(a[3 + c], b[3 + c]);
+      }
+      node = parent[node];
+    }
+  }
+  __syncthreads();
+  // --- emit nodes with both child boxes inline
+  float *out = nodes + (size_t)env * (nt - 1) * 16;
+  for (int i = tid; i < n_int; i += kBvhThreads) {
+    int cl = child[2 * i], cr = child[2 * i + 1];
+    const float *a = box + (size_t)cl * 6, *b = box + (size_t)cr * 6;
+    int el = cl >= n_int ? ~(int)(uint32_t)(keys[cl - n_int] & 0xFFFFFFFFull) : cl;
+    int er = cr >= n_int ? ~(int)(uint32_t)(keys[cr - n_int] & 0xFFFFFFFFull) : cr;
+    float *o = out + (size_t)i * 16;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(el);
+    o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(er);
+    o[8] = b[0]; o[9] = b[1]; o[10] = b[2]; o[11] = 0.0f;
+    o[12] = b[3]; o[13] = b[4]; o[14] = b[5]; o[15] = 0.0f;
+  }
+}
+
+static size_t bvh_lds_bytes(int nt, int npad) {
+  return (size_t)npad * 8 + (size_t)(2 * nt - 1) * 24 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 +
+         (size_t)6 * kBvhThreads * 4 + 64;
+}
+
+}  // namespace agx
+
+using namespace agx;
+
+extern "C" int agx_scene_transform(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset,
+                                   const float *asset_state, const uint8_t *mask, float *tri_world, void *stream) {
+  AGX_REQUIRE(n > 0 && nt > 0 && na > 0, "bad sizes n=%d nt=%d na=%d", n, nt, na);
+  AGX_REQUIRE(tri_local && tri_asset && asset_state && tri_world, "null buffer");
+  dim3 grid(blocks_for(nt, 256), n);
+  hipLaunchKernelGGL(k_scene_transform, grid, dim3(256), 0, (hipStream_t)stream, n, nt, na, tri_local, tri_asset, asset_state,
+                     mask, tri_world);
+  return check_launch("agx_scene_transform");
+}
+
+extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, const float *half_extents, const uint8_t *mask,
+                                     float *boxes, void *stream) {
+  AGX_REQUIRE(n > 0 && na > 0, "bad sizes");
+  AGX_REQUIRE(asset_state && half_extents && boxes, "null buffer");
+  dim3 grid(blocks_for(n, 256), na);
+  hipLaunchKernelGGL(k_boxes_from_assets, grid, dim3(256), 0, (hipStream_t)stream, n, na, asset_state, half_extents, mask, boxes);
+  return check_launch("agx_boxes_from_assets");
+}
+
+extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
+
+extern "C" int agx_bvh_build(int n, int nt, const float *tri_world, const uint8_t *mask, float *nodes, void *stream) {
+  AGX_REQUIRE(n > 0, "bad num_envs");
+  AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
+  AGX_REQUIRE(tri_world && nodes, "null buffer");
+  int npad = 1;
+  while (npad < nt) npad <<= 1;
+  size_t lds = bvh_lds_bytes(nt, npad);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bvh_build), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  AGX_REQUIRE(lds <= 160 * 1024, "LBVH build needs %zu bytes of LDS (> 160 KiB)", lds);
+  hipLaunchKernelGGL(k_bvh_build, dim3(n), dim3(kBvhThreads), lds, (hipStream_t)stream, nt, npad, tri_world, mask, nodes);
+  return check_launch("agx_bvh_build");
+}

@@ -1,0 +1,364 @@
+"""EnvManager: same orchestration API as aerial_gym/env_manager/env_manager.py, driving the
+HIP library instead of Isaac Gym + Warp + torch op chains.
+
+Per env step (`step` + the task's reward + `post_reward_calculation_step`) the launches are
+    agx_dynamics_substeps   k sub-steps: controller .. integration .. collision   (1 kernel)
+    agx_reward_*            task reward, crash / truncation flags, reset set       (1 kernel)
+    agx_reset_masked        reset sampling + derived-state refresh                  (1 kernel)
+    [scene + BVH rebuild of reset envs, sensor pose, ray-cast, post-processing]
+    agx_obs_*               observation packing                                     (1 kernel)
+all stream-ordered on torch's current stream, with no host synchronisation unless the
+caller asks for the reset set as indices or `strict_rng` is requested.
+"""
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import AgxEnvBuffers, AgxResetArgs
+from ..registry.env_registry import env_config_registry
+from ..registry.robot_registry import robot_registry
+from ..registry.sim_registry import sim_config_registry
+from ..robots.robot_manager import RobotManagerHIP
+from ..tensors import aos_view, soa
+from ..utils.logging import CustomLogger
+from ..utils.random_source import TorchRandomSource
+from .asset_manager import AssetManager
+from .base_env_manager import BaseManager
+from .scene_manager import SceneManager
+
+logger = CustomLogger("env_manager")
+
+
+class ResetSet:
+    """Lazy stand-in for the `envs_to_reset` index tensor returned by the reference
+    (env_manager.py:364-375).  Holding the device mask keeps the step free of host syncs;
+    `len()`, iteration or `.indices` materialise the indices (one sync) on demand."""
+
+    def __init__(self, mask):
+        self.mask = mask
+        self._idx = None
+
+    @property
+    def indices(self):
+        if self._idx is None:
+            self._idx = self.mask.nonzero(as_tuple=False).squeeze(-1)
+        return self._idx
+
+    def __len__(self):
+        return int(self.indices.numel())
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __getitem__(self, i):
+        return self.indices[i]
+
+
+class EnvManager(BaseManager):
+    def __init__(self, sim_name, env_name, robot_name, controller_name, device, args=None, num_envs=None,
+                 use_warp=None, headless=None):
+        self.robot_name, self.controller_name = robot_name, controller_name
+        self.sim_config = sim_config_registry.make_sim(sim_name)
+        super().__init__(env_config_registry.make_env(env_name), device)
+        if num_envs is not None:
+            self.cfg.env.num_envs = num_envs
+        if use_warp is not None:
+            self.cfg.env.use_warp = use_warp
+        if headless is not None:
+            self.sim_config.viewer.headless = headless
+        self.num_envs = self.cfg.env.num_envs
+        self.use_warp = self.cfg.env.use_warp
+        self.env_args = args or {}
+        # strict_rng: consume the torch RNG exactly when and how the reference does (needs a
+        # host sync per step to learn whether any env resets).  Default: draw every step.
+        self.strict_rng = bool(self.env_args.get("strict_rng", False))
+        self.random_source = self.env_args.get("random_source") or TorchRandomSource(device)
+        self.global_tensor_dict = {}
+        self.keep_in_env = None
+        self.step_counter = 0
+        self._lib = None
+        self.populate_env(env_cfg=self.cfg, sim_cfg=self.sim_config)
+        self.prepare_sim()
+        self.sim_steps = self.global_tensor_dict["sim_steps"]
+
+    # ------------------------------------------------------------------ construction
+    def populate_env(self, env_cfg, sim_cfg):
+        N, dev, g = self.num_envs, self.device, self.global_tensor_dict
+        g["random_source"] = self.random_source
+        g["env_manager"] = self
+        g["strict_rng"] = self.strict_rng
+        g["sim_config"] = sim_cfg
+        g["crashes"] = torch.zeros(N, dtype=torch.bool, device=dev)
+        g["truncations"] = torch.zeros(N, dtype=torch.bool, device=dev)
+        g["reset_mask"] = torch.zeros(N, dtype=torch.uint8, device=dev)
+        g["reset_flag"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        g["sim_steps"] = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.collision_tensor, self.truncation_tensor = g["crashes"], g["truncations"]
+        self.num_env_actions = env_cfg.env.num_env_actions
+        g["num_env_actions"] = self.num_env_actions
+        g["env_actions"] = None
+        g["prev_env_actions"] = None
+        # root state (IGE_env_manager.py:293-358): SoA storage, reference-shaped aliases
+        state = soa(13, N, dev)
+        state[6] = 1.0
+        g["robot_state_soa"] = state
+        g["robot_state_tensor"] = aos_view(state)
+        g["robot_position"] = aos_view(state, 0, 3)
+        g["robot_orientation"] = aos_view(state, 3, 7)
+        g["robot_linvel"] = aos_view(state, 7, 10)
+        g["robot_angvel"] = aos_view(state, 10, 13)
+        # env bounds (IGE_env_manager.py:150-166, 513-519)
+        e = env_cfg.env
+        self.bounds_soa = (soa(3, N, dev), soa(3, N, dev))
+        lo = (torch.tensor(e.lower_bound_min) + torch.tensor(e.lower_bound_max)) / 2.0
+        hi = (torch.tensor(e.upper_bound_min) + torch.tensor(e.upper_bound_max)) / 2.0
+        self.bounds_soa[0][:] = lo.to(dev).unsqueeze(1)
+        self.bounds_soa[1][:] = hi.to(dev).unsqueeze(1)
+        g["env_bounds_min"], g["env_bounds_max"] = aos_view(self.bounds_soa[0]), aos_view(self.bounds_soa[1])
+        g["gravity"] = torch.tensor(sim_cfg.sim.gravity, device=dev).expand(N, -1)
+        g["dt"] = sim_cfg.sim.dt
+        # obstacles: which boxes live in which env (asset_loader.py:148-194 semantics)
+        self.scene = SceneManager(env_cfg, N, dev, self.random_source)
+        self.keep_in_env = self.scene.keep_in_env_num
+        g["num_obstacles_in_env"] = self.scene.num_assets
+        self.robot_manager = RobotManagerHIP(self.global_tensor_dict, self.cfg, self.robot_name, self.controller_name, dev)
+
+    def prepare_sim(self):
+        g = self.global_tensor_dict
+        self._lib = _lib.load()  # fails loudly when the HIP library is absent
+        self.scene.prepare_for_simulation(g)
+        self.asset_manager = AssetManager(g, self.keep_in_env, self.scene)
+        self.robot_manager.prepare_for_sim(g, self.scene)
+        self.num_robot_actions = g["num_robot_actions"]
+        self._bind()
+        self.asset_manager.prepare_for_sim(self)
+
+    def _bind(self):
+        """Collect raw device pointers once: tensors are allocated once and never re-allocated."""
+        g, robot = self.global_tensor_dict, self.robot_manager.robot
+        if torch.device(self.device).type != "cuda":
+            # tensors can be inspected on the CPU (host-logic tests), stepping cannot
+            self._buffers = None
+            return
+        mm = robot.control_allocator.motor_model
+        B = AgxEnvBuffers()
+        p = _lib.dptr
+        B.state, B.derived = p(g["robot_state_soa"]), p(g["robot_derived_soa"])
+        B.actions, B.prev_actions = p(g["robot_actions_soa"]), p(g["robot_prev_actions_soa"])
+        B.motor_thrust, B.motor_kT = p(mm.thrust_soa), p(mm.kT_soa)
+        B.motor_tau_inc, B.motor_tau_dec = p(mm.tau_inc_soa), p(mm.tau_dec_soa)
+        B.gains = p(g.get("controller_gains_soa"))
+        B.wrench_cmd = p(g.get("controller_wrench_soa"))
+        B.crashes, B.truncations = p(g["crashes"]), p(g["truncations"])
+        B.sim_steps, B.reset_mask, B.reset_flag = p(g["sim_steps"]), p(g["reset_mask"]), p(g["reset_flag"])
+        B.bounds_min, B.bounds_max = p(self.bounds_soa[0]), p(self.bounds_soa[1])
+        B.disturb = None
+        for i, v in enumerate(robot.max_force_and_torque_disturbance):
+            B.disturb_max[i] = v
+        B.boxes = p(self.scene.boxes_soa) if self.scene.num_assets > 0 else None
+        B.num_boxes = self.scene.num_assets
+        self._buffers = B
+        self._params = robot.params
+        robot._env_binding = self
+        robot.controller._env_binding = self
+        self._make_reset_args()
+        self._disturb_buf = None
+
+    def _make_reset_args(self):
+        N, dev = self.num_envs, self.device
+        robot, e = self.robot_manager.robot, self.cfg.env
+        M = robot.cfg.control_allocator_config.num_motors
+        ctrl = robot.controller
+        self._randomize_gains = bool(getattr(ctrl.cfg, "randomize_params", False)) and hasattr(ctrl, "gains_soa")
+        # one flat buffer -> one RNG launch per draw in the sync-free mode
+        sizes = dict(bounds_lo=3, bounds_hi=3, state=13, gains=12, tau_inc=M, tau_dec=M, thrust=M, kT=M)
+        self._u_flat = torch.zeros(N * sum(sizes.values()), device=dev)
+        self._u = {}
+        off = 0
+        for name, c in sizes.items():
+            self._u[name] = self._u_flat[off:off + N * c].view(N, c)
+            off += N * c
+        R = AgxResetArgs()
+        p = _lib.dptr
+        R.u_bounds_lo, R.u_bounds_hi, R.u_state = p(self._u["bounds_lo"]), p(self._u["bounds_hi"]), p(self._u["state"])
+        R.u_gains = p(self._u["gains"]) if self._randomize_gains else None
+        R.u_tau_inc, R.u_tau_dec = p(self._u["tau_inc"]), p(self._u["tau_dec"])
+        R.u_thrust, R.u_kT = p(self._u["thrust"]), p(self._u["kT"])
+        for i in range(3):
+            R.lower_bound_min[i], R.lower_bound_max[i] = e.lower_bound_min[i], e.lower_bound_max[i]
+            R.upper_bound_min[i], R.upper_bound_max[i] = e.upper_bound_min[i], e.upper_bound_max[i]
+        for i in range(13):
+            R.min_state[i], R.max_state[i] = robot.min_init_state[i], robot.max_init_state[i]
+        if hasattr(ctrl, "gains_min"):
+            for i in range(12):
+                R.gains_min[i], R.gains_max[i] = ctrl.gains_min[i], ctrl.gains_max[i]
+        rng = robot.control_allocator.motor_model.ranges
+        R.tau_inc_min, R.tau_inc_max = rng["tau_inc"]
+        R.tau_dec_min, R.tau_dec_max = rng["tau_dec"]
+        R.kT_min, R.kT_max = rng["kT"]
+        self._reset_args = R
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return _lib.current_stream(self.device)
+
+    def _require_device(self):
+        if self._buffers is None:
+            raise RuntimeError(
+                f"EnvManager on device '{self.device}': simulation needs a HIP device (cuda:N); "
+                "aerial_gym_simulator_amd has no CPU fallback"
+            )
+
+    def update_states(self):
+        self._require_device()
+        _lib.check(self._lib.agx_update_states(self._buffers, self.num_envs, self._stream()), "agx_update_states")
+
+    def controller_wrench(self, action):
+        self._require_device()
+        a = action.to(dtype=torch.float32).contiguous()
+        _lib.check(self._lib.agx_controller_wrench(self._params, self._buffers, self.num_envs, _lib.dptr(a), self._stream()),
+                   "agx_controller_wrench")
+        return self.robot_manager.robot.controller.wrench_command
+
+    # ------------------------------------------------------------------ reset
+    def _draw_reset_randoms(self, env_ids=None):
+        """Uniform draws for the robot reset.  strict_rng reproduces the reference's calls:
+        rand_like for all N in the order bounds(lo, hi) [IGE_env_manager.py:513-519] ...
+        robot state [base_multirotor.py:182], gains [base_lee_controller.py:101-118, len(env_ids)
+        rows], motor tau_inc, tau_dec, thrust, kT [motor_model.py:140-154]."""
+        rs, u = self.random_source, self._u
+        if not self.strict_rng:
+            rs.rand_into(self._u_flat, tag="reset_all")
+            return
+        robot = self.robot_manager.robot
+        rs.rand_into(u["bounds_lo"], tag="bounds_lo")
+        rs.rand_into(u["bounds_hi"], tag="bounds_hi")
+        self.asset_manager.draw_reset_randoms(env_ids)
+        rs.rand_into(u["state"], tag="robot_state")
+        if self._randomize_gains:
+            n = len(env_ids)
+            for k in range(4):
+                u["gains"][env_ids, 3 * k:3 * k + 3] = rs.rand(n, 3, tag="gains%d" % k)
+        rs.rand_into(u["tau_inc"], tag="tau_inc")
+        rs.rand_into(u["tau_dec"], tag="tau_dec")
+        rs.rand_into(u["thrust"], tag="thrust")
+        if robot.cfg.control_allocator_config.motor_model_config.use_rps:
+            rs.rand_into(u["kT"], tag="kT")
+        self.robot_manager.draw_sensor_reset_randoms(env_ids)
+
+    def _launch_reset(self):
+        """Device side of EnvManager.reset_idx for the envs flagged in reset_mask."""
+        self.asset_manager.reset_masked(self)  # obstacle poses, scene triangles, BVH, boxes
+        _lib.check(self._lib.agx_reset_masked(self._params, self._buffers, self.num_envs, self._reset_args, self._stream()),
+                   "agx_reset_masked")
+        self.robot_manager.reset_sensors_masked()
+
+    def reset_idx(self, env_ids=None):
+        self._require_device()
+        g = self.global_tensor_dict
+        if env_ids is None:
+            env_ids = torch.arange(self.num_envs, device=self.device)
+        env_ids = torch.as_tensor(env_ids, device=self.device, dtype=torch.long)
+        if env_ids.numel() == 0:
+            return
+        g["reset_mask"].zero_()
+        g["reset_mask"][env_ids] = 1
+        g["reset_flag"].fill_(1)
+        self._draw_reset_randoms(env_ids)
+        self._launch_reset()
+
+    def reset_robots(self, env_ids):
+        self.reset_idx(env_ids)
+
+    def randomize_controller_gains(self, env_ids):
+        pass  # folded into agx_reset_masked (u_gains)
+
+    def reset(self):
+        self.reset_idx(torch.arange(self.num_envs, device=self.device))
+
+    def reset_terminated_and_truncated_envs(self):
+        g = self.global_tensor_dict
+        if self.strict_rng:
+            if int(g["reset_flag"].item()) == 0:  # host sync, like the reference's nonzero()/len()
+                return ResetSet(g["reset_mask"])
+            env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1)
+            self._draw_reset_randoms(env_ids)
+        else:
+            self._draw_reset_randoms()
+        self._launch_reset()
+        return ResetSet(g["reset_mask"])
+
+    # ------------------------------------------------------------------ stepping
+    def reset_tensors(self):
+        self.collision_tensor[:] = 0
+        self.truncation_tensor[:] = 0
+
+    def num_physics_steps(self):
+        e = self.cfg.env
+        return max(math.floor(self.random_source.gauss(e.num_physics_steps_per_env_step_mean,
+                                                       e.num_physics_steps_per_env_step_std)), 0)
+
+    def _draw_disturbance(self, k):
+        """apply_disturbance draws per sub-step (base_multirotor.py:213-234): bernoulli(p) [N],
+        then two rand_like [N,3]; stored SoA [k][7][N] for the kernel."""
+        robot = self.robot_manager.robot
+        if not robot.cfg.disturbance.enable_disturbance or k == 0:
+            self._buffers.disturb = None
+            return
+        N, rs = self.num_envs, self.random_source
+        if self._disturb_buf is None or self._disturb_buf.shape[0] < k:
+            self._disturb_buf = torch.zeros(max(k, 1), 7, N, device=self.device)
+        p = robot.cfg.disturbance.prob_apply_disturbance
+        for s in range(k):
+            self._disturb_buf[s, 0] = rs.bernoulli(p, N, tag="disturb_occ")
+            self._disturb_buf[s, 1:4] = rs.rand(N, 3, tag="disturb_f").t()
+            self._disturb_buf[s, 4:7] = rs.rand(N, 3, tag="disturb_t").t()
+        self._buffers.disturb = _lib.dptr(self._disturb_buf)
+
+    def simulate(self, actions, env_actions=None, num_substeps=1):
+        """k physics sub-steps (pre_physics_step + physics_step + post_physics_step +
+        compute_observations of the reference) in one launch."""
+        self._require_device()
+        a = actions
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(dtype=torch.float32).contiguous()
+        if a.shape != (self.num_envs, self.num_robot_actions):
+            raise ValueError("Action tensor does not have the correct number of environments")
+        self._draw_disturbance(num_substeps)
+        _lib.check(
+            self._lib.agx_dynamics_substeps(self._params, self._buffers, self.num_envs, _lib.dptr(a), num_substeps, self._stream()),
+            "agx_dynamics_substeps",
+        )
+
+    def step(self, actions, env_actions=None):
+        if env_actions is not None:
+            raise NotImplementedError("kinematic obstacle actions (env_actions) are not supported yet (SURVEY f4)")
+        self.simulate(actions, env_actions, self.num_physics_steps())
+        self.step_counter += 1
+
+    def compute_observations(self):
+        pass  # the collision flag is accumulated inside agx_dynamics_substeps
+
+    def post_reward_calculation_step(self):
+        envs_to_reset = self.reset_terminated_and_truncated_envs()
+        self.render(render_components="sensors")
+        return envs_to_reset
+
+    def render(self, render_components="sensors"):
+        if render_components == "sensors":
+            self.render_sensors()
+
+    def render_sensors(self):
+        self.robot_manager.capture_sensors()
+
+    def render_viewer(self):
+        pass
+
+    def get_obs(self):
+        return self.global_tensor_dict
+
+    def delete_env(self):
+        """The reference's tasks call this on close() although its EnvManager lacks it
+        (position_setpoint_task.py:132-133); provided here."""
+        self._buffers = None

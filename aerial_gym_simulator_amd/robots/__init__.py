@@ -1,0 +1,18 @@
+"""Robot registration (names of aerial_gym/robots/__init__.py:37-66 that are in scope)."""
+from ..config.robot_config import (
+    BaseOctarotorCfg,
+    BaseOctarotorWithLidar32x512Cfg,
+    BaseQuadCfg,
+    BaseQuadWithCamera64x48Cfg,
+    BaseQuadWithCameraCfg,
+    BaseQuadWithLidarCfg,
+)
+from ..registry.robot_registry import robot_registry
+from .base_multirotor import BaseMultirotor
+
+robot_registry.register("base_quadrotor", BaseMultirotor, BaseQuadCfg)
+robot_registry.register("base_octarotor", BaseMultirotor, BaseOctarotorCfg)
+robot_registry.register("base_quadrotor_with_camera", BaseMultirotor, BaseQuadWithCameraCfg)
+robot_registry.register("base_quadrotor_with_camera_64x48", BaseMultirotor, BaseQuadWithCamera64x48Cfg)
+robot_registry.register("base_quadrotor_with_lidar", BaseMultirotor, BaseQuadWithLidarCfg)
+robot_registry.register("base_octarotor_with_lidar_32x512", BaseMultirotor, BaseOctarotorWithLidar32x512Cfg)

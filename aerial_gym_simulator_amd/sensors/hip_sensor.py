@@ -1,0 +1,173 @@
+"""Ray-cast sensor front-end: WarpSensor + WarpCam + WarpLidar of the reference
+(sensors/warp/warp_sensor.py:83-249, warp_cam.py:31-182, warp_lidar.py:40-191) on the HIP
+kernels.  Capture = agx_sensor_pose -> agx_raycast_{camera,lidar} -> agx_sensor_postprocess."""
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib
+from ..utils.math import quat_from_euler_xyz, quat_from_euler_xyz_tensor
+
+RAY_MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3}
+
+
+class HipSensor:
+    def __init__(self, sensor_config, num_envs, scene, device):
+        self.cfg, self.num_envs, self.scene, self.device = sensor_config, num_envs, scene, device
+        self.num_sensors = sensor_config.num_sensors
+        cfg = sensor_config
+        if cfg.sensor_type not in ("camera", "lidar"):
+            raise NotImplementedError(f"sensor_type {cfg.sensor_type} is not supported yet (SURVEY f1)")
+        self.is_lidar = cfg.sensor_type == "lidar"
+        if self.is_lidar:
+            self.mode = RAY_MODE["range"]
+            if cfg.return_pointcloud:
+                self.mode = RAY_MODE["pointcloud_world" if cfg.pointcloud_in_world_frame else "pointcloud"]
+            self._init_ray_table()
+        else:
+            self.mode = RAY_MODE["depth" if cfg.calculate_depth else "range"]
+            if cfg.return_pointcloud:
+                self.mode = RAY_MODE["pointcloud_world" if cfg.pointcloud_in_world_frame else "pointcloud"]
+            self._init_intrinsics()
+
+    # warp_cam.py:31-64
+    def _init_intrinsics(self):
+        W, H = self.cfg.width, self.cfg.height
+        u0, v0 = W / 2, H / 2
+        hfov = math.radians(self.cfg.horizontal_fov_deg)
+        f = W / 2 * 1 / math.tan(hfov / 2)
+        vfov = 2 * math.atan(H / (2 * f))
+        alpha_u, alpha_v = u0 / math.tan(hfov / 2), v0 / math.tan(vfov / 2)
+        # the four entries of K_inv that wp.transform_vector(K_inv, (x, y, 1)) touches
+        self.kinv = (C.c_float * 4)(1.0 / alpha_u, -u0 / alpha_u, 1.0 / alpha_v, -v0 / alpha_v)
+        self.c_x, self.c_y = int(u0), int(v0)
+
+    # warp_lidar.py:40-64
+    def _init_ray_table(self):
+        cfg = self.cfg
+        H, W = cfg.height, cfg.width
+        hmin, hmax = math.radians(cfg.horizontal_fov_deg_min), math.radians(cfg.horizontal_fov_deg_max)
+        vmin, vmax = math.radians(cfg.vertical_fov_deg_min), math.radians(cfg.vertical_fov_deg_max)
+        if hmax - hmin > 2 * math.pi:
+            raise ValueError("Horizontal FOV must be less than 2pi")
+        if vmax - vmin > math.pi:
+            raise ValueError("Vertical FOV must be less than pi")
+        az = torch.tensor([hmax - (hmax - hmin) * (j / (W - 1)) for j in range(W)], dtype=torch.float64)
+        el = torch.tensor([vmax - (vmax - vmin) * (i / (H - 1)) for i in range(H)], dtype=torch.float64)
+        rv = torch.stack(
+            [torch.cos(az)[None, :] * torch.cos(el)[:, None], torch.sin(az)[None, :] * torch.cos(el)[:, None],
+             torch.sin(el)[:, None].expand(H, W)], dim=2,
+        ).to(torch.float32)
+        rv = rv / torch.norm(rv, dim=2, keepdim=True)
+        self.ray_vectors = rv.contiguous().to(self.device)
+
+    def init_tensors(self, global_tensor_dict):
+        g, N, S, dev, cfg = global_tensor_dict, self.num_envs, self.num_sensors, self.device, self.cfg
+        self.g = g
+        self.pixels = g["depth_range_pixels"]
+        self.segmentation_pixels = g["segmentation_pixels"] if cfg.segmentation_camera else None
+        self.min_translation = torch.tensor(cfg.min_translation, device=dev)
+        self.max_translation = torch.tensor(cfg.max_translation, device=dev)
+        self.min_rotation = torch.deg2rad(torch.tensor(cfg.min_euler_rotation_deg, device=dev))
+        self.max_rotation = torch.deg2rad(torch.tensor(cfg.max_euler_rotation_deg, device=dev))
+        frame = quat_from_euler_xyz_tensor(torch.deg2rad(torch.tensor(cfg.euler_frame_rot_deg, dtype=torch.float32)))
+        self.frame_quat = (C.c_float * 4)(*[float(x) for x in frame])
+        self.sensor_local_position = torch.zeros(N, S, 3, device=dev)
+        self.sensor_local_orientation = torch.zeros(N, S, 4, device=dev)
+        mean_rot = (self.min_rotation + self.max_rotation) / 2.0
+        self.sensor_local_orientation[:] = quat_from_euler_xyz(mean_rot[0], mean_rot[1], mean_rot[2])
+        self.sensor_position = torch.zeros(N, S, 3, device=dev)
+        self.sensor_orientation = torch.zeros(N, S, 4, device=dev)
+        self.sensor_orientation[..., 3] = 1.0
+        self._u_pos = torch.zeros(N, S, 3, device=dev)
+        self._u_rot = torch.zeros(N, S, 3, device=dev)
+        self._noise_z = self._noise_u = None
+        if cfg.sensor_noise.enable_sensor_noise:
+            self._noise_z = torch.zeros_like(self.pixels)
+            self._noise_u = torch.zeros_like(self.pixels)
+        g["sensor_position"], g["sensor_orientation"] = self.sensor_position, self.sensor_orientation
+
+    # warp_sensor.py:153-172
+    def draw_reset_randoms(self, env_ids):
+        """strict_rng: rand_like over the reset envs only, translation then rotation."""
+        if not self.cfg.randomize_placement:
+            return
+        rs, n = self.g["random_source"], len(env_ids)
+        self._u_pos[env_ids] = rs.rand(n, self.num_sensors, 3, tag="sensor_pos")
+        self._u_rot[env_ids] = rs.rand(n, self.num_sensors, 3, tag="sensor_rot")
+
+    def reset_masked(self):
+        if not self.cfg.randomize_placement:
+            return
+        g = self.g
+        if not g.get("strict_rng", True):
+            rs = g["random_source"]
+            rs.rand_into(self._u_pos, tag="sensor_pos")
+            rs.rand_into(self._u_rot, tag="sensor_rot")
+        mask = (g["reset_mask"].bool() & (g["reset_flag"] != 0)).view(-1, 1, 1)
+        pos = (self.max_translation - self.min_translation) * self._u_pos + self.min_translation
+        eul = (self.max_rotation - self.min_rotation) * self._u_rot + self.min_rotation
+        quat = quat_from_euler_xyz(eul[..., 0], eul[..., 1], eul[..., 2])
+        self.sensor_local_position[:] = torch.where(mask, pos, self.sensor_local_position)
+        self.sensor_local_orientation[:] = torch.where(mask, quat, self.sensor_local_orientation)
+
+    def update(self):
+        env = self.g["env_manager"]
+        lib, stream, p, cfg, sc = env._lib, env._stream(), _lib.dptr, self.cfg, self.scene
+        N, S = self.num_envs, self.num_sensors
+        _lib.check(
+            lib.agx_sensor_pose(env._buffers, N, S, p(self.sensor_local_position), p(self.sensor_local_orientation),
+                                self.frame_quat, p(self.sensor_position), p(self.sensor_orientation), stream),
+            "agx_sensor_pose",
+        )
+        seg = p(self.segmentation_pixels) if self.segmentation_pixels is not None else None
+        if self.is_lidar:
+            _lib.check(
+                lib.agx_raycast_lidar(N, S, cfg.width, cfg.height, p(self.ray_vectors), float(cfg.max_range), self.mode,
+                                      p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
+                                      p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
+                "agx_raycast_lidar",
+            )
+        else:
+            _lib.check(
+                lib.agx_raycast_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), self.c_x, self.c_y,
+                                       self.mode, p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world),
+                                       p(sc.tri_seg), p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
+                "agx_raycast_camera",
+            )
+        if cfg.return_pointcloud:
+            self._postprocess_pointcloud()
+            return
+        zn = ud = None
+        sn = cfg.sensor_noise
+        if sn.enable_sensor_noise:
+            rs = self.g["random_source"]
+            zn = p(rs.normal_into(self._noise_z, tag="sensor_noise_z"))
+            ud = p(rs.rand_into(self._noise_u, tag="sensor_noise_u"))
+        _lib.check(
+            lib.agx_sensor_postprocess(self.pixels.numel(), p(self.pixels), zn, ud, float(getattr(sn, "std_a", 0.0)),
+                                       float(getattr(sn, "std_b", 0.0)), float(getattr(sn, "std_c", 0.0)),
+                                       float(getattr(sn, "mean_offset", 0.0)), float(sn.pixel_dropout_prob),
+                                       float(cfg.min_range), float(cfg.max_range), float(cfg.far_out_of_range_value),
+                                       float(cfg.near_out_of_range_value), int(bool(cfg.normalize_range)), stream),
+            "agx_sensor_postprocess",
+        )
+
+    def _postprocess_pointcloud(self):
+        """warp_sensor.py:202-227 point-cloud branch (rare path, kept in torch on device)."""
+        cfg = self.cfg
+        if cfg.pointcloud_in_world_frame:
+            return
+        nrm = self.pixels.norm(dim=4, keepdim=True).expand(-1, -1, -1, -1, 3)
+        self.pixels[nrm > cfg.max_range] = cfg.far_out_of_range_value
+        nrm = self.pixels.norm(dim=4, keepdim=True).expand(-1, -1, -1, -1, 3)
+        self.pixels[nrm < cfg.min_range] = cfg.near_out_of_range_value
+        if cfg.normalize_range:
+            self.pixels[:] = self.pixels / cfg.max_range
+
+    def get_observation(self):
+        return self.pixels, self.segmentation_pixels
+
+
+WarpSensor = HipSensor  # reference class name

@@ -1,0 +1,6 @@
+"""Task registration (aerial_gym/task/__init__.py)."""
+from ..config.task_config import navigation_task_config, position_setpoint_task_config
+from ..registry.task_registry import task_registry
+from .position_setpoint_task import PositionSetpointTask
+
+task_registry.register_task("position_setpoint_task", PositionSetpointTask, position_setpoint_task_config)

@@ -1,0 +1,111 @@
+"""PositionSetpointTask with the reference's API and step ordering
+(aerial_gym/task/position_setpoint_task/position_setpoint_task.py:21-203); reward, crash,
+truncation and observation packing run in agx_reward_position / agx_obs_position."""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..sim.sim_builder import SimBuilder
+from ..tensors import aos_view, soa
+from ..utils.logging import CustomLogger
+from ..utils.spaces import Box, Dict
+from .base_task import BaseTask
+
+logger = CustomLogger("position_setpoint_task")
+
+
+class PositionSetpointTask(BaseTask):
+    def __init__(self, task_config, seed=None, num_envs=None, headless=None, device=None, use_warp=None):
+        for name, val in (("seed", seed), ("num_envs", num_envs), ("headless", headless), ("device", device),
+                          ("use_warp", use_warp)):
+            if val is not None:
+                setattr(task_config, name, val)
+        super().__init__(task_config)
+        cfg = self.task_config
+        self.device = cfg.device
+        self.sim_env = SimBuilder().build_env(
+            sim_name=cfg.sim_name, env_name=cfg.env_name, robot_name=cfg.robot_name,
+            controller_name=cfg.controller_name, args=cfg.args, device=self.device, num_envs=cfg.num_envs,
+            use_warp=cfg.use_warp, headless=cfg.headless,
+        )
+        N, dev = self.sim_env.num_envs, self.device
+        self.num_envs = N
+        self.actions = torch.zeros((N, cfg.action_space_dim), device=dev)
+        self.prev_actions = torch.zeros_like(self.actions)
+        self.counter = 0
+        self.target_soa = soa(3, N, dev)
+        self.target_position = aos_view(self.target_soa)
+        self.obs_dict = self.sim_env.get_obs()
+        self.obs_dict["num_obstacles_in_env"] = 1
+        self.terminations = self.obs_dict["crashes"]
+        self.truncations = self.obs_dict["truncations"]
+        self.rewards = torch.zeros(N, device=dev)
+        self.observation_space = Dict({"observations": Box(low=-1.0, high=1.0, shape=(13,), dtype=np.float32)})
+        self.action_space = Box(low=-1.0, high=1.0, shape=(cfg.action_space_dim,), dtype=np.float32)
+        self.task_obs = {
+            "observations": torch.zeros((N, cfg.observation_space_dim), device=dev),
+            "priviliged_obs": torch.zeros((N, cfg.privileged_observation_space_dim), device=dev),
+            "collisions": torch.zeros((N, 1), device=dev),
+            "rewards": torch.zeros((N, 1), device=dev),
+        }
+        self.infos = {}
+
+    def close(self):
+        self.sim_env.delete_env()
+
+    def reset(self):
+        self.target_position[:, 0:3] = 0.0
+        self.infos = {}
+        self.sim_env.reset()
+        return self.get_return_tuple()
+
+    def reset_idx(self, env_ids):
+        self.target_position[:, 0:3] = 0.0
+        self.infos = {}
+        self.sim_env.reset_idx(env_ids)
+
+    def render(self):
+        return None
+
+    def step(self, actions):
+        self.counter += 1
+        self.prev_actions[:] = self.actions
+        self.actions = actions
+        env = self.sim_env
+        env.step(actions=self.actions)
+        self.compute_rewards_and_crashes(self.obs_dict)
+        if self.task_config.return_state_before_reset:
+            return_tuple = self.get_return_tuple()
+        env.post_reward_calculation_step()
+        self.infos = {}
+        if not self.task_config.return_state_before_reset:
+            return_tuple = self.get_return_tuple()
+        return return_tuple
+
+    def compute_rewards_and_crashes(self, obs_dict):
+        """compute_reward + `truncations = sim_steps > episode_len` (reference :205-229,:172-174)."""
+        env = self.sim_env
+        env._require_device()
+        _lib.check(
+            env._lib.agx_reward_position(env._buffers, env.num_envs, _lib.dptr(self.target_soa),
+                                         int(self.task_config.episode_len_steps), int(env.cfg.env.reset_on_collision),
+                                         _lib.dptr(self.rewards), env._stream()),
+            "agx_reward_position",
+        )
+        return self.rewards, self.terminations
+
+    def get_return_tuple(self):
+        self.process_obs_for_task()
+        return (self.task_obs, self.rewards, self.terminations, self.truncations, self.infos)
+
+    def process_obs_for_task(self):
+        env = self.sim_env
+        env._require_device()
+        _lib.check(
+            env._lib.agx_obs_position(env._buffers, env.num_envs, _lib.dptr(self.target_soa),
+                                      _lib.dptr(self.task_obs["observations"]), env._stream()),
+            "agx_obs_position",
+        )
+        self.task_obs["rewards"] = self.rewards
+        self.task_obs["terminations"] = self.terminations
+        self.task_obs["truncations"] = self.truncations

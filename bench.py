@@ -1,0 +1,268 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/sec of task.step() on synthetic actions.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dynamics|depth]
+
+N = 1 : BASELINE.json configs[1] -- base_quadrotor, position-setpoint task, Lee position
+        controller, 8192 envs, empty_env, dynamics only -- plus (extra keys, same JSON line)
+        the "+depth" number of configs[2] when --with-depth is given.
+N > 1 : one process per GPU (torch.distributed / RCCL), 8192 envs per rank (weak scaling),
+        one all_gather of the packed (obs | reward | termination | truncation) per step.
+
+A "step" is one task.step(): k physics sub-steps + reward + reset + observation for every
+env.  Inputs (state, scenes, actions) are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic bytes per env per env-step, dynamics-only quad (A=4, M=4, obs 13, k=1)
+#   4*(13 state in + 4 action + 4 thrust in + 13 state out + 4 thrust out) = 152 B   -> agx_dynamics_substeps
+#   4*(13 obs + 1 reward) + 2 flags                                       =  58 B   -> reward / obs kernels
+BYTES_DYNAMICS_KERNEL = 152
+BYTES_ENV_STEP = 210
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
+    ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar"])
+    ap.add_argument("--with-depth", action="store_true", help="also time the +depth config (extra keys)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
+    return ap.parse_args()
+
+
+def make_task(workload, num_envs, device, strict_rng):
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    if workload == "dynamics":
+        cfg = position_setpoint_task_config
+        cfg.controller_name = "lee_position_control"
+        cfg.device = device
+        cfg.args = {"strict_rng": strict_rng}
+        return task_registry.make_task("position_setpoint_task", seed=1, num_envs=num_envs, headless=True)
+    cfg = navigation_task_config
+    cfg.device = device
+    cfg.args = {"strict_rng": True}
+    if workload == "lidar":
+        cfg.robot_name = "base_octarotor_with_lidar_32x512"
+        cfg.controller_name = "octarotor_velocity_control"
+    return task_registry.make_task("navigation_task", seed=1, num_envs=num_envs, headless=True)
+
+
+def timed_steps(task, actions, steps, warmup, world, gather_buf=None):
+    import torch.distributed as dist
+
+    def one(i):
+        obs, rew, term, trunc, _ = task.step(actions[i % len(actions)])
+        if gather_buf is not None:
+            packed = torch.cat([obs["observations"], rew.unsqueeze(1), term.unsqueeze(1).float(), trunc.unsqueeze(1).float()], dim=1)
+            dist.all_gather_into_tensor(gather_buf, packed)
+
+    for i in range(warmup):
+        one(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_time_dynamics(task, actions, reps=400):
+    """Average duration of one agx_dynamics_substeps launch, HIP events on torch's current
+    stream (the stream the kernel is launched on).  The queue is pre-filled behind a long
+    blocker kernel so the launches run back-to-back and host launch latency is excluded."""
+    from aerial_gym_simulator_amd import _lib
+
+    env = task.sim_env
+    a = actions[0].contiguous()
+    k = env.num_physics_steps()
+    lib, P, B, n, ptr = env._lib, env._params, env._buffers, env.num_envs, _lib.dptr(a)
+    blocker = torch.randn(4096, 4096, device=a.device)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        for _ in range(6):
+            blocker @ blocker  # keeps the GPU busy while the host enqueues the launches below
+        start.record()
+        s = env._stream()
+        for _ in range(reps):
+            lib.agx_dynamics_substeps(P, B, n, ptr, k, s)
+        stop.record()
+        torch.cuda.synchronize()
+        ms = start.elapsed_time(stop) / reps
+        best = ms if best is None else min(best, ms)
+    return best * 1e-3, k
+
+
+def cpu_baseline_dynamics(num_envs, budget_s=12.0):
+    """The CPU oracle (a C port of the reference's per-env step, oracle/) timed on this box's
+    host cores on the same workload: 8192 envs, position task, Lee position control, k=1."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle as orc
+    from oracle_env import OraclePositionEnv
+
+    from aerial_gym_simulator_amd.config.controller_config import lee_controller_config as L
+    from aerial_gym_simulator_amd.config.robot_config import BaseQuadCfg
+    from aerial_gym_simulator_amd.config.sim_config import BaseSimConfig
+    from aerial_gym_simulator_amd.robots.robot_model import robot_params_dict
+
+    pd = robot_params_dict(BaseQuadCfg, L, "position", BaseSimConfig)
+    n = num_envs
+    mid = lambda a, b: ((np.array(a) + np.array(b)) / 2).astype(np.float32)  # noqa: E731
+    gains = [np.tile(mid(getattr(L, f"K_{k}_tensor_max"), getattr(L, f"K_{k}_tensor_min")), (n, 1)) for k in ("pos", "vel", "rot", "angvel")]
+    ranges = dict(tau_inc=(0.04, 0.04), tau_dec=(0.04, 0.04), thrust=(0.0, 2.0), kT=(0.00000926312, 0.00001826312))
+    env = OraclePositionEnv(pd, n, 500, gains, BaseQuadCfg.init_config.min_init_state, BaseQuadCfg.init_config.max_init_state, ranges)
+    rng = np.random.default_rng(0)
+    draws = lambda: (rng.random((n, 13), np.float32), rng.random((n, 4), np.float32), rng.random((n, 4), np.float32),  # noqa: E731
+                     rng.random((n, 4), np.float32), rng.random((n, 4), np.float32))
+    env.reset_masked(np.ones(n, np.uint8), *draws())
+    actions = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(8)]
+    d = draws()
+    for i in range(5):
+        env.step(actions[i % 8], d)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for i in range(20):
+            env.step(actions[i % 8], d)
+        steps += 20
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {
+        "value": n * steps / dt,
+        "unit": "env-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{steps} env steps of {n} envs ({dt:.1f} s): oracle C port of the per-env step (OpenMP over envs), "
+                  "same task/config as the GPU run",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP GPU (no CPU fallback); use gpurun")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(device))  # RCCL over xGMI
+    n_gpus = max(world, 1)
+    task = make_task(args.workload, args.num_envs, device, args.strict_rng)
+    task.reset()
+    N, A = task.num_envs, task.task_config.action_space_dim
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
+    gather_buf = None
+    if world > 1:
+        obs_dim = task.task_obs["observations"].shape[1]
+        gather_buf = torch.zeros(world * N, obs_dim + 3, device=device)
+    dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf)
+    value = n_gpus * N * args.steps / dt
+    out = {
+        "metric": "env-steps/sec at N_envs=8192 per GPU (" + ("dynamics-only" if args.workload == "dynamics" else "+" + args.workload + " sensor") + ")",
+        "value": value,
+        "unit": "env-steps/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": {"dynamics": "base_quadrotor position_setpoint_task, lee_position_control, empty_env, 1 sub-step/step (BASELINE configs[1])",
+                         "depth": "base_quadrotor navigation_task, lee_velocity_control, 100 random boxes + 6 walls, 10 sub-steps/step, 64x48 depth+seg camera (BASELINE configs[2])",
+                         "lidar": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes, 32x512 LiDAR range+seg (BASELINE configs[3])"}[args.workload],
+            "num_envs_per_gpu": N,
+            "num_envs_total": n_gpus * N,
+            "sharding": f"envs x{n_gpus}, 1 all_gather/step" if world > 1 else "single GPU",
+            "rng": "strict (reference stream, host sync/step)" if (args.strict_rng or args.workload != "dynamics") else "sync-free (draw every step)",
+        },
+    }
+    if rank == 0 and args.workload == "dynamics":
+        kt, k = kernel_time_dynamics(task, actions)
+        achieved = BYTES_DYNAMICS_KERNEL * k * N / kt / 1e9
+        out["roofline"] = {
+            "bound": "hbm",
+            "kernel": "k_dynamics_substeps<4>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "launch_us": kt * 1e6,
+            "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N,
+            "note": "8192 envs move 1.2 MB per launch: launch-latency bound, see roofline_at_scale for the same kernel at 2^21 envs",
+        }
+    if rank == 0 and args.workload == "dynamics" and world == 1:
+        # same kernel where the roofline is meaningful (N = 2^21 envs, 319 MB per launch)
+        try:
+            big = make_task("dynamics", 1 << 21, device, False)
+            big.reset()
+            gb = torch.Generator(device=device).manual_seed(7)
+            ab = [torch.rand(1 << 21, A, device=device, generator=gb) * 2 - 1]
+            for _ in range(3):
+                big.step(ab[0])
+            kt2, k2 = kernel_time_dynamics(big, ab, reps=30)
+            ach2 = BYTES_DYNAMICS_KERNEL * k2 * (1 << 21) / kt2 / 1e9
+            out["roofline_at_scale"] = {"num_envs": 1 << 21, "bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach2 / HBM_PEAK_GBS, "launch_us": kt2 * 1e6,
+                                        "env_steps_per_s_kernel_only": (1 << 21) / kt2}
+            del big
+        except Exception as e:  # noqa: BLE001
+            out["roofline_at_scale"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
+        out["cpu_baseline"] = cpu_baseline_dynamics(N)
+    if rank == 0 and world == 1 and args.with_depth and args.workload == "dynamics":
+        t2 = make_task("depth", args.num_envs, device, True)
+        t2.reset()
+        a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
+        s2 = max(args.steps // 20, 20)
+        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 20, 5), 1)
+        out["plus_depth"] = {"value": N * s2 / dt2, "unit": "env-steps/s", "steps": s2, "ms_per_step": 1e3 * dt2 / s2,
+                             "rays_per_s": N * s2 * 64 * 48 / dt2}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,259 @@
+/*
+ * aerial_gym_hip.h -- C ABI of libaerialgym_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (ntnu-arl/aerial_gym_simulator) has no FFI of its own: its "plugin API" is
+ * Python (string registries + manager classes + one dict of aliasing tensors,
+ * SURVEY.md section 8b).  Behind those Python classes the reference calls three
+ * device back-ends -- PyTorch op chains, NVIDIA Warp kernels, and the Isaac Gym
+ * (PhysX) C API.  Every entry point below replaces one such call site and cites
+ * it.  The Python host (aerial_gym_simulator_amd/) binds them with ctypes, see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*;
+ *     no torch / C++ types cross the boundary.
+ *   - return 0 on success, negative on error (AGX_E_*); text via agx_last_error().
+ *   - no allocation, no ownership transfer, stream-ordered, no host sync.
+ *   - fp32 everywhere; quaternions are xyzw like the reference.
+ *   - env state is SoA, component-major:  X[c * num_envs + env]
+ *     (the reference is AoS [N, C]; the Python host exposes transposed views so
+ *      `robot_position[N,3]` etc. keep their reference shapes).
+ *   - images are [N, S, H, W] row-major exactly like the reference
+ *     (warp_cam.py:134-149 writes pixels[env, cam, y, x]).
+ */
+#ifndef AERIAL_GYM_HIP_H
+#define AERIAL_GYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_ABI_VERSION 1
+#define AGX_MAX_MOTORS 8
+#define AGX_MAX_ACTIONS 8
+#define AGX_MAX_SUBSTEPS 32
+
+enum {
+  AGX_OK = 0,
+  AGX_E_ARG = -1,     /* bad argument (null pointer, size out of range)  */
+  AGX_E_LAUNCH = -2,  /* hipLaunch / runtime error                       */
+  AGX_E_UNSUPPORTED = -3
+};
+
+/* controller ids, one per class registered in aerial_gym/control/__init__.py:42-100 */
+enum {
+  AGX_CTRL_NONE = 0,          /* no_control                                            */
+  AGX_CTRL_POSITION = 1,      /* LeePositionController     position_control.py:20      */
+  AGX_CTRL_VELOCITY = 2,      /* LeeVelocityController     velocity_control.py:18      */
+  AGX_CTRL_ATTITUDE = 3,      /* LeeAttitudeController     attitude_control.py:16      */
+  AGX_CTRL_RATES = 4,         /* LeeRatesController        rates_control.py:16         */
+  AGX_CTRL_ACCELERATION = 5,  /* LeeAccelerationController acceleration_control.py:16  */
+  AGX_CTRL_VEL_STEERING = 6,  /* LeeVelocitySteeringAngleController  :15               */
+  AGX_CTRL_FULLY_ACTUATED = 7 /* FullyActuatedController   fully_actuated_control.py:14 */
+};
+
+/* Constants shared by all envs.  Sources: config/robot_config/ *.py,
+ * config/controller_config/ *.py, config/sim_config/base_sim_config.py,
+ * resources/robots/<robot>/<robot>.urdf (composite mass/inertia computed as in
+ * robots/robot_manager.py:295-435).                                          */
+typedef struct AgxRobotParams {
+  int32_t num_motors;
+  int32_t num_actions;
+  int32_t controller;
+  int32_t root_link_mode;               /* force_application_level == "root_link" */
+  float dt;
+  float gravity[3];
+  float mass;
+  float inertia[9];                     /* row-major, body frame, about COM       */
+  float inertia_inv[9];
+  float alloc[6 * AGX_MAX_MOTORS];      /* allocation_matrix, 6 x M row-major     */
+  float alloc_pinv[AGX_MAX_MOTORS * 6]; /* pinv, M x 6 row-major                  */
+  float wrench_map[6 * AGX_MAX_MOTORS]; /* body wrench per unit motor thrust when
+                                           forces are applied at the motor links  */
+  float motor_dir[AGX_MAX_MOTORS];
+  float cq;
+  int32_t use_rps;
+  int32_t use_discrete_approximation;
+  int32_t integration_rk4;
+  float min_thrust, max_thrust, max_rate;
+  float max_yaw_rate;
+  float lin_drag_linear[3], lin_drag_quadratic[3];
+  float ang_drag_linear[3], ang_drag_quadratic[3];
+  float linear_damping, angular_damping;
+  float max_linear_velocity, max_angular_velocity;
+  float collision_radius;
+} AgxRobotParams;
+
+/* Per-env device buffers of the dynamics path (all SoA, fp32 unless noted).
+ * Keys in parentheses are the reference's global_tensor_dict names.          */
+typedef struct AgxEnvBuffers {
+  float *state;          /* [13][N] p q v w            (robot_state_tensor)            */
+  float *derived;        /* [16][N] euler(3) qveh(4) vveh(3) vbody(3) wbody(3)
+                            (robot_euler_angles, robot_vehicle_orientation,
+                             robot_vehicle_linvel, robot_body_linvel, robot_body_angvel) */
+  float *actions;        /* [A][N] (robot_actions)  -- written from actions_in        */
+  float *prev_actions;   /* [A][N] (robot_prev_actions)                               */
+  float *motor_thrust;   /* [M][N] MotorModel.current_motor_thrust                    */
+  float *motor_kT;       /* [M][N] motor_thrust_constant (use_rps only)               */
+  float *motor_tau_inc;  /* [M][N] motor_time_constants_increasing                    */
+  float *motor_tau_dec;  /* [M][N] motor_time_constants_decreasing                    */
+  float *gains;          /* [12][N] K_pos K_vel K_rot K_angvel (current values)       */
+  float *wrench_cmd;     /* [6][N]  controller output of the LAST sub-step (may be 0)  */
+  uint8_t *crashes;      /* [N] bool (crashes)                                        */
+  uint8_t *truncations;  /* [N] bool (truncations)                                    */
+  int32_t *sim_steps;    /* [N]   EnvManager.sim_steps                                */
+  uint8_t *reset_mask;   /* [N]   envs to reset = crashes*reset_on_collision | truncations
+                            (env_manager.py:364-371), written by the task reward kernels          */
+  int32_t *reset_flag;   /* [1]   device flag: zeroed by agx_dynamics_substeps, set by the
+                            task reward kernel when any env must reset, read by agx_reset_masked */
+  float *bounds_min;     /* [3][N] (env_bounds_min)                                    */
+  float *bounds_max;     /* [3][N] (env_bounds_max)                                    */
+  /* optional inputs */
+  const float *disturb;  /* [k][7][N] per sub-step (bernoulli, 6 x U01) or NULL       */
+  float disturb_max[6];
+  const float *boxes;    /* [K][10][N] obstacle OBBs centre(3) quat(4) half(3) or NULL */
+  int32_t num_boxes;
+} AgxEnvBuffers;
+
+const char *agx_last_error(void);
+int agx_abi_version(void);
+
+/* ---- dynamics -------------------------------------------------------------------
+ * agx_dynamics_substeps: `k` physics sub-steps of every env, fused in one launch.
+ * Replaces, per sub-step: RobotManagerIGE.pre_physics_step (robot_manager.py:486-489),
+ * BaseMultirotor.step (base_multirotor.py:296-307: update_states, clip, controller,
+ * ControlAllocator.allocate_output control_allocation.py:52-114, MotorModel
+ * motor_model.py:88-138, simulate_drag, apply_disturbance),
+ * gym.apply_rigid_body_force_tensors + gym.simulate + refresh_* (IGE_env_manager.py:
+ * 444-449,477,486-495) and EnvManager.compute_observations (env_manager.py:358-362);
+ * plus reset_tensors / sim_steps += 1 of EnvManager.step (env_manager.py:399-432).
+ * actions_in: [N][A] row-major, exactly the tensor the policy hands to task.step().  */
+int agx_dynamics_substeps(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
+                          const float *actions_in, int k_substeps, void *stream);
+
+/* BaseMultirotor.update_states alone (base_multirotor.py:287-294). */
+int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
+
+/* Controller plug-in entry: BaseLeeController subclasses' update(), returning the wrench
+ * [6][N] into buf->wrench_cmd (control/controllers/ *.py).  Uses buf->state/derived as is.
+ * action: [N][A] row-major (clipped to +-10 like BaseMultirotor.clip_actions).          */
+int agx_controller_wrench(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
+                          const float *action, void *stream);
+
+/* ---- tasks ----------------------------------------------------------------------
+ * Position-setpoint task: compute_rewards_and_crashes + truncation test
+ * (position_setpoint_task.py:205-229,245-282,172-174).  Writes reward[N], ORs the
+ * distance crash into crashes, truncations = sim_steps > episode_len, and sets
+ * *buf->reset_flag to 1 if any env is to be reset
+ * (env_manager.py:364-371: crashes*reset_on_collision + truncations).            */
+int agx_reward_position(const AgxEnvBuffers *buf, int num_envs, const float *target /*[3][N]*/,
+                        int episode_len, int reset_on_collision, float *reward, void *stream);
+
+/* process_obs_for_task (position_setpoint_task.py:194-203): obs [N][13] row-major. */
+int agx_obs_position(const AgxEnvBuffers *buf, int num_envs, const float *target, float *obs,
+                     void *stream);
+
+/* Navigation task reward (navigation_task.py:416-521).  rp: 18 floats in the order of
+ * config/task_config/navigation_task_config.py:30-48.  pos_err / prev_pos_err [3][N]. */
+int agx_reward_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
+                          const float *rp, float curriculum_progress, float *pos_err,
+                          float *prev_pos_err, int episode_len, int reset_on_collision,
+                          float *reward, void *stream);
+
+/* ---- reset ----------------------------------------------------------------------
+ * Masked reset, in the order of EnvManager.reset_idx (env_manager.py:273-301):
+ *   env bounds (IsaacGymEnv.reset_idx, IGE_env_manager.py:513-519), robot state
+ *   (BaseMultirotor.reset_idx base_multirotor.py:177-205), controller gains
+ *   (BaseLeeController.randomize_params base_lee_controller.py:101-118, if enabled),
+ *   motor model (MotorModel.reset_idx motor_model.py:140-154), sim_steps[reset] = 0;
+ * and, when *buf->reset_flag != 0, update_states for ALL envs (base_multirotor.py:205):
+ * the reference refreshes every env's derived tensors whenever at least one env resets.
+ * Nothing is touched when the flag is 0.
+ * The uniform draws are inputs, in the AoS layout torch produces them:
+ *   u_bounds_lo/hi [N][3], u_state [N][13], u_gains [N][12] (or NULL),
+ *   u_tau_inc/u_tau_dec/u_thrust/u_kT [N][M].
+ * The reset set is buf->reset_mask.                                                   */
+typedef struct AgxResetArgs {
+  const float *u_bounds_lo, *u_bounds_hi;
+  const float *u_state, *u_gains, *u_tau_inc, *u_tau_dec, *u_thrust, *u_kT;
+  float lower_bound_min[3], lower_bound_max[3], upper_bound_min[3], upper_bound_max[3];
+  float min_state[13], max_state[13];
+  float gains_min[12], gains_max[12];
+  float tau_inc_min, tau_inc_max, tau_dec_min, tau_dec_max, kT_min, kT_max;
+} AgxResetArgs;
+
+int agx_reset_masked(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
+                     const AgxResetArgs *args, void *stream);
+
+/* ---- scene / ray-cast -------------------------------------------------------------
+ * Scene = per-env triangle soup with a fixed topology: T triangles, each owned by one
+ * asset (obstacle) whose pose comes from env_asset_state_tensor.                      */
+
+/* WarpEnv.reset_idx (warp_env_manager.py:40-54): v_world = tf_apply(q_asset, p_asset, v).
+ * tri_local/tri_world: [N][T][9] (a,b,c xyz); tri_asset: [T]; asset_state: [N][K][13].
+ * Only envs with mask[env] != 0 are transformed (mask NULL = all).                    */
+int agx_scene_transform(int num_envs, int num_tris, int num_assets, const float *tri_local,
+                        const int32_t *tri_asset, const float *asset_state, const uint8_t *mask,
+                        float *tri_world, void *stream);
+
+/* wp.Mesh(...) BVH build / mesh.refit() (warp_env_manager.py:162-166, 52-53).
+ * One workgroup per env builds a binary LBVH over the T triangles in LDS and stores
+ * T-1 nodes of 16 floats each: [lo_l(3) child_l | hi_l(3) child_r | lo_r(3) pad | hi_r(3) pad],
+ * child < 0 encodes a leaf: triangle index = ~child.                                   */
+size_t agx_bvh_nodes_bytes(int num_envs, int num_tris);
+int agx_bvh_build(int num_envs, int num_tris, const float *tri_world, const uint8_t *mask,
+                  float *nodes, void *stream);
+
+/* Obstacle OBBs for the collision test, from the same asset poses:
+ * boxes [K][10][N] <- asset_state [N][K][13], half_extents [N][K][3].                  */
+int agx_boxes_from_assets(int num_envs, int num_assets, const float *asset_state,
+                          const float *half_extents, const uint8_t *mask, float *boxes,
+                          void *stream);
+
+/* WarpSensor.update pose composition (warp_sensor.py:177-187).
+ * local_pos [N][S][3], local_quat [N][S][4], frame_quat [4] -> pos [N][S][3], quat [N][S][4] */
+int agx_sensor_pose(const AgxEnvBuffers *buf, int num_envs, int num_sensors,
+                    const float *local_pos, const float *local_quat, const float *frame_quat,
+                    float *pos, float *quat, void *stream);
+
+enum { AGX_RAY_RANGE = 0, AGX_RAY_DEPTH = 1, AGX_RAY_POINTCLOUD = 2, AGX_RAY_POINTCLOUD_WORLD = 3 };
+
+/* DepthCameraWarpKernels.draw_optimized_kernel_{depth_range,depth_range_segmentation,
+ * pointcloud,pointcloud_segmentation} (warp_camera_kernels.py:176-282, 13-66, 125-172).
+ * kinv = {K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]} (warp_cam.py:31-64).
+ * pixels [N][S][H][W] (or x3), seg [N][S][H][W] int32 or NULL; tri_seg [N][T] int32.    */
+int agx_raycast_camera(int num_envs, int num_sensors, int width, int height, const float *kinv,
+                       float far_plane, int c_x, int c_y, int mode, const float *cam_pos,
+                       const float *cam_quat, const float *tri_world, const int32_t *tri_seg,
+                       const float *nodes, int num_tris, float *pixels, int32_t *seg,
+                       void *stream);
+
+/* LidarWarpKernels.draw_optimized_kernel_{range,range_segmentation,pointcloud,
+ * pointcloud_segmentation} (warp_lidar_kernels.py:167-194,130-163,13-86).
+ * ray_vectors [H][W][3] (warp_lidar.py:40-64).                                          */
+int agx_raycast_lidar(int num_envs, int num_sensors, int width, int height,
+                      const float *ray_vectors, float far_plane, int mode, const float *pos,
+                      const float *quat, const float *tri_world, const int32_t *tri_seg,
+                      const float *nodes, int num_tris, float *pixels, int32_t *seg, void *stream);
+
+/* WarpSensor.apply_noise / apply_range_limits / normalize_observation
+ * (warp_sensor.py:202-247), scalar images, in place.  z_normal/u_dropout optional.     */
+int agx_sensor_postprocess(size_t count, float *pixels, const float *z_normal,
+                           const float *u_dropout, float std_a, float std_b, float std_c,
+                           float mean_offset, float dropout_prob, float min_range,
+                           float max_range, float far_oor, float near_oor, int normalize,
+                           void *stream);
+
+/* NavigationTask.post_image_reward_addition's min over the image
+ * (navigation_task.py:351-357): min_pixel[N] = min(10*img, with img<0 -> 10).          */
+int agx_image_min(int num_envs, int pixels_per_env, const float *pixels, float *min_pixel,
+                  void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AERIAL_GYM_HIP_H */

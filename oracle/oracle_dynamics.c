@@ -195,6 +195,7 @@ static void rotmat_to_quat_xyzw(const float m[9], float q[4]) {
 /* ------------------------------------------------------------------ */
 void orc_update_states(int n, const float *state, float *euler, float *qveh, float *vveh,
                        float *vbody, float *wbody) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float *s = state + 13 * i;
     const float *q = s + 3, *v = s + 7, *w = s + 10;
@@ -501,6 +502,7 @@ void orc_substep(const OrcRobotParams *P, int n, float *state, const float *acti
                  float *body_wrench, int do_integrate) {
   const int M = P->num_motors, A = P->num_actions;
   orc_update_states(n, state, euler, qveh, vveh, vbody, wbody);
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     float *s = state + 13 * i;
     float *a = action_clipped + A * i;
@@ -572,6 +574,7 @@ void orc_integrate(const OrcRobotParams *P, int n, float *state, const float *bo
 /* ------------------------------------------------------------------ */
 void orc_collide_sphere_boxes(int n, int nb, float radius, const float *state, const float *boxes,
                               uint8_t *crashes) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float *p = state + 13 * i;
     uint8_t hit = 0;
@@ -597,6 +600,7 @@ void orc_collide_sphere_boxes(int n, int nb, float radius, const float *state, c
 /* ------------------------------------------------------------------ */
 void orc_reward_position(int n, const float *state, const float *qveh, const float *wbody,
                          const float *target, uint8_t *crashes, float *reward) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float *p = state + 13 * i, *q = p + 3;
     float d[3] = {target[3 * i] - p[0], target[3 * i + 1] - p[1], target[3 * i + 2] - p[2]};
@@ -623,6 +627,7 @@ void orc_reward_position(int n, const float *state, const float *qveh, const flo
 
 void orc_obs_position(int n, const float *state, const float *vbody, const float *wbody,
                       const float *target, float *obs) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     const float *s = state + 13 * i;
     float *o = obs + 13 * i;

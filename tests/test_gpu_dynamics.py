@@ -1,0 +1,238 @@
+"""GPU parity tests of the dynamics path: HIP kernels (through the C ABI) vs the CPU oracle on
+the same inputs, and vs the golden vectors of the reference.  Tolerance: fp32 state within
+1e-5 per step (north_star); flags bit-exact."""
+import numpy as np
+import pytest
+import torch
+from conftest import golden_params, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+STEP_CASES = ["quad_position", "quad_velocity", "quad_attitude", "quad_acceleration", "quad_no_control",
+              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated"]
+TOL = 1e-5
+
+
+def _angle_err(a, b):
+    d = np.abs(a - b)
+    return float(np.minimum(d, 2 * np.pi - d).max())
+
+
+def _derived_split(d):
+    return d[:, 0:3], d[:, 3:7], d[:, 7:10], d[:, 10:13], d[:, 13:16]
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_single_substep_vs_oracle_and_golden(orc, case):
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    n = g["state"].shape[1]
+    P = orc.make_params(pd)
+    H = DynHarness(pd, n)
+    H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"])
+    H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+    for k in range(g["state"].shape[0]):
+        st, th = g["state"][k].copy(), g["thrust_in"][k].copy()
+        dist = g["disturb"][k] if g["disturb"][k].any() else None
+        o = orc.substep(P, st, g["action"][k], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"],
+                        g["Kw"], disturb=dist, disturb_max=g["disturb_max"], integrate=True)
+        H.set(state=g["state"][k], thrust=g["thrust_in"][k])
+        if dist is not None:
+            H.set_disturb(dist[None], g["disturb_max"])
+        H.substeps(g["action"][k], 1)
+        gs, gt, gd = H.get("state"), H.get("thrust"), H.get("derived")
+        assert rel_err(gs, st) < TOL, (case, k, "state vs oracle")
+        assert rel_err(gt, th) < TOL, (case, k)
+        e, qv, vv, vb, wb = _derived_split(gd)
+        assert _angle_err(e, o.euler) < TOL
+        for got, ref, gold in ((qv, o.qveh, g["qveh"][k]), (vv, o.vveh, g["vveh"][k]), (vb, o.vbody, g["vbody"][k]),
+                               (wb, o.wbody, g["wbody"][k])):
+            assert rel_err(got, ref) < TOL
+            assert rel_err(got, gold) < TOL  # the reference's own numbers
+        assert rel_err(gt, g["thrust_out"][k]) < TOL
+        if "no_control" not in case:
+            assert rel_err(H.get("wrench"), g["wrench_cmd"][k]) < TOL
+            assert rel_err(H.get("wrench"), o.wrench_cmd) < TOL
+        assert np.array_equal(H.get("actions"), g["action"][k])
+
+
+@pytest.mark.parametrize("case", ["quad_position", "octarotor_velocity"])
+def test_fused_k_substeps_equal_k_launches(orc, case):
+    """10 fused sub-steps == 10 oracle sub-steps (config 3/4 use 10, env_with_obstacles.py:29)."""
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    n = g["state"].shape[1]
+    P = orc.make_params(pd)
+    K = 10
+    H = DynHarness(pd, n)
+    H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"], state=g["state"][0], thrust=g["thrust_in"][0])
+    H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+    rng = np.random.default_rng(5)
+    dist = np.zeros((K, n, 7), np.float32)
+    use_dist = case.startswith("octarotor")
+    if use_dist:
+        dist[:, :, 0] = rng.random((K, n)) < 0.3
+        dist[:, :, 1:] = rng.random((K, n, 6))
+        H.set_disturb(dist, g["disturb_max"])
+    st, th = g["state"][0].copy(), g["thrust_in"][0].copy()
+    act = g["action"][0]
+    for s in range(K):
+        o = orc.substep(P, st, act, th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"], g["Kw"],
+                        disturb=dist[s] if use_dist else None, disturb_max=g["disturb_max"])
+    H.substeps(act, K)
+    assert rel_err(H.get("state"), st) < 5e-5  # 10 steps of <= 1e-5 each
+    assert rel_err(H.get("thrust"), th) < 5e-5
+    # derived tensors are those of the LAST sub-step's pre-physics state (stale by one step)
+    assert rel_err(H.get("derived")[:, 10:16], np.concatenate([o.vbody, o.wbody], axis=1)) < 5e-5
+    assert np.array_equal(H.get("prev_actions"), act)  # appendix A #2
+    assert int(H.sim_steps.cpu()[0]) == 1
+
+
+def test_collision_flags_bit_exact(orc):
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_quad_position")
+    pd = golden_params(g)
+    n, K = 256, 24
+    rng = np.random.default_rng(11)
+    state = np.zeros((n, 13), np.float32)
+    state[:, 0:3] = rng.uniform(-2, 2, (n, 3))
+    state[:, 6] = 1
+    boxes = np.zeros((n, K, 10), np.float32)
+    boxes[..., 0:3] = rng.uniform(-2.5, 2.5, (n, K, 3))
+    q = rng.normal(size=(n, K, 4))
+    boxes[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    boxes[..., 7:10] = rng.uniform(0.05, 0.6, (n, K, 3))
+    H = DynHarness(pd, n)
+    H.set(state=state, thrust=np.full((n, 4), 0.6, np.float32), kT=np.full((n, 4), 1.2e-5, np.float32),
+          tau_inc=np.full((n, 4), 0.04, np.float32), tau_dec=np.full((n, 4), 0.04, np.float32))
+    H.set_gains(*(np.tile(g[k][:1], (n, 1)) for k in ("Kp", "Kv", "KR", "Kw")))
+    H.set_boxes(boxes)
+    act = np.zeros((n, 4), np.float32)
+    act[:, 0:3] = state[:, 0:3]  # hold position
+    H.substeps(act, 1)
+    got = H.crashes.cpu().numpy()
+    # the predicate is evaluated on the post-step position: feed the kernel's own state to the oracle
+    crashes = np.zeros(n, np.uint8)
+    orc.collide_sphere_boxes(pd["collision_radius"], H.get("state"), boxes, crashes)
+    assert np.array_equal(got, crashes.astype(bool))
+    assert 0.1 < crashes.mean() < 0.9
+
+
+def test_reward_obs_position(orc):
+    from gpu_harness import DynHarness
+
+    g = load_golden("reward_position")
+    pd = golden_params(load_golden("step_quad_position"))
+    n = g["state"].shape[0]
+    H = DynHarness(pd, n)
+    derived = np.zeros((n, 16), np.float32)
+    derived[:, 3:7], derived[:, 10:13], derived[:, 13:16] = g["qveh"], g["vbody"], g["wbody"]
+    H.set(state=g["state"], derived=derived)
+    H.crashes.copy_(torch.from_numpy(g["crashes_in"]))
+    H.sim_steps.copy_(torch.arange(n, dtype=torch.int32) % 7 + 498)
+    r = H.reward_position(g["target"], 500)
+    assert rel_err(r, g["reward"]) < TOL
+    assert np.array_equal(H.crashes.cpu().numpy(), g["crashes_out"])
+    trunc = (np.arange(n) % 7 + 498) > 500
+    assert np.array_equal(H.trunc.cpu().numpy(), trunc)
+    assert np.array_equal(H.reset_mask.cpu().numpy().astype(bool), g["crashes_out"] | trunc)
+    assert int(H.reset_flag.cpu()[0]) == 1
+    assert np.array_equal(H.obs_position(g["target"]), g["obs"])
+
+
+def test_reward_navigation(orc):
+    from gpu_harness import DynHarness
+
+    g = load_golden("reward_navigation")
+    pd = golden_params(load_golden("step_quad_velocity"))
+    n = g["state"].shape[0]
+    H = DynHarness(pd, n)
+    derived = np.zeros((n, 16), np.float32)
+    derived[:, 3:7] = g["qveh"]
+    H.set(state=g["state"], derived=derived, actions=g["action"], prev_actions=g["prev_action"])
+    H.crashes.copy_(torch.from_numpy(g["crashes"]))
+    r, pe, ppe = H.reward_navigation(g["target"], g["rp"], float(g["curriculum_progress"]), g["prev_pos_err"],
+                                     np.zeros_like(g["pos_err"]), 100)
+    assert rel_err(pe, g["pos_err"]) < TOL
+    assert np.array_equal(ppe, g["prev_pos_err"])
+    assert rel_err(r, g["reward"]) < TOL
+
+
+def test_reset_masked_vs_oracle(orc):
+    from gpu_harness import DynHarness
+
+    g = load_golden("trace_position_64")
+    pd = golden_params(g)
+    n = g["init_state"].shape[0]
+    H = DynHarness(pd, n)
+    ranges = dict(tau_inc=(0.04, 0.04), tau_dec=(0.04, 0.04), kT=(0.00000926312, 0.00001826312))
+    rng = np.random.default_rng(3)
+    mask = (rng.random(n) < 0.4).astype(np.uint8)
+    state0 = g["state_after_step"][10]
+    H.set(state=state0, thrust=g["init_thrust"], kT=g["init_kT"], tau_inc=g["init_tau_inc"], tau_dec=g["init_tau_dec"])
+    H.sim_steps.fill_(7)
+    u = dict(u_bounds_lo=rng.random((n, 3)), u_bounds_hi=rng.random((n, 3)), u_state=g["init_u_state"],
+             u_tau_inc=g["init_u_tau_inc"], u_tau_dec=g["init_u_tau_dec"], u_thrust=g["init_u_thrust"], u_kT=g["init_u_kT"])
+    e = 1.0
+    H.reset_masked(mask, u, ranges, g["min_init_state"], g["max_init_state"], ([-e] * 3, [-e] * 3, [e] * 3, [e] * 3))
+    ref = state0.copy()
+    orc.reset_robot_state(mask, g["init_u_state"], g["min_init_state"], g["max_init_state"], -np.ones((n, 3), np.float32),
+                          np.ones((n, 3), np.float32), ref)
+    got = H.get("state")
+    assert rel_err(got, ref) < 1e-6
+    m = mask.astype(bool)
+    assert np.array_equal(got[~m], state0[~m])
+    assert rel_err(H.get("thrust")[m], g["init_thrust"][m]) < 1e-6  # same draws as the reference's initial reset
+    assert np.array_equal(H.get("thrust")[~m], g["init_thrust"][~m])
+    assert rel_err(H.get("kT")[m], g["init_kT"][m]) < 1e-6
+    steps = H.sim_steps.cpu().numpy()
+    assert np.all(steps[m] == 0) and np.all(steps[~m] == 7)
+    # derived refreshed for ALL envs
+    eu, qv, vv, vb, wb = orc.update_states(got)
+    assert rel_err(H.get("derived")[:, 3:7], qv) < TOL and rel_err(H.get("derived")[:, 13:16], wb) < TOL
+    # nothing happens when no env resets
+    before = H.get("derived").copy()
+    H.set(state=state0)
+    H.reset_masked(np.zeros(n, np.uint8), u, ranges, g["min_init_state"], g["max_init_state"], ([-e] * 3, [-e] * 3, [e] * 3, [e] * 3))
+    assert np.array_equal(H.get("derived"), before)
+
+
+def test_large_batch_properties(orc):
+    """BASELINE config-2 size (8192 envs): shard-concatenation equivalence (envs independent) and
+    agreement with the oracle on a random subset."""
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_quad_position")
+    pd = golden_params(g)
+    n = 8192
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, g["state"].shape[1], n)
+    state, thrust = g["state"][0][idx], g["thrust_in"][0][idx]
+    state = (state + rng.normal(scale=0.05, size=state.shape)).astype(np.float32)
+    state[:, 3:7] /= np.linalg.norm(state[:, 3:7], axis=1, keepdims=True)
+    act = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    arrs = dict(kT=g["kT"][idx], tau_inc=g["tau_inc"][idx], tau_dec=g["tau_dec"][idx])
+    H = DynHarness(pd, n)
+    H.set(state=state, thrust=thrust, **arrs)
+    H.set_gains(g["Kp"][idx], g["Kv"][idx], g["KR"][idx], g["Kw"][idx])
+    H.substeps(act, 3)
+    full = H.get("state")
+    half = n // 2
+    for lo in (0, half):
+        Hs = DynHarness(pd, half)
+        Hs.set(state=state[lo:lo + half], thrust=thrust[lo:lo + half], **{k: v[lo:lo + half] for k, v in arrs.items()})
+        Hs.set_gains(*(g[k][idx][lo:lo + half] for k in ("Kp", "Kv", "KR", "Kw")))
+        Hs.substeps(act[lo:lo + half], 3)
+        assert np.array_equal(Hs.get("state"), full[lo:lo + half])  # bit-identical: no cross-env coupling
+    sub = rng.choice(n, 512, replace=False)
+    st, th = state[sub].copy(), thrust[sub].copy()
+    P = orc.make_params(pd)
+    for _ in range(3):
+        orc.substep(P, st, act[sub], th, arrs["kT"][sub], arrs["tau_inc"][sub], arrs["tau_dec"][sub], g["Kp"][idx][sub],
+                    g["Kv"][idx][sub], g["KR"][idx][sub], g["Kw"][idx][sub])
+    assert rel_err(full[sub], st) < 3e-5

@@ -1,0 +1,145 @@
+"""CPU: pins the C oracle against golden vectors produced by the REFERENCE's own torch code
+(tests/golden/*.npz, oracle/gen_golden.py).  Tolerances are relative to 1 + max|ref|."""
+import numpy as np
+import pytest
+from conftest import golden_params, load_golden, rel_err
+
+STEP_CASES = ["quad_position", "quad_velocity", "quad_attitude", "quad_acceleration", "quad_no_control",
+              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated"]
+
+
+def test_math_helpers(orc):
+    g = load_golden("math_utils")
+    n = g["q"].shape[0]
+    assert rel_err(orc.quat_mul(g["q"], g["q2"]), g["quat_mul"]) < 1e-6
+    assert rel_err(orc.quat_from_euler(g["e"]), g["quat_from_euler"]) < 1e-6
+    assert rel_err(orc.tf_apply(g["q"], g["t"], g["v"]), g["tf_apply"]) < 1e-6
+    state = np.zeros((n, 13), np.float32)
+    state[:, 3:7], state[:, 7:10], state[:, 10:13] = g["q"], g["v"], g["v"]
+    euler, qveh, vveh, vbody, wbody = orc.update_states(state)
+    # angles are compared modulo 2 pi (ssa wraps at +-pi)
+    d = np.abs(euler - g["ssa_euler"])
+    assert np.minimum(d, 2 * np.pi - d).max() < 2e-6
+    assert rel_err(qveh, g["vehicle_quat"]) < 1e-6
+    assert rel_err(vbody, g["quat_rotate_inverse"]) < 1e-6
+    assert rel_err(wbody, g["quat_rotate_inverse"]) < 1e-6
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_substep_matches_reference(orc, case):
+    """BaseMultirotor.step of the reference vs orc_substep (rows a1-a14)."""
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    P = orc.make_params(pd)
+    W = np.array(pd["wrench_map"], np.float32).reshape(6, -1)
+    mask = g["application_mask"]
+    for k in range(g["state"].shape[0]):
+        st, th = g["state"][k].copy(), g["thrust_in"][k].copy()
+        dist = g["disturb"][k] if g["disturb"][k].any() else None
+        o = orc.substep(P, st, g["action"][k], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"],
+                        g["Kw"], disturb=dist, disturb_max=g["disturb_max"], integrate=False)
+        d = np.abs(o.euler - g["euler"][k])
+        assert np.minimum(d, 2 * np.pi - d).max() < 2e-6
+        for name, got in (("qveh", o.qveh), ("vveh", o.vveh), ("vbody", o.vbody), ("wbody", o.wbody)):
+            assert rel_err(got, g[name][k]) < 1e-6, (case, k, name)
+        if "no_control" not in case:
+            assert rel_err(o.wrench_cmd, g["wrench_cmd"][k]) < 2e-6, (case, k)
+        assert rel_err(th, g["thrust_out"][k]) < 5e-6, (case, k)
+        assert rel_err(o.action_clipped, g["action_after"][k]) < 1e-7, (case, k)
+        u = g["force"][k][:, mask, 2]
+        bw = u @ W.T
+        bw[:, 0:3] += g["force"][k][:, 0, :]
+        bw[:, 3:6] += g["torque"][k][:, 0, :]
+        assert rel_err(o.body_wrench, bw) < 3e-6, (case, k)
+        # per-motor force / torque tensors of control_allocation.py:103-114
+        cq, md = pd["cq"], np.array(pd["motor_dir"], np.float32)[: pd["num_motors"]]
+        assert rel_err(g["torque"][k][:, mask, 2], -cq * md[None, :] * th) < 5e-6
+
+
+def test_hover_equilibrium_kat(orc):
+    """KAT: Lee position control at the setpoint, level, at rest => thrust = m g, torque = 0."""
+    g = load_golden("step_quad_position")
+    pd = golden_params(g)
+    P = orc.make_params(pd)
+    n = 4
+    st = np.zeros((n, 13), np.float32)
+    st[:, 6] = 1.0
+    th = np.full((n, 4), 0.6, np.float32)
+    o = orc.substep(P, st, np.zeros((n, 4), np.float32), th, g["kT"][:n], g["tau_inc"][:n], g["tau_dec"][:n],
+                    g["Kp"][:n], g["Kv"][:n], g["KR"][:n], g["Kw"][:n], integrate=False)
+    assert np.allclose(o.wrench_cmd[:, 2], 0.25 * 9.81, rtol=1e-6)
+    assert np.abs(o.wrench_cmd[:, 3:]).max() < 1e-7
+
+
+def test_allocation_identity_kat(orc):
+    """A A+ w = w on the quad's rank-4 subspace (control_allocation.py:32-34 warns rank 4)."""
+    pd = golden_params(load_golden("step_quad_position"))
+    A = np.array(pd["alloc"], np.float64).reshape(6, 4)
+    Ap = np.array(pd["alloc_pinv"], np.float64).reshape(4, 6)
+    w = np.array([0, 0, 2.4, 0.01, -0.02, 0.003])
+    assert np.allclose(A @ (Ap @ w), w, atol=1e-7)
+
+
+def test_octarotor_wrench_map_differs_from_allocation():
+    """The octarotor config's allocation matrix embeds cq = 0.1 while the motor model applies
+    cq = 0.01 at the links: the physically applied wrench (URDF frames) is NOT A u."""
+    r = load_golden("robot_octarotor")
+    assert np.abs(r["wrench_map"][:3] - r["alloc"][:3]).max() < 1e-7
+    assert np.abs(r["wrench_map"][3:] - r["alloc"][3:]).max() > 0.05
+    q = load_golden("robot_quad")
+    assert np.abs(q["wrench_map"] - q["alloc"]).max() < 1e-12
+
+
+def test_position_reward_and_obs(orc):
+    g = load_golden("reward_position")
+    crashes = g["crashes_in"].astype(np.uint8)
+    r = orc.reward_position(g["state"], g["qveh"], g["wbody"], g["target"], crashes)
+    assert rel_err(r, g["reward"]) < 2e-6
+    assert np.array_equal(crashes.astype(bool), g["crashes_out"])
+    assert np.array_equal(orc.obs_position(g["state"], g["vbody"], g["wbody"], g["target"]), g["obs"])
+
+
+def test_navigation_reward(orc):
+    g = load_golden("reward_navigation")
+    pe = np.ascontiguousarray(g["prev_pos_err"]).copy()  # becomes "current" inside, then prev <- cur
+    ppe = np.zeros_like(pe)
+    r = orc.reward_navigation(g["state"], g["qveh"], g["target"], g["action"], g["prev_action"],
+                              float(g["curriculum_progress"]), g["rp"], pe, ppe, g["crashes"].astype(np.uint8))
+    assert rel_err(pe, g["pos_err"]) < 1e-6
+    assert rel_err(ppe, g["prev_pos_err"]) == 0.0
+    assert rel_err(r, g["reward"]) < 3e-6
+
+
+@pytest.mark.parametrize("tag", ["position", "attitude"])
+def test_trace_config1(orc, tag):
+    """BASELINE config 1 (64 envs, empty_env): oracle loop vs the trace assembled from the
+    reference's control / reward / reset code (+ oracle integrator).  Chaotic divergence is
+    bounded by comparing teacher-forced one-step predictions AND the free-running trace."""
+    from oracle_env import OraclePositionEnv
+
+    g = load_golden(f"trace_{tag}_64")
+    pd = golden_params(g)
+    n = g["init_state"].shape[0]
+    ranges = dict(tau_inc=(0.04, 0.04), tau_dec=(0.04, 0.04), thrust=(0.0, 2.0), kT=(0.00000926312, 0.00001826312))
+    env = OraclePositionEnv(pd, n, int(g["episode_len"]), (g["Kp"], g["Kv"], g["KR"], g["Kw"]),
+                            g["min_init_state"], g["max_init_state"], ranges)
+    env.reset_masked(np.ones(n, np.uint8), g["init_u_state"], g["init_u_tau_inc"], g["init_u_tau_dec"],
+                     g["init_u_thrust"], g["init_u_kT"])
+    assert rel_err(env.state, g["init_state"]) < 1e-6
+    assert rel_err(env.thrust, g["init_thrust"]) < 1e-6
+    assert rel_err(env.kT, g["init_kT"]) < 1e-6
+    T = g["action"].shape[0]
+    worst_r = worst_s = early_s = 0.0
+    for t in range(T):
+        draws = (g["u_state"][t], g["u_tau_inc"][t], g["u_tau_dec"][t], g["u_thrust"][t], g["u_kT"][t])
+        obs, rew, crashes, trunc, reset_mask, state_after = env.step(g["action"][t], draws)
+        assert np.array_equal(reset_mask.astype(bool), g["reset_mask"][t]), t
+        assert np.array_equal(trunc.astype(bool), g["truncations"][t]), t
+        worst_s = max(worst_s, rel_err(state_after, g["state_after_step"][t]))
+        if t < 20:
+            early_s = worst_s
+        worst_r = max(worst_r, rel_err(rew, g["reward"][t]))
+        assert rel_err(obs, g["obs"][t]) < 5e-4, t
+    # fp32 noise grows along the free-running (closed-loop but chaotic under random actions) trace
+    assert early_s < 5e-5, early_s  # ~1e-6 per step
+    assert worst_s < 1e-3 and worst_r < 1e-3, (worst_s, worst_r)
