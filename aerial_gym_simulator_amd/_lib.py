@@ -127,6 +127,8 @@ _SIGNATURES = {
         C.c_int,
         [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.POINTER(C.c_float), C.c_float, _P, _P, C.c_int, C.c_int, _P, _P],
     ),
+    "agx_obs_navigation": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, _P, _P]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
     "agx_scene_transform": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_bvh_nodes_bytes": (C.c_size_t, [C.c_int, C.c_int]),

@@ -519,6 +519,46 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
   if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag, 1);
 }
 
+// navigation_task.py:369-393; one wave per env so the depth min-pool is a coalesced sweep
+__global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
+                                                         const float *__restrict__ u_vec, const float *__restrict__ u_euler,
+                                                         const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
+                                                         int obs_dim, float *__restrict__ obs) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  float *o = obs + (size_t)i * obs_dim;
+  if (lane == 0) {
+    V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
+    Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
+    V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
+    V3 v = quat_rotate_inverse(qveh, tgt - p);
+    // 0.1 * 2 * rand_like(vec - 0.5): the -0.5 sits inside rand_like in the reference (:374)
+    V3 pv = V3{v.x + 0.1f * 2.0f * u_vec[(size_t)i * 3], v.y + 0.1f * 2.0f * u_vec[(size_t)i * 3 + 1],
+               v.z + 0.1f * 2.0f * u_vec[(size_t)i * 3 + 2]};
+    float dist = norm(v);
+    o[0] = pv.x / dist; o[1] = pv.y / dist; o[2] = pv.z / dist; o[3] = dist;
+    float e0 = ssa(B.derived[0 * n + i]), e1 = ssa(B.derived[1 * n + i]);
+    o[4] = e0 + 0.1f * (u_euler[(size_t)i * 3] - 0.5f);
+    o[5] = e1 + 0.1f * (u_euler[(size_t)i * 3 + 1] - 0.5f);
+    o[6] = 0.0f;
+    o[7] = B.derived[10 * n + i]; o[8] = B.derived[11 * n + i]; o[9] = B.derived[12 * n + i];
+    o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
+    o[13] = B.actions[0 * n + i]; o[14] = B.actions[1 * n + i]; o[15] = B.actions[2 * n + i]; o[16] = B.actions[3 * n + i];
+  }
+  if (pixels) {
+    const float *img = pixels + (size_t)i * ns * H * W;  // sensor 0
+    const int ch = (H + gh - 1) / gh, cw = (W + gw - 1) / gw;
+    for (int cell = lane; cell < gh * gw; cell += 64) {
+      int cy = cell / gw, cx = cell % gw;
+      float m = INFINITY;
+      for (int y = cy * ch; y < min((cy + 1) * ch, H); ++y)
+        for (int x = cx * cw; x < min((cx + 1) * cw, W); ++x) m = fminf(m, img[(size_t)y * W + x]);
+      if (17 + cell < obs_dim) o[17 + cell] = m;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Reset (base_multirotor.py:177-205, motor_model.py:140-154, env_manager.py:301)
 // ---------------------------------------------------------------------------------------
@@ -670,6 +710,18 @@ extern "C" int agx_reward_navigation(const AgxEnvBuffers *B, int n, const float 
   hipLaunchKernelGGL(k_reward_navigation, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *B, n, 4, target,
                      R, cpf, pos_err, prev_pos_err, episode_len, reset_on_collision, reward);
   return check_launch("agx_reward_navigation");
+}
+
+extern "C" int agx_obs_navigation(const AgxEnvBuffers *B, int n, const float *target, const float *u_vec,
+                                  const float *u_euler, const float *pixels, int ns, int H, int W, int gh, int gw,
+                                  int obs_dim, float *obs, void *stream) {
+  if (int e = check_common(nullptr, B, n)) return e;
+  AGX_REQUIRE(target && u_vec && u_euler && obs && B->state && B->derived && B->actions, "null buffer");
+  AGX_REQUIRE(obs_dim >= 17, "obs_dim must be >= 17");
+  AGX_REQUIRE(!pixels || (ns > 0 && H > 0 && W > 0 && gh > 0 && gw > 0), "bad image sizes");
+  hipLaunchKernelGGL(k_obs_navigation, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec,
+                     u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs);
+  return check_launch("agx_obs_navigation");
 }
 
 extern "C" int agx_reset_masked(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R,

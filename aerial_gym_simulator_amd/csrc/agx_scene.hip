@@ -195,8 +195,9 @@ __global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int nt, int npad, con
   for (int i = tid; i < nt; i += kBvhThreads) {
     int node = parent[n_int + i];
     while (node >= 0) {
-      __threadfence_block();
+      __threadfence_block();  // release: this thread's box is written before the arrival
       if (atomicAdd(&counter[node], 1) == 0) break;
+      __threadfence_block();  // acquire: the sibling's box is read after the arrival
       const float *a = box + (size_t)child[2 * node] * 6, *b = box + (size_t)child[2 * node + 1] * 6;
       float *o = box + (size_t)node * 6;
 #pragma unroll

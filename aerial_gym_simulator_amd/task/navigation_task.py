@@ -1,0 +1,195 @@
+"""NavigationTask with the reference's API and step ordering
+(aerial_gym/task/navigation_task/navigation_task.py:24-357).  Reward / truncation / reset set,
+observation packing and the image min run in the HIP library; success / timeout bookkeeping
+and the curriculum stay as (tiny) host logic like the reference.
+
+The reference encodes the depth image with a pre-trained VAE (dense conv net, outside the
+simulation hot path); with `vae_config.use_vae = False` (default here) the 64
+latent slots carry an 8 x 8 min-pooled depth grid instead."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..sim.sim_builder import SimBuilder
+from ..tensors import aos_view, soa
+from ..utils.logging import CustomLogger
+from ..utils.spaces import Box, Dict
+from .base_task import BaseTask
+
+logger = CustomLogger("navigation_task")
+
+
+class NavigationTask(BaseTask):
+    def __init__(self, task_config, seed=None, num_envs=None, headless=None, device=None, use_warp=None):
+        for name, val in (("seed", seed), ("num_envs", num_envs), ("headless", headless), ("device", device),
+                          ("use_warp", use_warp)):
+            if val is not None:
+                setattr(task_config, name, val)
+        super().__init__(task_config)
+        cfg = self.task_config
+        self.device = cfg.device
+        self.sim_env = SimBuilder().build_env(
+            sim_name=cfg.sim_name, env_name=cfg.env_name, robot_name=cfg.robot_name,
+            controller_name=cfg.controller_name, args=cfg.args, device=self.device, num_envs=cfg.num_envs,
+            use_warp=cfg.use_warp, headless=cfg.headless,
+        )
+        N, dev = self.sim_env.num_envs, self.device
+        self.num_envs = N
+        self.target_soa = soa(3, N, dev)
+        self.target_position = aos_view(self.target_soa)
+        self.target_min_ratio = torch.tensor(cfg.target_min_ratio, device=dev).expand(N, -1)
+        self.target_max_ratio = torch.tensor(cfg.target_max_ratio, device=dev).expand(N, -1)
+        self.success_aggregate = self.crashes_aggregate = self.timeouts_aggregate = 0
+        self.pos_err_soa, self.prev_pos_err_soa = soa(3, N, dev), soa(3, N, dev)
+        self.pos_error_vehicle_frame = aos_view(self.pos_err_soa)
+        self.pos_error_vehicle_frame_prev = aos_view(self.prev_pos_err_soa)
+        if cfg.vae_config.use_vae:
+            raise NotImplementedError("the VAE image encoder is out of scope (SURVEY.md row 14); set use_vae = False")
+        self.obs_dict = self.sim_env.get_obs()
+        if "curriculum_level" not in self.obs_dict:
+            self.curriculum_level = cfg.curriculum.min_level
+            self.obs_dict["curriculum_level"] = self.curriculum_level
+        else:
+            self.curriculum_level = self.obs_dict["curriculum_level"]
+        self.obs_dict["num_obstacles_in_env"] = self.curriculum_level
+        self._update_progress()
+        self.terminations = self.obs_dict["crashes"]
+        self.truncations = self.obs_dict["truncations"]
+        self.rewards = torch.zeros(N, device=dev)
+        self.min_pixel_dist = torch.zeros(N, device=dev)
+        self.observation_space = Dict(
+            {"observations": Box(low=-1.0, high=1.0, shape=(cfg.observation_space_dim,), dtype=np.float32)}
+        )
+        self.action_space = Box(low=-1.0, high=1.0, shape=(4,), dtype=np.float32)
+        self.action_transformation_function = cfg.action_transformation_function
+        self.task_obs = {"observations": torch.zeros((N, cfg.observation_space_dim), device=dev)}
+        self.num_task_steps = 0
+        self.infos = {}
+        self._rp = (C.c_float * 18)(*[float(cfg.reward_parameters[k]) for k in cfg.REWARD_PARAMETER_ORDER])
+        self._u_vec = torch.zeros(N, 3, device=dev)
+        self._u_euler = torch.zeros(N, 3, device=dev)
+        self.curriculum_check_every = int(cfg.args.get("curriculum_check_every", 1)) if isinstance(cfg.args, dict) else 1
+
+    def _update_progress(self):
+        c = self.task_config.curriculum
+        self.curriculum_progress_fraction = (self.curriculum_level - c.min_level) / (c.max_level - c.min_level)
+
+    def close(self):
+        self.sim_env.delete_env()
+
+    def reset(self):
+        self.sim_env.reset()
+        self.reset_idx(torch.arange(self.sim_env.num_envs, device=self.device))
+        self.sim_env.render(render_components="sensors")
+        return self.get_return_tuple()
+
+    def reset_idx(self, env_ids):
+        """Target resample (navigation_task.py:166-175): rand_like for all N, then index."""
+        rs = self.obs_dict["random_source"]
+        ratio = (self.target_max_ratio - self.target_min_ratio) * rs.rand(self.num_envs, 3, tag="target") + self.target_min_ratio
+        bmin, bmax = self.obs_dict["env_bounds_min"], self.obs_dict["env_bounds_max"]
+        new = bmin + (bmax - bmin) * ratio
+        if isinstance(env_ids, torch.Tensor) and env_ids.dtype in (torch.bool, torch.uint8):
+            self.target_position[:] = torch.where(env_ids.bool().unsqueeze(1), new, self.target_position)
+        else:
+            self.target_position[env_ids] = new[env_ids]
+        self.infos = {}
+
+    def render(self):
+        return self.sim_env.render()
+
+    def check_and_update_curriculum_level(self, successes, crashes, timeouts):
+        self.success_aggregate += torch.sum(successes)
+        self.crashes_aggregate += torch.sum(crashes)
+        self.timeouts_aggregate += torch.sum(timeouts)
+        if self.num_task_steps % self.curriculum_check_every != 0:
+            return
+        instances = self.success_aggregate + self.crashes_aggregate + self.timeouts_aggregate
+        c = self.task_config.curriculum
+        if int(instances) >= c.check_after_log_instances:  # host sync, as in the reference (:237)
+            success_rate = float(self.success_aggregate / instances)
+            if success_rate > c.success_rate_for_increase:
+                self.curriculum_level += c.increase_step
+            elif success_rate < c.success_rate_for_decrease:
+                self.curriculum_level -= c.decrease_step
+            self.curriculum_level = min(max(self.curriculum_level, c.min_level), c.max_level)
+            self.obs_dict["curriculum_level"] = self.curriculum_level
+            self.obs_dict["num_obstacles_in_env"] = self.curriculum_level
+            self._update_progress()
+            logger.warning(f"Curriculum Level: {self.curriculum_level}, success rate {success_rate:.3f}")
+            self.success_aggregate = self.crashes_aggregate = self.timeouts_aggregate = 0
+
+    def step(self, actions):
+        env = self.sim_env
+        transformed_action = self.action_transformation_function(actions)
+        env.step(actions=transformed_action)
+        self.compute_rewards_and_crashes(self.obs_dict)
+        if self.task_config.return_state_before_reset:
+            return_tuple = self.get_return_tuple()
+        # successes / timeouts (navigation_task.py:311-326)
+        near = torch.norm(self.target_position - self.obs_dict["robot_position"], dim=1) < 1.0
+        crashed = self.terminations
+        successes = self.truncations & near & ~crashed
+        timeouts = self.truncations & ~successes & ~crashed
+        self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = successes, timeouts, crashed
+        self.check_and_update_curriculum_level(successes, crashed, timeouts)
+        reset_envs = env.post_reward_calculation_step()
+        if env.strict_rng:
+            if len(reset_envs) > 0:
+                self.reset_idx(reset_envs.indices)
+        else:
+            self.reset_idx(reset_envs.mask)
+        self.num_task_steps += 1
+        self.process_image_observation()
+        self.post_image_reward_addition()
+        if not self.task_config.return_state_before_reset:
+            return_tuple = self.get_return_tuple()
+        return return_tuple
+
+    def process_image_observation(self):
+        pass  # the min-pooled latents are written by agx_obs_navigation
+
+    def post_image_reward_addition(self):
+        """navigation_task.py:351-357.  `rewards[terminations < 0] += ...` never selects anything
+        for a bool tensor, so only min_pixel_dist is produced (reference quirk, kept)."""
+        env, px = self.sim_env, self.obs_dict.get("depth_range_pixels")
+        if px is None or px.dim() != 4:
+            return
+        ppe = px.shape[1] * px.shape[2] * px.shape[3]
+        _lib.check(env._lib.agx_image_min(env.num_envs, ppe, _lib.dptr(px), _lib.dptr(self.min_pixel_dist), env._stream()),
+                   "agx_image_min")
+
+    def compute_rewards_and_crashes(self, obs_dict):
+        env = self.sim_env
+        env._require_device()
+        _lib.check(
+            env._lib.agx_reward_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), self._rp,
+                                           float(self.curriculum_progress_fraction), _lib.dptr(self.pos_err_soa),
+                                           _lib.dptr(self.prev_pos_err_soa), int(self.task_config.episode_len_steps),
+                                           int(env.cfg.env.reset_on_collision), _lib.dptr(self.rewards), env._stream()),
+            "agx_reward_navigation",
+        )
+        return self.rewards, self.terminations
+
+    def get_return_tuple(self):
+        self.process_obs_for_task()
+        return (self.task_obs, self.rewards, self.terminations, self.truncations, self.infos)
+
+    def process_obs_for_task(self):
+        env = self.sim_env
+        env._require_device()
+        rs = self.obs_dict["random_source"]
+        rs.rand_into(self._u_vec, tag="obs_vec")
+        rs.rand_into(self._u_euler, tag="obs_euler")
+        px = self.obs_dict.get("depth_range_pixels")
+        use_px = px is not None and px.dim() == 4 and self.task_config.observation_space_dim > 17
+        S, H, W = (px.shape[1], px.shape[2], px.shape[3]) if use_px else (0, 0, 0)
+        _lib.check(
+            env._lib.agx_obs_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), _lib.dptr(self._u_vec),
+                                        _lib.dptr(self._u_euler), _lib.dptr(px) if use_px else None, S, H, W, 8, 8,
+                                        int(self.task_config.observation_space_dim),
+                                        _lib.dptr(self.task_obs["observations"]), env._stream()),
+            "agx_obs_navigation",
+        )

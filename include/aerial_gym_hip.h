@@ -164,6 +164,17 @@ int agx_reward_navigation(const AgxEnvBuffers *buf, int num_envs, const float *t
                           float *prev_pos_err, int episode_len, int reset_on_collision,
                           float *reward, void *stream);
 
+/* process_obs_for_task of the navigation task (navigation_task.py:369-393): obs [N][obs_dim]
+ * row-major = unit vector to target (+0.2 U01 noise) | distance | roll, pitch (+-0.05 noise) | 0 |
+ * body lin/ang velocity | robot_actions(4) | latents.  u_vec, u_euler: [N][3] U01 draws.
+ * The reference fills the latents with a VAE encoding of the depth image (a conv net outside
+ * the simulation hot path); here latents = grid_h x grid_w min-pooled depth image
+ * (pixels [N][S][H][W], sensor 0), or left untouched when pixels == NULL.                  */
+int agx_obs_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
+                       const float *u_vec, const float *u_euler, const float *pixels,
+                       int num_sensors, int height, int width, int grid_h, int grid_w,
+                       int obs_dim, float *obs, void *stream);
+
 /* ---- reset ----------------------------------------------------------------------
  * Masked reset, in the order of EnvManager.reset_idx (env_manager.py:273-301):
  *   env bounds (IsaacGymEnv.reset_idx, IGE_env_manager.py:513-519), robot state
