@@ -10,7 +10,7 @@ import os
 AERIAL_GYM_DIRECTORY = os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
 
 from . import control, env_manager, robots, task  # noqa: E402,F401  (populate the registries)
-from .registry import (  # noqa: E402,F401
+from .registry.registries import (  # noqa: E402,F401
     controller_registry,
     env_config_registry,
     robot_registry,

@@ -6,7 +6,7 @@
 // that fp32 results track the reference to rounding; the library is compiled with
 // -ffp-contract=off, so every + - * / sqrt is one correctly rounded IEEE operation
 // (this is what makes crash flags, segmentation ids and depth bit-reproducible on
-// the CPU oracle).
+// the CPU reference used by the parity tests).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

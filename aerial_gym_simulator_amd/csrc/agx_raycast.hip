@@ -17,7 +17,7 @@
 //   * exactness: ray/triangle uses Warp's watertight Woop test incl. its fmaf-compensated
 //     edge functions and fp64 fallback; closest hit keeps the smallest (t, face) pair, so
 //     the result is independent of traversal order and bit-identical to a brute-force
-//     loop over all triangles (oracle/oracle_raycast.c).
+//     loop over all triangles (DESIGN.md "closest-hit semantics").
 //
 // No MFMA: traversal is branchy gather work; the bound is LDS latency / VALU, with HBM
 // traffic = scene + image bytes (DESIGN.md "ray-cast roofline").

@@ -7,7 +7,7 @@
 // tree is rebuilt from the new positions (Morton order), which keeps traversal tight.
 //
 // The BVH is a pure accelerator: the ray-cast result is defined over all triangles with
-// a (t, face-index) tie-break (see oracle/oracle_raycast.c), so any topology is valid as
+// a (t, face-index) tie-break (DESIGN.md "closest-hit semantics"), so any topology is valid as
 // long as node boxes are conservative -- they are grown by kBoxEps like Warp's 1e-3.
 #include "agx_common.h"
 #include "agx_device_math.h"

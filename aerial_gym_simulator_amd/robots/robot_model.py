@@ -64,7 +64,7 @@ def _fill(dst, values):
 
 
 def robot_params_dict(robot_cfg, controller_cfg, controller_kind, sim_cfg):
-    """Plain-number description of the robot (also what the tests hand to the oracle)."""
+    """Plain-number description of the robot (the parity tests consume the same dict)."""
     ca = robot_cfg.control_allocator_config
     mm = ca.motor_model_config
     model = robot_cfg.robot_model

@@ -1,0 +1,192 @@
+"""CPU: C-ABI surface, host logic, API contract (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from conftest import ROOT, load_golden
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from aerial_gym_simulator_amd import _build, _lib
+
+    path = _build.build_library()
+    assert os.path.exists(path)
+    header = open(os.path.join(ROOT, "include", "aerial_gym_hip.h")).read()
+    declared = set(re.findall(r"\b(agx_[a-z_0-9]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(path)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/aerial_gym_hip.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    L = _lib.load()
+    assert L.agx_abi_version() == 1
+    # links only against the HIP runtime / libc: no torch, no python in the C ABI library
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    libs = re.findall(r"Shared library: \[(.*?)\]", needed)
+    assert any("amdhip64" in x for x in libs)
+    assert not any(("torch" in x) or ("python" in x) or ("c10" in x) for x in libs), libs
+
+
+def test_struct_layouts_match_header():
+    """sizeof of the ctypes mirrors == sizeof in C (compiled with gcc from the header)."""
+    from aerial_gym_simulator_amd import _lib
+
+    src = '#include <stdio.h>\n#include "aerial_gym_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(AgxRobotParams), sizeof(AgxEnvBuffers), sizeof(AgxResetArgs));return 0;}'
+    exe = "/tmp/agx_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
+    sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(_lib.AgxRobotParams), ctypes.sizeof(_lib.AgxEnvBuffers), ctypes.sizeof(_lib.AgxResetArgs)]
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "aerial_gym_simulator_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    assert "oracle" not in open(os.path.join(ROOT, "include", "aerial_gym_hip.h")).read().lower()
+
+
+def test_registries_and_names():
+    import aerial_gym_simulator_amd as ag
+
+    for name in ("lee_position_control", "lee_velocity_control", "lee_attitude_control", "lee_rates_control",
+                 "lee_acceleration_control", "no_control", "octarotor_velocity_control", "rov_fully_actuated_control"):
+        assert name in ag.controller_registry.get_controller_names()
+    for name in ("base_quadrotor", "base_octarotor", "base_quadrotor_with_camera"):
+        assert name in ag.robot_registry.get_robot_names()
+    assert set(ag.task_registry.get_task_names()) >= {"position_setpoint_task", "navigation_task"}
+    assert ag.sim_config_registry.make_sim("base_sim").sim.dt == 0.01
+    with pytest.raises(ValueError):
+        ag.robot_registry.get_robot_class("nope")
+
+
+def _make_position_task(n=16):
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.task.position_setpoint_task import PositionSetpointTask
+
+    cfg.controller_name = "lee_position_control"
+    return PositionSetpointTask(cfg, num_envs=n, device="cpu", seed=3)
+
+
+def test_tensor_dict_contract_and_aliasing():
+    t = _make_position_task(16)
+    g = t.sim_env.get_obs()
+    for key, shape in (("robot_position", (16, 3)), ("robot_orientation", (16, 4)), ("robot_linvel", (16, 3)),
+                       ("robot_angvel", (16, 3)), ("robot_body_linvel", (16, 3)), ("robot_body_angvel", (16, 3)),
+                       ("robot_vehicle_orientation", (16, 4)), ("robot_vehicle_linvel", (16, 3)),
+                       ("robot_euler_angles", (16, 3)), ("robot_actions", (16, 4)), ("robot_prev_actions", (16, 4)),
+                       ("crashes", (16,)), ("truncations", (16,)), ("env_bounds_min", (16, 3)), ("env_bounds_max", (16, 3)),
+                       ("gravity", (16, 3)), ("robot_mass", (16,)), ("robot_inertia", (16, 3, 3)), ("robot_state_tensor", (16, 13))):
+        assert tuple(g[key].shape) == shape, key
+    assert g["crashes"].dtype == torch.bool and t.sim_env.sim_steps.dtype == torch.int32
+    # reference-shaped views alias the SoA storage (callers mutate in place)
+    g["robot_position"][5, 2] = 7.5
+    assert g["robot_state_soa"][2, 5] == 7.5 and g["robot_state_tensor"][5, 2] == 7.5
+    g["robot_state_tensor"][3, 10:13] = torch.tensor([1.0, 2.0, 3.0])
+    assert torch.equal(g["robot_angvel"][3], torch.tensor([1.0, 2.0, 3.0]))
+    assert t.terminations is g["crashes"] and t.truncations is g["truncations"]
+    assert abs(float(g["robot_mass"][0]) - 0.25) < 1e-7
+    assert t.task_obs["observations"].shape == (16, 13) and t.task_obs["observations"].is_contiguous()
+    assert t.action_space.shape == (4,) and t.observation_space["observations"].shape == (13,)
+
+
+def test_robot_model_matches_urdf_derived_constants():
+    from aerial_gym_simulator_amd.config.robot_config import BaseOctarotorCfg, BaseQuadCfg
+    from aerial_gym_simulator_amd.robots.robot_model import composite_body, motor_wrench_map
+
+    for name, cfg in (("quad", BaseQuadCfg), ("octarotor", BaseOctarotorCfg)):
+        g = load_golden("robot_" + name)  # computed from the reference's URDF files
+        m, com, J = composite_body(cfg.robot_model)
+        assert abs(m - float(g["mass"])) < 1e-12 and np.abs(com - g["com"]).max() < 1e-12
+        assert np.abs(J - g["inertia"]).max() < 1e-12
+        ca = cfg.control_allocator_config
+        W = motor_wrench_map(cfg.robot_model, ca.motor_directions, ca.motor_model_config.thrust_to_torque_ratio, com)
+        assert np.abs(W - g["wrench_map"]).max() < 1e-12
+        assert abs(cfg.robot_model.collision_sphere_radius - float(g["collision_radius"])) < 1e-15
+
+
+def test_stepping_without_hip_device_fails_loudly():
+    t = _make_position_task(8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        t.step(torch.zeros(8, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        t.reset()
+    from aerial_gym_simulator_amd import _lib
+
+    with pytest.raises(RuntimeError, match="HIP device"):
+        _lib.dptr(torch.zeros(4))
+
+
+def test_scene_manager_semantics():
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    env = SimBuilder().build_env("base_sim", "env_with_random_boxes", "base_quadrotor_with_camera_64x48", "lee_velocity_control",
+                                 "cpu", num_envs=6)
+    sc = env.scene
+    assert (sc.num_assets, sc.num_tris, sc.keep_in_env_num) == (106, 1272, 6)
+    sem = sc.asset_semantic_id.numpy()
+    assert set(sem[0, :6]) == {9, 10, 11, 12, 13, 14}            # walls keep their fixed ids
+    assert sem[0, 6] == 106 and sem[1, 6] == 100 + 106 + 6        # global counter from 100 (env_manager.py:147)
+    assert sc.tri_local.shape == (6, 1272, 9) and sc.tri_seg.shape == (6, 1272)
+    he = sc.half_extents.numpy()
+    assert he[:, 6:].min() >= 0.05 - 1e-6 and he[:, 6:].max() <= 0.6 + 1e-6
+    g = env.get_obs()
+    assert g["depth_range_pixels"].shape == (6, 1, 48, 64) and g["segmentation_pixels"].dtype == torch.int32
+    env2 = SimBuilder().build_env("base_sim", "env_with_obstacles", "base_quadrotor_with_camera", "lee_velocity_control", "cpu", num_envs=3)
+    assert (env2.scene.num_assets, env2.scene.keep_in_env_num) == (44, 9)  # 3 panels + 35 objects + 6 walls
+
+
+def test_navigation_action_transform_matches_reference():
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config as cfg
+
+    g = load_golden("reward_navigation")
+    out = cfg.action_transformation_function(torch.from_numpy(g["action_transform_in"]))
+    assert np.abs(out.numpy() - g["action_transform_out"]).max() < 1e-6
+
+
+def _gather_worker(rank, world, port, ret):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from aerial_gym_simulator_amd.sharding import StepGather, shard_range
+
+    total, obs_dim = 10, 13
+    lo, hi = shard_range(total, rank, world)
+    full_obs = torch.arange(total * obs_dim, dtype=torch.float32).view(total, obs_dim)
+    sg = StepGather(hi - lo, obs_dim, "cpu")
+    sg.pack(full_obs[lo:hi], torch.arange(lo, hi).float(), torch.arange(lo, hi) % 2 == 0, torch.arange(lo, hi) % 3 == 0)
+    sg.gather()
+    obs, rew, term, trunc = sg.unpack()
+    ok = torch.equal(obs, full_obs) and torch.equal(rew, torch.arange(total).float())
+    ok = ok and torch.equal(term, torch.arange(total) % 2 == 0) and torch.equal(trunc, torch.arange(total) % 3 == 0)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_sharded_gather_world2_gloo():
+    """N > 1 path on CPU: 2 processes, gloo, one all-gather of the packed step outputs ==
+    concatenation of the shards."""
+    import torch.multiprocessing as mp
+
+    from aerial_gym_simulator_amd.sharding import semantic_id_offset, shard_range
+
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert semantic_id_offset(2, 8192, 106) == 2 * 8192 * 106
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert dict(ret) == {0: True, 1: True}
