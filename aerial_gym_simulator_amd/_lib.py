@@ -78,6 +78,8 @@ class AgxEnvBuffers(C.Structure):
         ("sim_steps", C.c_void_p),
         ("reset_mask", C.c_void_p),
         ("reset_flag", C.c_void_p),
+        ("flag_parity", C.c_int32),
+        ("episode_count", C.c_void_p),
         ("bounds_min", C.c_void_p),
         ("bounds_max", C.c_void_p),
         ("disturb", C.c_void_p),
@@ -85,6 +87,23 @@ class AgxEnvBuffers(C.Structure):
         ("boxes", C.c_void_p),
         ("num_boxes", C.c_int32),
     ]
+
+
+class AgxTaskArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("episode_len", C.c_int32),
+        ("reset_on_collision", C.c_int32),
+        ("curriculum_progress", C.c_float),
+        ("target", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("pos_err", C.c_void_p),
+        ("prev_pos_err", C.c_void_p),
+        ("rp", C.c_float * 18),
+    ]
+
+
+TASK_NONE, TASK_POSITION, TASK_NAVIGATION = 0, 1, 2
 
 
 class AgxResetArgs(C.Structure):
@@ -111,6 +130,8 @@ class AgxResetArgs(C.Structure):
         ("tau_dec_max", C.c_float),
         ("kT_min", C.c_float),
         ("kT_max", C.c_float),
+        ("randomize_gains", C.c_int32),
+        ("seed", C.c_uint64),
     ]
 
 
@@ -119,6 +140,7 @@ _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
     "agx_abi_version": (C.c_int, []),
     "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
+    "agx_env_step": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.POINTER(AgxTaskArgs), _P]),
     "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),
     "agx_controller_wrench": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, _P]),
     "agx_reward_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
@@ -130,6 +152,9 @@ _SIGNATURES = {
     "agx_obs_navigation": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, _P, _P]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
+    "agx_post_step_position": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P]),
+    "agx_reset_assets": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P, _P, _P, C.c_int,
+                                   C.c_int, _P, _P]),
     "agx_scene_transform": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_bvh_nodes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
@@ -180,7 +205,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.agx_abi_version() != 1:
+    if lib.agx_abi_version() != 2:
         raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
     _lib = lib
     return lib

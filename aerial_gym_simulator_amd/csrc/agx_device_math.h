@@ -108,15 +108,33 @@ AGX_DEV M33 quat_to_rotmat(Q4 q) {
   m.m22 = 1.0f - 2.0f * (xx + yy);
   return m;
 }
+// sin and cos of the same angle.  Every angle on this path is bounded (|x| < 64: Euler angles,
+// half angles, yaw set-points clipped to +-10), so a 3-term Cody-Waite reduction by pi/2 is
+// exact enough and the Payne-Hanek slow path of the generic sinf/cosf (hundreds of
+// instructions and ~100 VGPRs of dead weight per call site) is not needed.  Polynomials are
+// the single-precision minimax kernels of cephes sinf/cosf on [-pi/4, pi/4]; max error
+// ~1.2e-7, well inside the 1e-5 state tolerance (DESIGN.md "numerics").
+AGX_DEV void sincos_bounded(float x, float &sn, float &cs) {
+  const float kTwoOverPi = 0.636619772367581343f;
+  float kf = rintf(x * kTwoOverPi);
+  int k = (int)kf;
+  // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8 (cephes DP1..3 x 2)
+  float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+  float z = r * r;
+  float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+  float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  float s0 = (k & 1) ? pc : ps;
+  float c0 = (k & 1) ? ps : pc;
+  sn = (k & 2) ? -s0 : s0;
+  cs = ((k + 1) & 2) ? -c0 : c0;
+}
+
 // utils/math.py:156-172
 AGX_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
   float sy, cy, sr, cr, sp, cp;
-  sy = sinf(yaw * 0.5f);
-  cy = cosf(yaw * 0.5f);
-  sr = sinf(roll * 0.5f);
-  cr = cosf(roll * 0.5f);
-  sp = sinf(pitch * 0.5f);
-  cp = cosf(pitch * 0.5f);
+  sincos_bounded(yaw * 0.5f, sy, cy);
+  sincos_bounded(roll * 0.5f, sr, cr);
+  sincos_bounded(pitch * 0.5f, sp, cp);
   Q4 q;
   q.w = cy * cr * cp + sy * sr * sp;
   q.x = cy * sr * cp - sy * cr * sp;

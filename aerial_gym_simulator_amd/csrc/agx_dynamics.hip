@@ -111,7 +111,9 @@ AGX_DEV V3 compute_body_torque(const AgxRobotParams &P, Q4 q, V3 wb, Q4 qd, V3 &
 // base_lee_controller.py:173-194
 AGX_DEV Q4 desired_orientation_pos_vel(V3 f, float yaw) {
   V3 b3 = f / norm(f);
-  V3 tmp = V3{cosf(yaw), sinf(yaw), 0.0f};
+  float sy, cy;
+  sincos_bounded(yaw, sy, cy);
+  V3 tmp = V3{cy, sy, 0.0f};
   V3 b2 = cross(b3, tmp);
   b2 = b2 / norm(b2);
   V3 b1 = cross(b2, b3);
@@ -128,21 +130,23 @@ AGX_DEV Q4 desired_orientation_forces_yaw(V3 f, float yaw) {
 
 // base_lee_controller.py:201-215 (stale matrix entries only ever multiply zero rates)
 AGX_DEV V3 euler_rates_to_body_rates(V3 euler, V3 r) {
-  float sp = sinf(euler.y), cp = cosf(euler.y);
-  float sr = sinf(euler.x), cr = cosf(euler.x);
+  float sp, cp, sr, cr;
+  sincos_bounded(euler.y, sp, cp);
+  sincos_bounded(euler.x, sr, cr);
   return V3{1.0f * r.x + 0.0f * r.y + (-sp) * r.z, 0.0f * r.x + cr * r.y + (sr * cp) * r.z,
             0.0f * r.x + (-sr) * r.y + (cr * cp) * r.z};
 }
 
 // One env's controller (control/controllers/*.py).  a[] holds the +-10 clipped action and
 // is mutated where the reference mutates it.
+template <int CTRL>
 AGX_DEV Wrench run_controller(const AgxRobotParams &P, const EnvState &s, const Derived &d, float (&a)[AGX_MAX_ACTIONS],
                               const Gains &g) {
   Wrench w{V3{0, 0, 0}, V3{0, 0, 0}};
   const V3 grav = V3{P.gravity[0], P.gravity[1], P.gravity[2]};
   const float m = P.mass;
   const V3 zero = V3{0, 0, 0};
-  switch (P.controller) {
+  switch (CTRL) {
     case AGX_CTRL_POSITION: {  // position_control.py:20-51
       V3 acc = compute_acceleration(s, d.qveh, V3{a[0], a[1], a[2]}, zero, g);
       V3 f = (acc - grav) * m;
@@ -263,7 +267,8 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
   if (wm2 != 0.0f) {
     float wm = sqrtf(wm2);
     float half = dt * wm * 0.5f;
-    float sn = sinf(half), cs = cosf(half);
+    float sn, cs;
+    sincos_bounded(half, sn, cs);  // |half| = dt |w| / 2 <= 0.5 (|w| <= 100 rad/s)
     float sc = sn / wm;
     float x1 = w_new.x * sc, y1 = w_new.y * sc, z1 = w_new.z * sc;
     Q4 q = s.q;
@@ -280,123 +285,224 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
 }
 
 // sphere (robot collision sphere, quad.urdf:16) vs obstacle OBBs; replaces the PhysX
-// contact-force test of env_manager.py:358-362
-AGX_DEV bool collide_boxes(const float *__restrict__ boxes, int nb, int n, int i, V3 p, float r) {
+// contact-force test of env_manager.py:358-362.  The predicate uses only IEEE + - *
+// (bit-reproducible); the culling in front of it is conservative, so the flag is exact.
+AGX_DEV bool sphere_hits_box(V3 p, V3 c, Q4 q, V3 h, float r2) {
+  V3 l = quat_rotate_inverse(q, p - c);
+  float ex = fabsf(l.x) - h.x, ey = fabsf(l.y) - h.y, ez = fabsf(l.z) - h.z;
+  float d2 = 0.0f;
+  if (ex > 0.0f) d2 += ex * ex;
+  if (ey > 0.0f) d2 += ey * ey;
+  if (ez > 0.0f) d2 += ez * ez;
+  return d2 < r2;
+}
+
+// One pass over the env's K boxes for ALL k sub-step positions (kept in LDS,
+// traj[(s*3+c)*bd + tid]): each box is fetched once per env step instead of once per sub-step,
+// and boxes whose bounding sphere cannot reach the AABB of the k positions cost 4 loads.
+AGX_DEV bool collide_trajectory(const float *__restrict__ boxes, int nb, int n, int i, const float *traj, int k, int bd,
+                                int tid, V3 lo, V3 hi, float r) {
   bool hit = false;
   const float r2 = r * r;
   for (int b = 0; b < nb; ++b) {
-    const float *bx = boxes + (size_t)b * 10 * n + i;
-    V3 c = V3{bx[0 * (size_t)n], bx[1 * (size_t)n], bx[2 * (size_t)n]};
+    const float *bx = boxes + (size_t)b * 11 * n + i;
+    V3 c = V3{bx[0], bx[(size_t)n], bx[2 * (size_t)n]};
+    float reach = bx[10 * (size_t)n] + r + 1.0e-3f;
+    float dx = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.0f);
+    float dy = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.0f);
+    float dz = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.0f);
+    if (dx * dx + dy * dy + dz * dz > reach * reach) continue;
     Q4 q = Q4{bx[3 * (size_t)n], bx[4 * (size_t)n], bx[5 * (size_t)n], bx[6 * (size_t)n]};
     V3 h = V3{bx[7 * (size_t)n], bx[8 * (size_t)n], bx[9 * (size_t)n]};
-    V3 l = quat_rotate_inverse(q, p - c);
-    float ex = fabsf(l.x) - h.x, ey = fabsf(l.y) - h.y, ez = fabsf(l.z) - h.z;
-    float d2 = 0.0f;
-    if (ex > 0.0f) d2 += ex * ex;
-    if (ey > 0.0f) d2 += ey * ey;
-    if (ez > 0.0f) d2 += ez * ez;
-    hit = hit || (d2 < r2);
+    for (int s = 0; s < k; ++s) {
+      V3 p = V3{traj[(s * 3 + 0) * bd + tid], traj[(s * 3 + 1) * bd + tid], traj[(s * 3 + 2) * bd + tid]};
+      hit = hit || sphere_hits_box(p, c, q, h, r2);
+    }
   }
   return hit;
 }
 
-template <int M>
-__global__ void __launch_bounds__(256) k_dynamics_substeps(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int A = P.num_actions;
-  EnvState s = load_state(B.state, n, i);
-  float u[M], kT[M], tinc[M], tdec[M];
+AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * expf(-(v * v) * ex); }
+AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (expf(-(v * v) * ex) - 1.0f); }
+
+// position_setpoint_task.py:245-282 on registers; returns the reward, ORs the distance crash
+AGX_DEV float reward_position(const EnvState &s, Q4 qveh, V3 wb, V3 tgt, bool &crash) {
+  V3 pe = quat_apply(conj(qveh), tgt - s.p);  // quat_apply_inverse
+  float dist = norm(pe);
+  float pos_reward = 3.0f * expf(-8.0f * dist * dist) + 2.0f * expf(-4.0f * dist * dist);
+  float dist_reward = (20.0f - dist) / 40.0f;
+  V3 up = quat_rotate(s.q, V3{0.0f, 0.0f, 1.0f});  // quat_axis(q, 2)
+  float tilt = fabsf(1.0f - up.z);
+  float up_reward = 0.2f / (0.1f + tilt * tilt);
+  float spin = norm(wb);
+  float ang_reward = (1.0f / (1.0f + spin * spin)) * 3.0f;
+  float total = pos_reward + dist_reward + pos_reward * (up_reward + ang_reward);
+  total = 1.0f * total;
+  if (dist > 8.0f) crash = true;
+  if (crash) total = -20.0f;
+  return total;
+}
+
+// navigation_task.py:416-521 on registers
+AGX_DEV float reward_navigation(const float *rp, float cpf, V3 pe, V3 ppe, float a0, float a2, float a3, float p0, float p2,
+                                float p3, bool crash) {
+  float mult = 1.0f + 2.0f * cpf;
+  float dist = norm(pe), prev_dist = norm(ppe);
+  float pos_reward = exp_reward(rp[0], rp[1], dist);
+  float close_reward = exp_reward(rp[2], rp[3], dist);
+  float closer = prev_dist - dist;
+  float closer_reward = (closer > 0.0f) ? rp[4] * closer : 2.0f * rp[4] * closer;
+  float dist_reward = (20.0f - dist) / 20.0f;
+  float dx = a0 - p0, dz = a2 - p2, dyaw = a3 - p3;
+  float diff_pen = exp_penalty(rp[5], rp[6], dx) + exp_penalty(rp[7], rp[8], dz) + exp_penalty(rp[9], rp[10], dyaw);
+  float abs_pen = cpf * exp_penalty(rp[11], rp[12], a0) + cpf * exp_penalty(rp[13], rp[14], a2) +
+                  cpf * exp_penalty(rp[15], rp[16], a3);
+  float total_pen = diff_pen + abs_pen;
+  float r = mult * (pos_reward + close_reward + closer_reward + dist_reward) + total_pen;
+  if (crash) r = rp[17];
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// The env step: k fused physics sub-steps + (optionally) the task's reward / crash /
+// truncation / reset set as an epilogue on the same registers.
+// ---------------------------------------------------------------------------------------
+template <int M, int CTRL>
+__global__ void __launch_bounds__(256) k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in,
+                                                  int k, AgxTaskArgs T) {
+  extern __shared__ float traj[];  // [k][3][blockDim] sub-step positions (only with obstacles)
+  const int tid = threadIdx.x, bd = blockDim.x;
+  const int i = blockIdx.x * bd + tid;
+  bool reset = false;
+  if (i < n) {
+    const int A = P.num_actions;
+    EnvState s = load_state(B.state, n, i);
+    float u[M], kT[M], tinc[M], tdec[M];
 #pragma unroll
-  for (int j = 0; j < M; ++j) {
-    u[j] = B.motor_thrust[j * n + i];
-    kT[j] = P.use_rps ? B.motor_kT[j * n + i] : 1.0f;
-    tinc[j] = B.motor_tau_inc[j * n + i];
-    tdec[j] = B.motor_tau_dec[j * n + i];
-  }
-  Gains g{};
-  if (P.controller != AGX_CTRL_NONE) g = load_gains(B.gains, n, i);
-  float a_in[AGX_MAX_ACTIONS], a_old[AGX_MAX_ACTIONS];
+    for (int j = 0; j < M; ++j) {
+      u[j] = B.motor_thrust[j * n + i];
+      kT[j] = P.use_rps ? B.motor_kT[j * n + i] : 1.0f;
+      tinc[j] = B.motor_tau_inc[j * n + i];
+      tdec[j] = B.motor_tau_dec[j * n + i];
+    }
+    Gains g{};
+    if (CTRL != AGX_CTRL_NONE) g = load_gains(B.gains, n, i);
+    float a_in[AGX_MAX_ACTIONS], a_old[AGX_MAX_ACTIONS];
 #pragma unroll
-  for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
-    a_in[c] = (c < A) ? actions_in[(size_t)i * A + c] : 0.0f;
-    a_old[c] = (c < A) ? B.actions[c * n + i] : 0.0f;
-  }
-  // EnvManager.reset_tensors (env_manager.py:342-344)
-  bool crashed = false;
-  Derived d{};
-  Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
-  if (i == 0) *B.reset_flag = 0;
-  const bool root_link = P.root_link_mode != 0;
-  for (int sub = 0; sub < k; ++sub) {
-    d = update_states(s);
-    float a[AGX_MAX_ACTIONS];
+    for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
+      a_in[c] = (c < A) ? actions_in[(size_t)i * A + c] : 0.0f;
+      a_old[c] = (c < A) ? B.actions[c * n + i] : 0.0f;
+    }
+    Derived d{};
+    if (k == 0 && T.kind != AGX_TASK_NONE) d = load_derived(B.derived, n, i);
+    Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
+    const bool root_link = P.root_link_mode != 0;
+    V3 tlo = s.p, thi = s.p;
+    for (int sub = 0; sub < k; ++sub) {
+      d = update_states(s);
+      float a[AGX_MAX_ACTIONS];
 #pragma unroll
-    for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a[c] = clamp_minmax(a_in[c], -10.0f, 10.0f);  // clip_actions
-    if (P.controller == AGX_CTRL_NONE) {
+      for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a[c] = clamp_minmax(a_in[c], -10.0f, 10.0f);  // clip_actions
+      if (CTRL == AGX_CTRL_NONE) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) u[j] = motor_update(P, a[j], u[j], kT[j], tinc[j], tdec[j]);
-    } else {
-      wc = run_controller(P, s, d, a, g);
-      const float w6[6] = {wc.f.x, wc.f.y, wc.f.z, wc.t.x, wc.t.y, wc.t.z};
+        for (int j = 0; j < M; ++j) u[j] = motor_update(P, a[j], u[j], kT[j], tinc[j], tdec[j]);
+      } else {
+        wc = run_controller<CTRL>(P, s, d, a, g);
+        const float w6[6] = {wc.f.x, wc.f.y, wc.f.z, wc.t.x, wc.t.y, wc.t.z};
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        float r = 0.0f;
+        for (int j = 0; j < M; ++j) {
+          float r = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) r += P.alloc_pinv[6 * j + c] * w6[c];
-        u[j] = motor_update(P, r, u[j], kT[j], tinc[j], tdec[j]);
+          for (int c = 0; c < 6; ++c) r += P.alloc_pinv[6 * j + c] * w6[c];
+          u[j] = motor_update(P, r, u[j], kT[j], tinc[j], tdec[j]);
+        }
+      }
+      float bw[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc += (root_link ? P.alloc[M * r + j] : P.wrench_map[M * r + j]) * u[j];
+        bw[r] = acc;
+      }
+      // simulate_drag (base_multirotor.py:260-285), pre-physics body velocities
+      {
+        float vbn = norm(d.vbody);
+        bw[0] += (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
+        bw[1] += (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
+        bw[2] += (-P.lin_drag_linear[2] * d.vbody.z) + (-P.lin_drag_quadratic[2] * vbn * d.vbody.z);
+        bw[3] += (-P.ang_drag_linear[0] * d.wbody.x) + (-P.ang_drag_quadratic[0] * fabsf(d.wbody.x) * d.wbody.x);
+        bw[4] += (-P.ang_drag_linear[1] * d.wbody.y) + (-P.ang_drag_quadratic[1] * fabsf(d.wbody.y) * d.wbody.y);
+        bw[5] += (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
+      }
+      if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234)
+        const float *dd = B.disturb + (size_t)sub * 7 * n + i;
+        float occ = dd[0];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          float lo = -B.disturb_max[c], hi = B.disturb_max[c];
+          bw[c] += ((hi - lo) * dd[(size_t)(1 + c) * n] + lo) * occ;
+        }
+      }
+      integrate(P, s, V3{bw[0], bw[1], bw[2]}, V3{bw[3], bw[4], bw[5]});
+      if (B.boxes) {
+        traj[(sub * 3 + 0) * bd + tid] = s.p.x;
+        traj[(sub * 3 + 1) * bd + tid] = s.p.y;
+        traj[(sub * 3 + 2) * bd + tid] = s.p.z;
+        if (sub == 0) { tlo = s.p; thi = s.p; }
+        tlo = V3{fminf(tlo.x, s.p.x), fminf(tlo.y, s.p.y), fminf(tlo.z, s.p.z)};
+        thi = V3{fmaxf(thi.x, s.p.x), fmaxf(thi.y, s.p.y), fmaxf(thi.z, s.p.z)};
       }
     }
-    float bw[6];
+    // EnvManager.reset_tensors + compute_observations (env_manager.py:342-344, 358-362)
+    bool crashed = false;
+    if (B.boxes && k > 0) crashed = collide_trajectory(B.boxes, B.num_boxes, n, i, traj, k, bd, tid, tlo, thi, P.collision_radius);
+    store_state(B.state, n, i, s);
+    if (k > 0) {
+      store_derived(B.derived, n, i, d);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      float acc = 0.0f;
-#pragma unroll
-      for (int j = 0; j < M; ++j) acc += (root_link ? P.alloc[M * r + j] : P.wrench_map[M * r + j]) * u[j];
-      bw[r] = acc;
-    }
-    // simulate_drag (base_multirotor.py:260-285), pre-physics body velocities
-    {
-      float vbn = norm(d.vbody);
-      bw[0] += (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
-      bw[1] += (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
-      bw[2] += (-P.lin_drag_linear[2] * d.vbody.z) + (-P.lin_drag_quadratic[2] * vbn * d.vbody.z);
-      bw[3] += (-P.ang_drag_linear[0] * d.wbody.x) + (-P.ang_drag_quadratic[0] * fabsf(d.wbody.x) * d.wbody.x);
-      bw[4] += (-P.ang_drag_linear[1] * d.wbody.y) + (-P.ang_drag_quadratic[1] * fabsf(d.wbody.y) * d.wbody.y);
-      bw[5] += (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
-    }
-    if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234)
-      const float *dd = B.disturb + (size_t)sub * 7 * n + i;
-      float occ = dd[0];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        float lo = -B.disturb_max[c], hi = B.disturb_max[c];
-        bw[c] += ((hi - lo) * dd[(size_t)(1 + c) * n] + lo) * occ;
+      for (int j = 0; j < M; ++j) B.motor_thrust[j * n + i] = u[j];
+      if (B.wrench_cmd) {
+        B.wrench_cmd[0 * n + i] = wc.f.x; B.wrench_cmd[1 * n + i] = wc.f.y; B.wrench_cmd[2 * n + i] = wc.f.z;
+        B.wrench_cmd[3 * n + i] = wc.t.x; B.wrench_cmd[4 * n + i] = wc.t.y; B.wrench_cmd[5 * n + i] = wc.t.z;
       }
     }
-    integrate(P, s, V3{bw[0], bw[1], bw[2]}, V3{bw[3], bw[4], bw[5]});
-    if (B.boxes) crashed = crashed || collide_boxes(B.boxes, B.num_boxes, n, i, s.p, P.collision_radius);
-  }
-  store_state(B.state, n, i, s);
-  if (k > 0) {
-    store_derived(B.derived, n, i, d);
-#pragma unroll
-    for (int j = 0; j < M; ++j) B.motor_thrust[j * n + i] = u[j];
     // RobotManagerIGE.pre_physics_step runs every sub-step: prev <- cur, cur <- action
+    float a_cur[AGX_MAX_ACTIONS], a_prev[AGX_MAX_ACTIONS];
 #pragma unroll
-    for (int c = 0; c < AGX_MAX_ACTIONS; ++c)
-      if (c < A) {
-        B.prev_actions[c * n + i] = (k >= 2) ? a_in[c] : a_old[c];
-        B.actions[c * n + i] = a_in[c];
+    for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
+      a_cur[c] = (k > 0) ? a_in[c] : a_old[c];
+      a_prev[c] = (k >= 2) ? a_in[c] : ((k == 1) ? a_old[c] : ((c < A) ? B.prev_actions[c * n + i] : 0.0f));
+      if (c < A && k > 0) {
+        B.prev_actions[c * n + i] = a_prev[c];
+        B.actions[c * n + i] = a_cur[c];
       }
-    if (B.wrench_cmd) {
-      B.wrench_cmd[0 * n + i] = wc.f.x; B.wrench_cmd[1 * n + i] = wc.f.y; B.wrench_cmd[2 * n + i] = wc.f.z;
-      B.wrench_cmd[3 * n + i] = wc.t.x; B.wrench_cmd[4 * n + i] = wc.t.y; B.wrench_cmd[5 * n + i] = wc.t.z;
     }
+    const int steps = B.sim_steps[i] + 1;
+    B.sim_steps[i] = steps;
+    bool trunc = false;
+    if (T.kind != AGX_TASK_NONE) {
+      V3 tgt = V3{T.target[0 * n + i], T.target[1 * n + i], T.target[2 * n + i]};
+      float rew;
+      if (T.kind == AGX_TASK_POSITION) {
+        rew = reward_position(s, d.qveh, d.wbody, tgt, crashed);
+      } else {
+        V3 ppe = V3{T.pos_err[0 * n + i], T.pos_err[1 * n + i], T.pos_err[2 * n + i]};
+        T.prev_pos_err[0 * n + i] = ppe.x; T.prev_pos_err[1 * n + i] = ppe.y; T.prev_pos_err[2 * n + i] = ppe.z;
+        V3 pe = quat_rotate_inverse(d.qveh, tgt - s.p);
+        T.pos_err[0 * n + i] = pe.x; T.pos_err[1 * n + i] = pe.y; T.pos_err[2 * n + i] = pe.z;
+        rew = reward_navigation(T.rp, T.curriculum_progress, pe, ppe, a_cur[0], a_cur[2], a_cur[3], a_prev[0], a_prev[2],
+                                a_prev[3], crashed);
+      }
+      T.reward[i] = rew;
+      trunc = steps > T.episode_len;
+      reset = (crashed && T.reset_on_collision) || trunc;
+      B.reset_mask[i] = reset ? 1 : 0;
+    }
+    B.crashes[i] = crashed ? 1 : 0;
+    B.truncations[i] = trunc ? 1 : 0;
   }
-  B.crashes[i] = crashed ? 1 : 0;
-  B.truncations[i] = 0;
-  B.sim_steps[i] = B.sim_steps[i] + 1;
+  if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
 
 __global__ void __launch_bounds__(256) k_update_states(AgxEnvBuffers B, int n) {
@@ -416,18 +522,26 @@ __global__ void __launch_bounds__(256) k_controller_wrench(AgxRobotParams P, Agx
 #pragma unroll
   for (int c = 0; c < AGX_MAX_ACTIONS; ++c)
     a[c] = (c < P.num_actions) ? clamp_minmax(action[(size_t)i * P.num_actions + c], -10.0f, 10.0f) : 0.0f;
-  Wrench wc = run_controller(P, s, d, a, g);
+  Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
+  switch (P.controller) {
+    case AGX_CTRL_POSITION: wc = run_controller<AGX_CTRL_POSITION>(P, s, d, a, g); break;
+    case AGX_CTRL_VELOCITY: wc = run_controller<AGX_CTRL_VELOCITY>(P, s, d, a, g); break;
+    case AGX_CTRL_ATTITUDE: wc = run_controller<AGX_CTRL_ATTITUDE>(P, s, d, a, g); break;
+    case AGX_CTRL_RATES: wc = run_controller<AGX_CTRL_RATES>(P, s, d, a, g); break;
+    case AGX_CTRL_ACCELERATION: wc = run_controller<AGX_CTRL_ACCELERATION>(P, s, d, a, g); break;
+    case AGX_CTRL_VEL_STEERING: wc = run_controller<AGX_CTRL_VEL_STEERING>(P, s, d, a, g); break;
+    case AGX_CTRL_FULLY_ACTUATED: wc = run_controller<AGX_CTRL_FULLY_ACTUATED>(P, s, d, a, g); break;
+    default: break;
+  }
   B.wrench_cmd[0 * n + i] = wc.f.x; B.wrench_cmd[1 * n + i] = wc.f.y; B.wrench_cmd[2 * n + i] = wc.f.z;
   B.wrench_cmd[3 * n + i] = wc.t.x; B.wrench_cmd[4 * n + i] = wc.t.y; B.wrench_cmd[5 * n + i] = wc.t.z;
 }
 
 // ---------------------------------------------------------------------------------------
-// Tasks
+// Stand-alone task kernels (same device functions as the fused epilogue)
 // ---------------------------------------------------------------------------------------
-
-// position_setpoint_task.py:205-229, 245-282 + truncation (:172-174) + reset set (env_manager.py:364-371)
 __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n, const float *__restrict__ target, int episode_len,
-                                  int reset_on_collision, float *__restrict__ reward) {
+                                                          int reset_on_collision, float *__restrict__ reward) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool reset = false;
   if (i < n) {
@@ -435,59 +549,44 @@ __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n,
     Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
     V3 wb = V3{B.derived[13 * n + i], B.derived[14 * n + i], B.derived[15 * n + i]};
     V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
-    V3 pe = quat_apply(conj(qveh), tgt - s.p);  // quat_apply_inverse
-    float dist = norm(pe);
-    float pos_reward = 3.0f * expf(-8.0f * dist * dist) + 2.0f * expf(-4.0f * dist * dist);
-    float dist_reward = (20.0f - dist) / 40.0f;
-    V3 up = quat_rotate(s.q, V3{0.0f, 0.0f, 1.0f});  // quat_axis(q, 2)
-    float tilt = fabsf(1.0f - up.z);
-    float up_reward = 0.2f / (0.1f + tilt * tilt);
-    float spin = norm(wb);
-    float ang_reward = (1.0f / (1.0f + spin * spin)) * 3.0f;
-    float total = pos_reward + dist_reward + pos_reward * (up_reward + ang_reward);
-    total = 1.0f * total;
     bool crash = B.crashes[i] != 0;
-    if (dist > 8.0f) crash = true;
-    if (crash) total = -20.0f;
-    reward[i] = total;
+    reward[i] = reward_position(s, qveh, wb, tgt, crash);
     B.crashes[i] = crash ? 1 : 0;
     bool trunc = B.sim_steps[i] > episode_len;
     B.truncations[i] = trunc ? 1 : 0;
     reset = (crash && reset_on_collision) || trunc;
     B.reset_mask[i] = reset ? 1 : 0;
   }
-  if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag, 1);
+  if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
 
 // position_setpoint_task.py:194-203, obs [N][13] row-major (what the policy network consumes)
+AGX_DEV void write_obs_position(int n, int i, const float *__restrict__ target, float *__restrict__ obs, const EnvState &s,
+                                const Derived &d) {
+  float *o = obs + (size_t)i * 13;
+  o[0] = target[0 * n + i] - s.p.x; o[1] = target[1 * n + i] - s.p.y; o[2] = target[2 * n + i] - s.p.z;
+  o[3] = s.q.x; o[4] = s.q.y; o[5] = s.q.z; o[6] = s.q.w;
+  o[7] = d.vbody.x; o[8] = d.vbody.y; o[9] = d.vbody.z;
+  o[10] = d.wbody.x; o[11] = d.wbody.y; o[12] = d.wbody.z;
+}
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float *o = obs + (size_t)i * 13;
-  o[0] = target[0 * n + i] - B.state[0 * n + i];
-  o[1] = target[1 * n + i] - B.state[1 * n + i];
-  o[2] = target[2 * n + i] - B.state[2 * n + i];
-  o[3] = B.state[3 * n + i]; o[4] = B.state[4 * n + i]; o[5] = B.state[5 * n + i]; o[6] = B.state[6 * n + i];
-  o[7] = B.derived[10 * n + i]; o[8] = B.derived[11 * n + i]; o[9] = B.derived[12 * n + i];
-  o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
+  write_obs_position(n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
 }
-
-AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * expf(-(v * v) * ex); }
-AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (expf(-(v * v) * ex) - 1.0f); }
 
 struct NavParams {
   float rp[18];
 };
 
 // navigation_task.py:416-521 (+ :305-309 truncation)
-__global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int n, int A, const float *__restrict__ target, NavParams R,
-                                    float cpf, float *__restrict__ pos_err, float *__restrict__ prev_pos_err,
-                                    int episode_len, int reset_on_collision, float *__restrict__ reward) {
+__global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target, NavParams R,
+                                                            float cpf, float *__restrict__ pos_err,
+                                                            float *__restrict__ prev_pos_err, int episode_len,
+                                                            int reset_on_collision, float *__restrict__ reward) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool reset = false;
   if (i < n) {
-    const float *rp = R.rp;
-    float mult = 1.0f + 2.0f * cpf;
     V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
     Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
     V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
@@ -495,28 +594,15 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
     prev_pos_err[0 * n + i] = ppe.x; prev_pos_err[1 * n + i] = ppe.y; prev_pos_err[2 * n + i] = ppe.z;
     V3 pe = quat_rotate_inverse(qveh, tgt - p);
     pos_err[0 * n + i] = pe.x; pos_err[1 * n + i] = pe.y; pos_err[2 * n + i] = pe.z;
-    float dist = norm(pe), prev_dist = norm(ppe);
-    float pos_reward = exp_reward(rp[0], rp[1], dist);
-    float close_reward = exp_reward(rp[2], rp[3], dist);
-    float closer = prev_dist - dist;
-    float closer_reward = (closer > 0.0f) ? rp[4] * closer : 2.0f * rp[4] * closer;
-    float dist_reward = (20.0f - dist) / 20.0f;
-    float a0 = B.actions[0 * n + i], a2 = B.actions[2 * n + i], a3 = B.actions[3 * n + i];
-    float dx = a0 - B.prev_actions[0 * n + i], dz = a2 - B.prev_actions[2 * n + i], dyaw = a3 - B.prev_actions[3 * n + i];
-    float diff_pen = exp_penalty(rp[5], rp[6], dx) + exp_penalty(rp[7], rp[8], dz) + exp_penalty(rp[9], rp[10], dyaw);
-    float abs_pen = cpf * exp_penalty(rp[11], rp[12], a0) + cpf * exp_penalty(rp[13], rp[14], a2) +
-                    cpf * exp_penalty(rp[15], rp[16], a3);
-    float total_pen = diff_pen + abs_pen;
-    float r = mult * (pos_reward + close_reward + closer_reward + dist_reward) + total_pen;
     bool crash = B.crashes[i] != 0;
-    if (crash) r = rp[17];
-    reward[i] = r;
+    reward[i] = reward_navigation(R.rp, cpf, pe, ppe, B.actions[0 * n + i], B.actions[2 * n + i], B.actions[3 * n + i],
+                                  B.prev_actions[0 * n + i], B.prev_actions[2 * n + i], B.prev_actions[3 * n + i], crash);
     bool trunc = B.sim_steps[i] > episode_len;
     B.truncations[i] = trunc ? 1 : 0;
     reset = (crash && reset_on_collision) || trunc;
     B.reset_mask[i] = reset ? 1 : 0;
   }
-  if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag, 1);
+  if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
 
 // navigation_task.py:369-393; one wave per env so the depth min-pool is a coalesced sweep
@@ -560,52 +646,147 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Reset (base_multirotor.py:177-205, motor_model.py:140-154, env_manager.py:301)
+// Reset.  Uniform draws come either from tensors (host RNG, reference-faithful stream) or
+// from Philox4x32-10 evaluated in place (sync-free mode).
 // ---------------------------------------------------------------------------------------
-template <int M>
-__global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (*B.reset_flag == 0) return;  // nobody resets: the reference does not touch anything
-  bool reset = B.reset_mask[i] != 0;
-  EnvState s;
-  if (reset) {
-    // IsaacGymEnv.reset_idx: env bounds first, the robot spawn uses them
-    float bmin[3], bmax[3];
+struct U4 {
+  uint32_t x, y, z, w;
+};
+AGX_DEV U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * R.u_bounds_lo[(size_t)i * 3 + c] + R.lower_bound_min[c];
-      bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * R.u_bounds_hi[(size_t)i * 3 + c] + R.upper_bound_min[c];
-      B.bounds_min[c * n + i] = bmin[c];
-      B.bounds_max[c * n + i] = bmax[c];
-    }
-    float r[13];
-#pragma unroll
-    for (int c = 0; c < 13; ++c) r[c] = (R.max_state[c] - R.min_state[c]) * R.u_state[(size_t)i * 13 + c] + R.min_state[c];
-    s.p = V3{bmin[0] + (bmax[0] - bmin[0]) * r[0], bmin[1] + (bmax[1] - bmin[1]) * r[1], bmin[2] + (bmax[2] - bmin[2]) * r[2]};
-    s.q = quat_from_euler(r[3], r[4], r[5]);
-    s.v = V3{r[7], r[8], r[9]};
-    s.w = V3{r[10], r[11], r[12]};
-    store_state(B.state, n, i, s);
-    if (R.u_gains) {
-#pragma unroll
-      for (int c = 0; c < 12; ++c)
-        B.gains[c * n + i] = (R.gains_max[c] - R.gains_min[c]) * R.u_gains[(size_t)i * 12 + c] + R.gains_min[c];
-    }
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-      size_t k = (size_t)i * M + j;
-      B.motor_tau_inc[j * n + i] = (R.tau_inc_max - R.tau_inc_min) * R.u_tau_inc[k] + R.tau_inc_min;
-      B.motor_tau_dec[j * n + i] = (R.tau_dec_max - R.tau_dec_min) * R.u_tau_dec[k] + R.tau_dec_min;
-      B.motor_thrust[j * n + i] = (P.max_thrust - P.min_thrust) * R.u_thrust[k] + P.min_thrust;
-      if (P.use_rps) B.motor_kT[j * n + i] = (R.kT_max - R.kT_min) * R.u_kT[k] + R.kT_min;
-    }
-    B.sim_steps[i] = 0;
-  } else {
-    s = load_state(B.state, n, i);
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
+  return U4{c0, c1, c2, c3};
+}
+AGX_DEV float u01_from_bits(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0, 1), 24 bits like torch.rand
+
+enum { RNG_BOUNDS = 0, RNG_STATE = 1, RNG_GAINS = 2, RNG_MOTOR = 3, RNG_ASSET_SEL = 4, RNG_ASSETS = 16 };
+
+// j-th uniform of stream `stream` of env `env` in its `episode`-th reset
+AGX_DEV float rng_u01(uint64_t seed, int env, int episode, int stream, int j) {
+  U4 r = philox4x32_10((uint32_t)env, (uint32_t)episode, (uint32_t)stream, (uint32_t)(j >> 2), (uint32_t)seed, (uint32_t)(seed >> 32));
+  int l = j & 3;
+  return u01_from_bits(l == 0 ? r.x : (l == 1 ? r.y : (l == 2 ? r.z : r.w)));
+}
+
+AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin[3], float bmax[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float ulo = R.u_state ? R.u_bounds_lo[(size_t)i * 3 + c] : rng_u01(R.seed, i, episode, RNG_BOUNDS, c);
+    float uhi = R.u_state ? R.u_bounds_hi[(size_t)i * 3 + c] : rng_u01(R.seed, i, episode, RNG_BOUNDS, 3 + c);
+    bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
+    bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
+  }
+}
+
+// returns the (possibly new) state of env i; `with_flag`: the caller already checked the flag
+template <int M>
+AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int n, const AgxResetArgs &R, int i) {
+  EnvState s;
+  if (B.reset_mask[i] == 0) return load_state(B.state, n, i);
+  const int ep = B.episode_count ? B.episode_count[i] : 0;
+  // IsaacGymEnv.reset_idx: env bounds first, the robot spawn uses them
+  float bmin[3], bmax[3];
+  sample_bounds(R, i, ep, bmin, bmax);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    B.bounds_min[c * n + i] = bmin[c];
+    B.bounds_max[c * n + i] = bmax[c];
+  }
+  float r[13];
+#pragma unroll
+  for (int c = 0; c < 13; ++c) {
+    float u = R.u_state ? R.u_state[(size_t)i * 13 + c] : rng_u01(R.seed, i, ep, RNG_STATE, c);
+    r[c] = (R.max_state[c] - R.min_state[c]) * u + R.min_state[c];
+  }
+  s.p = V3{bmin[0] + (bmax[0] - bmin[0]) * r[0], bmin[1] + (bmax[1] - bmin[1]) * r[1], bmin[2] + (bmax[2] - bmin[2]) * r[2]};
+  s.q = quat_from_euler(r[3], r[4], r[5]);
+  s.v = V3{r[7], r[8], r[9]};
+  s.w = V3{r[10], r[11], r[12]};
+  store_state(B.state, n, i, s);
+  if (R.randomize_gains) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      float u = R.u_state ? R.u_gains[(size_t)i * 12 + c] : rng_u01(R.seed, i, ep, RNG_GAINS, c);
+      B.gains[c * n + i] = (R.gains_max[c] - R.gains_min[c]) * u + R.gains_min[c];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    size_t k = (size_t)i * M + j;
+    float u0 = R.u_state ? R.u_tau_inc[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 0);
+    float u1 = R.u_state ? R.u_tau_dec[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 1);
+    float u2 = R.u_state ? R.u_thrust[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 2);
+    B.motor_tau_inc[j * n + i] = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
+    B.motor_tau_dec[j * n + i] = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
+    B.motor_thrust[j * n + i] = (P.max_thrust - P.min_thrust) * u2 + P.min_thrust;
+    if (P.use_rps) {
+      float u3 = R.u_state ? R.u_kT[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 3);
+      B.motor_kT[j * n + i] = (R.kT_max - R.kT_min) * u3 + R.kT_min;
+    }
+  }
+  B.sim_steps[i] = 0;
+  if (B.episode_count) B.episode_count[i] = ep + 1;
+  return s;
+}
+
+// Reset (base_multirotor.py:177-205, motor_model.py:140-154, env_manager.py:301) and,
+// when WITH_OBS, the position task's observation of the post-reset state.
+template <int M, bool WITH_OBS>
+__global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
+                                                      const float *__restrict__ target, float *__restrict__ obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
+  if (i >= n) return;
+  if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
+    if (WITH_OBS) write_obs_position(n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+    return;
+  }
+  EnvState s = reset_env<M>(P, B, n, R, i);
   // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
-  store_derived(B.derived, n, i, update_states(s));
+  Derived d = update_states(s);
+  store_derived(B.derived, n, i, d);
+  if (WITH_OBS) write_obs_position(n, i, target, obs, s, d);
+}
+
+// AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295)
+__global__ void __launch_bounds__(256) k_reset_assets(AgxEnvBuffers B, int n, int K, AgxResetArgs R, const float *__restrict__ u1,
+                                                       const float *__restrict__ u2, const float *__restrict__ u_sel,
+                                                       const float *__restrict__ min_ratio, const float *__restrict__ max_ratio,
+                                                       int num_obstacles, int nk, float *__restrict__ asset_state) {
+  const int env = blockIdx.y;
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= K) return;
+  if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[env] == 0) return;
+  const int ep = B.episode_count ? B.episode_count[env] : 0;
+  const bool host_rng = u1 != nullptr;
+  float usel = host_rng ? u_sel[env] : rng_u01(R.seed, env, ep, RNG_ASSET_SEL, 0);
+  // strict mode hands over the bernoulli outcome (0/1); the device generator thresholds at 0.15
+  const bool sel = host_rng ? (usel > 0.0f) : (usel < 0.15f);
+  const int n_active = sel ? max(num_obstacles / 2, nk / 2) : max(num_obstacles, nk);
+  float bmin[3], bmax[3];
+  sample_bounds(R, env, ep, bmin, bmax);
+  const size_t base = ((size_t)env * K + a) * 13;
+  float ratio[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    float u = host_rng ? (sel ? u2[base + c] : u1[base + c]) : rng_u01(R.seed, env, ep, RNG_ASSETS + a, c);
+    ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * u + min_ratio[base + c];
+  }
+  float *st = asset_state + base;
+  if (a >= n_active) {
+    st[0] = -1000.0f; st[1] = -1000.0f; st[2] = -1000.0f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st[c] = bmin[c] + (bmax[c] - bmin[c]) * ratio[c];
+  }
+  Q4 q = quat_from_euler(ratio[3], ratio[4], ratio[5]);
+  st[3] = q.x; st[4] = q.y; st[5] = q.z; st[6] = q.w;
 }
 
 }  // namespace agx
@@ -615,22 +796,32 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
 // =========================================================================================
 using namespace agx;
 
-#define AGX_DISPATCH_M(M_, ...)                          \
-  switch (M_) {                                          \
-    case 1: { constexpr int kM = 1; __VA_ARGS__; } break; \
-    case 2: { constexpr int kM = 2; __VA_ARGS__; } break; \
-    case 3: { constexpr int kM = 3; __VA_ARGS__; } break; \
-    case 4: { constexpr int kM = 4; __VA_ARGS__; } break; \
-    case 5: { constexpr int kM = 5; __VA_ARGS__; } break; \
-    case 6: { constexpr int kM = 6; __VA_ARGS__; } break; \
-    case 7: { constexpr int kM = 7; __VA_ARGS__; } break; \
-    case 8: { constexpr int kM = 8; __VA_ARGS__; } break; \
-    default: return fail(AGX_E_ARG, "num_motors %d not in 1..8", M_); \
+// instantiate the step kernel for every (motor count, controller) pair in use by the reference's
+// multirotor configs: 4 (quad, lmf*, x500, magpie), 6, 8 (octarotor) motors
+#define AGX_DISPATCH_M(M_, ...)                                       \
+  switch (M_) {                                                       \
+    case 4: { constexpr int kM = 4; __VA_ARGS__; } break;             \
+    case 6: { constexpr int kM = 6; __VA_ARGS__; } break;             \
+    case 8: { constexpr int kM = 8; __VA_ARGS__; } break;             \
+    default: return fail(AGX_E_UNSUPPORTED, "num_motors %d: kernels are built for 4, 6 and 8 motors", M_); \
+  }
+#define AGX_DISPATCH_CTRL(C_, ...)                                                         \
+  switch (C_) {                                                                            \
+    case AGX_CTRL_NONE: { constexpr int kC = AGX_CTRL_NONE; __VA_ARGS__; } break;          \
+    case AGX_CTRL_POSITION: { constexpr int kC = AGX_CTRL_POSITION; __VA_ARGS__; } break;  \
+    case AGX_CTRL_VELOCITY: { constexpr int kC = AGX_CTRL_VELOCITY; __VA_ARGS__; } break;  \
+    case AGX_CTRL_ATTITUDE: { constexpr int kC = AGX_CTRL_ATTITUDE; __VA_ARGS__; } break;  \
+    case AGX_CTRL_RATES: { constexpr int kC = AGX_CTRL_RATES; __VA_ARGS__; } break;        \
+    case AGX_CTRL_ACCELERATION: { constexpr int kC = AGX_CTRL_ACCELERATION; __VA_ARGS__; } break; \
+    case AGX_CTRL_VEL_STEERING: { constexpr int kC = AGX_CTRL_VEL_STEERING; __VA_ARGS__; } break; \
+    case AGX_CTRL_FULLY_ACTUATED: { constexpr int kC = AGX_CTRL_FULLY_ACTUATED; __VA_ARGS__; } break; \
+    default: return fail(AGX_E_ARG, "unknown controller id %d", C_);                       \
   }
 
 static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) {
   AGX_REQUIRE(B != nullptr, "null buffers");
   AGX_REQUIRE(n > 0, "num_envs must be > 0 (got %d)", n);
+  AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
   if (P) {
     AGX_REQUIRE(P->num_motors >= 1 && P->num_motors <= AGX_MAX_MOTORS, "num_motors out of range");
     AGX_REQUIRE(P->num_actions >= 1 && P->num_actions <= AGX_MAX_ACTIONS, "num_actions out of range");
@@ -643,21 +834,35 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   return AGX_OK;
 }
 
-extern "C" int agx_dynamics_substeps(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *actions_in,
-                                     int k, void *stream) {
+extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *actions_in, int k,
+                            const AgxTaskArgs *task, void *stream) {
   if (int e = check_common(P, B, n)) return e;
   AGX_REQUIRE(P != nullptr, "null params");
   AGX_REQUIRE(actions_in != nullptr, "null actions");
   AGX_REQUIRE(k >= 0 && k <= AGX_MAX_SUBSTEPS, "k_substeps out of range: %d", k);
   AGX_REQUIRE(B->state && B->derived && B->actions && B->prev_actions && B->motor_thrust && B->motor_tau_inc &&
-                  B->motor_tau_dec && B->crashes && B->truncations && B->sim_steps && B->reset_flag,
+                  B->motor_tau_dec && B->crashes && B->truncations && B->sim_steps,
               "null env buffer");
   AGX_REQUIRE(P->controller == AGX_CTRL_NONE || B->gains, "null gains");
   AGX_REQUIRE(!P->use_rps || B->motor_kT, "null motor_kT with use_rps");
+  AgxTaskArgs T{};
+  if (task) T = *task;
+  AGX_REQUIRE(T.kind >= AGX_TASK_NONE && T.kind <= AGX_TASK_NAVIGATION, "bad task kind %d", T.kind);
+  if (T.kind != AGX_TASK_NONE) {
+    AGX_REQUIRE(T.target && T.reward && B->reset_mask && B->reset_flag, "null task buffer");
+    AGX_REQUIRE(T.kind != AGX_TASK_NAVIGATION || (T.pos_err && T.prev_pos_err && P->num_actions >= 4), "null navigation buffer");
+  }
   const int block = pick_block(n);
-  AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL(k_dynamics_substeps<kM>, dim3(blocks_for(n, block)), dim3(block), 0,
-                                                   (hipStream_t)stream, *P, *B, n, actions_in, k));
-  return check_launch("agx_dynamics_substeps");
+  const size_t lds = B->boxes ? (size_t)k * 3 * block * sizeof(float) : 0;
+  AGX_DISPATCH_M(P->num_motors,
+                 AGX_DISPATCH_CTRL(P->controller, hipLaunchKernelGGL((k_env_step<kM, kC>), dim3(blocks_for(n, block)), dim3(block),
+                                                                     lds, (hipStream_t)stream, *P, *B, n, actions_in, k, T)));
+  return check_launch("agx_env_step");
+}
+
+extern "C" int agx_dynamics_substeps(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *actions_in,
+                                     int k, void *stream) {
+  return agx_env_step(P, B, n, actions_in, k, nullptr, stream);
 }
 
 extern "C" int agx_update_states(const AgxEnvBuffers *B, int n, void *stream) {
@@ -681,7 +886,8 @@ extern "C" int agx_controller_wrench(const AgxRobotParams *P, const AgxEnvBuffer
 extern "C" int agx_reward_position(const AgxEnvBuffers *B, int n, const float *target, int episode_len,
                                    int reset_on_collision, float *reward, void *stream) {
   if (int e = check_common(nullptr, B, n)) return e;
-  AGX_REQUIRE(target && reward && B->reset_flag && B->reset_mask && B->state && B->derived && B->crashes && B->truncations && B->sim_steps,
+  AGX_REQUIRE(target && reward && B->reset_flag && B->reset_mask && B->state && B->derived && B->crashes && B->truncations &&
+                  B->sim_steps,
               "null buffer");
   const int block = pick_block(n);
   hipLaunchKernelGGL(k_reward_position, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *B, n, target,
@@ -707,8 +913,8 @@ extern "C" int agx_reward_navigation(const AgxEnvBuffers *B, int n, const float 
   NavParams R;
   for (int c = 0; c < 18; ++c) R.rp[c] = rp[c];  // rp is a HOST pointer (18 config scalars)
   const int block = pick_block(n);
-  hipLaunchKernelGGL(k_reward_navigation, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *B, n, 4, target,
-                     R, cpf, pos_err, prev_pos_err, episode_len, reset_on_collision, reward);
+  hipLaunchKernelGGL(k_reward_navigation, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *B, n, target, R, cpf,
+                     pos_err, prev_pos_err, episode_len, reset_on_collision, reward);
   return check_launch("agx_reward_navigation");
 }
 
@@ -724,17 +930,49 @@ extern "C" int agx_obs_navigation(const AgxEnvBuffers *B, int n, const float *ta
   return check_launch("agx_obs_navigation");
 }
 
+static int check_reset(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R) {
+  if (int e = check_common(P, B, n)) return e;
+  AGX_REQUIRE(P && R && B->reset_flag && B->reset_mask && B->bounds_min && B->bounds_max, "null argument");
+  if (R->u_state) {
+    AGX_REQUIRE(R->u_bounds_lo && R->u_bounds_hi && R->u_tau_inc && R->u_tau_dec && R->u_thrust, "null reset input");
+    AGX_REQUIRE(!P->use_rps || R->u_kT, "null u_kT with use_rps");
+    AGX_REQUIRE(!R->randomize_gains || R->u_gains, "null u_gains with randomize_gains");
+  } else {
+    AGX_REQUIRE(B->episode_count, "device RNG needs buf->episode_count");
+  }
+  AGX_REQUIRE(!R->randomize_gains || B->gains, "null gains with randomize_gains");
+  return AGX_OK;
+}
+
 extern "C" int agx_reset_masked(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R,
                                 void *stream) {
-  if (int e = check_common(P, B, n)) return e;
-  AGX_REQUIRE(P && R && B->reset_flag && B->reset_mask, "null argument");
-  AGX_REQUIRE(R->u_bounds_lo && R->u_bounds_hi && R->u_state && R->u_tau_inc && R->u_tau_dec && R->u_thrust &&
-                  B->bounds_min && B->bounds_max,
-              "null reset input");
-  AGX_REQUIRE(!P->use_rps || R->u_kT, "null u_kT with use_rps");
-  AGX_REQUIRE(!R->u_gains || B->gains, "null gains with u_gains");
+  if (int e = check_reset(P, B, n, R)) return e;
   const int block = pick_block(n);
-  AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL(k_reset_masked<kM>, dim3(blocks_for(n, block)), dim3(block), 0,
-                                                   (hipStream_t)stream, *P, *B, n, *R));
+  AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, false>), dim3(blocks_for(n, block)), dim3(block), 0,
+                                                   (hipStream_t)stream, *P, *B, n, *R, nullptr, nullptr));
   return check_launch("agx_reset_masked");
+}
+
+extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R,
+                                      const float *target, float *obs, void *stream) {
+  if (int e = check_reset(P, B, n, R)) return e;
+  AGX_REQUIRE(target && obs && B->state && B->derived, "null buffer");
+  const int block = pick_block(n);
+  AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, true>), dim3(blocks_for(n, block)), dim3(block), 0,
+                                                   (hipStream_t)stream, *P, *B, n, *R, target, obs));
+  return check_launch("agx_post_step_position");
+}
+
+extern "C" int agx_reset_assets(const AgxEnvBuffers *B, int n, int K, const AgxResetArgs *R, const float *u1, const float *u2,
+                                const float *u_sel, const float *min_ratio, const float *max_ratio, int num_obstacles,
+                                int num_keep, float *asset_state, void *stream) {
+  if (int e = check_common(nullptr, B, n)) return e;
+  AGX_REQUIRE(K > 0 && R && min_ratio && max_ratio && asset_state && B->reset_flag && B->reset_mask, "bad arguments");
+  AGX_REQUIRE((u1 && u2 && u_sel && R->u_state) || (!u1 && !u2 && !u_sel && !R->u_state),
+              "asset draws and robot draws must both come from tensors or both from the device generator");
+  AGX_REQUIRE(u1 || B->episode_count, "device RNG needs buf->episode_count");
+  dim3 grid(blocks_for(K, 64), n);
+  hipLaunchKernelGGL(k_reset_assets, grid, dim3(64), 0, (hipStream_t)stream, *B, n, K, *R, u1, u2, u_sel, min_ratio, max_ratio,
+                     num_obstacles, num_keep, asset_state);
+  return check_launch("agx_reset_assets");
 }

@@ -47,11 +47,13 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
   if (mask && !mask[env]) return;
   const float *as = asset_state + ((size_t)env * na + k) * 13;
   const float *he = half_extents + ((size_t)env * na + k) * 3;
-  float *bx = boxes + (size_t)k * 10 * n + env;
+  float *bx = boxes + (size_t)k * 11 * n + env;
 #pragma unroll
   for (int c = 0; c < 7; ++c) bx[(size_t)c * n] = as[c];
 #pragma unroll
   for (int c = 0; c < 3; ++c) bx[(size_t)(7 + c) * n] = he[c];
+  // bounding-sphere radius (for the conservative cull), rounded up
+  bx[(size_t)10 * n] = sqrtf(he[0] * he[0] + he[1] * he[1] + he[2] * he[2]) * 1.000001f;
 }
 
 // ------------------------------------------------------------------------------------ LBVH

@@ -74,6 +74,11 @@ class EnvManager(BaseManager):
         # host sync per step to learn whether any env resets).  Default: draw every step.
         self.strict_rng = bool(self.env_args.get("strict_rng", False))
         self.random_source = self.env_args.get("random_source") or TorchRandomSource(device)
+        # seed of the device-side counter RNG used by the sync-free mode (Philox4x32-10)
+        self.rng_seed = int(self.env_args.get("rng_seed", torch.initial_seed())) & 0xFFFFFFFFFFFFFFFF
+        self._parity = 0
+        self.task_args = None   # AgxTaskArgs: reward / flags fused into the env-step launch
+        self.post_obs = None    # (target_ptr, obs_ptr): observation fused into the reset launch
         self.global_tensor_dict = {}
         self.keep_in_env = None
         self.step_counter = 0
@@ -92,7 +97,8 @@ class EnvManager(BaseManager):
         g["crashes"] = torch.zeros(N, dtype=torch.bool, device=dev)
         g["truncations"] = torch.zeros(N, dtype=torch.bool, device=dev)
         g["reset_mask"] = torch.zeros(N, dtype=torch.uint8, device=dev)
-        g["reset_flag"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        g["reset_flag"] = torch.zeros(2, dtype=torch.int32, device=dev)  # double buffered by step parity
+        g["episode_count"] = torch.zeros(N, dtype=torch.int32, device=dev)
         g["sim_steps"] = torch.zeros(N, dtype=torch.int32, device=dev)
         self.collision_tensor, self.truncation_tensor = g["crashes"], g["truncations"]
         self.num_env_actions = env_cfg.env.num_env_actions
@@ -152,6 +158,8 @@ class EnvManager(BaseManager):
         B.wrench_cmd = p(g.get("controller_wrench_soa"))
         B.crashes, B.truncations = p(g["crashes"]), p(g["truncations"])
         B.sim_steps, B.reset_mask, B.reset_flag = p(g["sim_steps"]), p(g["reset_mask"]), p(g["reset_flag"])
+        B.flag_parity = self._parity
+        B.episode_count = p(g["episode_count"])
         B.bounds_min, B.bounds_max = p(self.bounds_soa[0]), p(self.bounds_soa[1])
         B.disturb = None
         for i, v in enumerate(robot.max_force_and_torque_disturbance):
@@ -164,6 +172,7 @@ class EnvManager(BaseManager):
         robot.controller._env_binding = self
         self._make_reset_args()
         self._disturb_buf = None
+        self._reward_fresh = self._obs_fresh = False
 
     def _make_reset_args(self):
         N, dev = self.num_envs, self.device
@@ -181,10 +190,13 @@ class EnvManager(BaseManager):
             off += N * c
         R = AgxResetArgs()
         p = _lib.dptr
-        R.u_bounds_lo, R.u_bounds_hi, R.u_state = p(self._u["bounds_lo"]), p(self._u["bounds_hi"]), p(self._u["state"])
-        R.u_gains = p(self._u["gains"]) if self._randomize_gains else None
-        R.u_tau_inc, R.u_tau_dec = p(self._u["tau_inc"]), p(self._u["tau_dec"])
-        R.u_thrust, R.u_kT = p(self._u["thrust"]), p(self._u["kT"])
+        if self.strict_rng:  # host tensors; otherwise all NULL = device generator
+            R.u_bounds_lo, R.u_bounds_hi, R.u_state = p(self._u["bounds_lo"]), p(self._u["bounds_hi"]), p(self._u["state"])
+            R.u_gains = p(self._u["gains"]) if self._randomize_gains else None
+            R.u_tau_inc, R.u_tau_dec = p(self._u["tau_inc"]), p(self._u["tau_dec"])
+            R.u_thrust, R.u_kT = p(self._u["thrust"]), p(self._u["kT"])
+        R.randomize_gains = int(self._randomize_gains)
+        R.seed = self.rng_seed
         for i in range(3):
             R.lower_bound_min[i], R.lower_bound_max[i] = e.lower_bound_min[i], e.lower_bound_max[i]
             R.upper_bound_min[i], R.upper_bound_max[i] = e.upper_bound_min[i], e.upper_bound_max[i]
@@ -229,8 +241,7 @@ class EnvManager(BaseManager):
         rows], motor tau_inc, tau_dec, thrust, kT [motor_model.py:140-154]."""
         rs, u = self.random_source, self._u
         if not self.strict_rng:
-            rs.rand_into(self._u_flat, tag="reset_all")
-            return
+            return  # the reset kernels draw with the device generator
         robot = self.robot_manager.robot
         rs.rand_into(u["bounds_lo"], tag="bounds_lo")
         rs.rand_into(u["bounds_hi"], tag="bounds_hi")
@@ -247,11 +258,18 @@ class EnvManager(BaseManager):
             rs.rand_into(u["kT"], tag="kT")
         self.robot_manager.draw_sensor_reset_randoms(env_ids)
 
-    def _launch_reset(self):
-        """Device side of EnvManager.reset_idx for the envs flagged in reset_mask."""
+    def _launch_reset(self, with_obs=False):
+        """Device side of EnvManager.reset_idx for the envs flagged in reset_mask (all kernels
+        return immediately when reset_flag[parity] is 0)."""
         self.asset_manager.reset_masked(self)  # obstacle poses, scene triangles, BVH, boxes
-        _lib.check(self._lib.agx_reset_masked(self._params, self._buffers, self.num_envs, self._reset_args, self._stream()),
-                   "agx_reset_masked")
+        if with_obs and self.post_obs is not None:
+            _lib.check(self._lib.agx_post_step_position(self._params, self._buffers, self.num_envs, self._reset_args,
+                                                        self.post_obs[0], self.post_obs[1], self._stream()),
+                       "agx_post_step_position")
+            self._obs_fresh = True
+        else:
+            _lib.check(self._lib.agx_reset_masked(self._params, self._buffers, self.num_envs, self._reset_args, self._stream()),
+                       "agx_reset_masked")
         self.robot_manager.reset_sensors_masked()
 
     def reset_idx(self, env_ids=None):
@@ -264,7 +282,7 @@ class EnvManager(BaseManager):
             return
         g["reset_mask"].zero_()
         g["reset_mask"][env_ids] = 1
-        g["reset_flag"].fill_(1)
+        g["reset_flag"][self._parity] = 1
         self._draw_reset_randoms(env_ids)
         self._launch_reset()
 
@@ -279,14 +297,10 @@ class EnvManager(BaseManager):
 
     def reset_terminated_and_truncated_envs(self):
         g = self.global_tensor_dict
-        if self.strict_rng:
-            if int(g["reset_flag"].item()) == 0:  # host sync, like the reference's nonzero()/len()
-                return ResetSet(g["reset_mask"])
+        if self.strict_rng and int(g["reset_flag"][self._parity].item()) != 0:  # host sync, like the reference's nonzero()/len()
             env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1)
             self._draw_reset_randoms(env_ids)
-        else:
-            self._draw_reset_randoms()
-        self._launch_reset()
+        self._launch_reset(with_obs=True)
         return ResetSet(g["reset_mask"])
 
     # ------------------------------------------------------------------ stepping
@@ -327,13 +341,20 @@ class EnvManager(BaseManager):
             raise ValueError("Action tensor does not have the correct number of environments")
         self._draw_disturbance(num_substeps)
         _lib.check(
-            self._lib.agx_dynamics_substeps(self._params, self._buffers, self.num_envs, _lib.dptr(a), num_substeps, self._stream()),
-            "agx_dynamics_substeps",
+            self._lib.agx_env_step(self._params, self._buffers, self.num_envs, _lib.dptr(a), num_substeps, self.task_args,
+                                   self._stream()),
+            "agx_env_step",
         )
+        self._reward_fresh = self.task_args is not None
+        self._obs_fresh = False
 
     def step(self, actions, env_actions=None):
         if env_actions is not None:
             raise NotImplementedError("kinematic obstacle actions (env_actions) are not supported yet (SURVEY f4)")
+        self._require_device()
+        # new env step: switch to the reset flag the previous step's reset kernel cleared
+        self._parity ^= 1
+        self._buffers.flag_parity = self._parity
         self.simulate(actions, env_actions, self.num_physics_steps())
         self.step_counter += 1
 

@@ -9,7 +9,7 @@ Device data owned here
     tri_world     [N, T, 9]   after tf_apply(asset pose)   (rebuilt for reset envs)
     tri_seg       [N, T]      int32 segmentation id of the owning asset
     bvh_nodes     [N, T-1, 16] LBVH built on device by agx_bvh_build
-    boxes_soa     [K*10, N]   OBBs for the collision test
+    boxes_soa     [K*11, N]   OBBs (+ bounding radius) for the collision test
 """
 import random
 
@@ -95,7 +95,7 @@ class SceneManager:
         self.tri_world = torch.zeros_like(self.tri_local)
         self.tri_asset = torch.arange(K, device=dev, dtype=torch.int32).repeat_interleave(12).contiguous()
         self.tri_seg = self.asset_semantic_id.to(torch.int32).repeat_interleave(12, dim=1).contiguous()
-        self.boxes_soa = torch.zeros(K * 10, N, device=dev)
+        self.boxes_soa = torch.zeros(K * 11, N, device=dev)
         self.bvh_nodes = torch.zeros(N, max(12 * K - 1, 1), 16, device=dev)
         g["scene_tri_world"] = self.tri_world
         g["scene_tri_seg"] = self.tri_seg

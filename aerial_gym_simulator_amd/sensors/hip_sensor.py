@@ -105,7 +105,8 @@ class HipSensor:
             rs = g["random_source"]
             rs.rand_into(self._u_pos, tag="sensor_pos")
             rs.rand_into(self._u_rot, tag="sensor_rot")
-        mask = (g["reset_mask"].bool() & (g["reset_flag"] != 0)).view(-1, 1, 1)
+        env = g["env_manager"]
+        mask = (g["reset_mask"].bool() & (g["reset_flag"][env._parity] != 0)).view(-1, 1, 1)
         pos = (self.max_translation - self.min_translation) * self._u_pos + self.min_translation
         eul = (self.max_rotation - self.min_rotation) * self._u_rot + self.min_rotation
         quat = quat_from_euler_xyz(eul[..., 0], eul[..., 1], eul[..., 2])

@@ -71,6 +71,22 @@ class NavigationTask(BaseTask):
         self._u_vec = torch.zeros(N, 3, device=dev)
         self._u_euler = torch.zeros(N, 3, device=dev)
         self.curriculum_check_every = int(cfg.args.get("curriculum_check_every", 1)) if isinstance(cfg.args, dict) else 1
+        self._fuse_with_env()
+
+    def _fuse_with_env(self):
+        env = self.sim_env
+        if env._buffers is None:
+            return
+        T = _lib.AgxTaskArgs()
+        T.kind = _lib.TASK_NAVIGATION
+        T.episode_len = int(self.task_config.episode_len_steps)
+        T.reset_on_collision = int(env.cfg.env.reset_on_collision)
+        T.curriculum_progress = float(self.curriculum_progress_fraction)
+        T.target, T.reward = _lib.dptr(self.target_soa), _lib.dptr(self.rewards)
+        T.pos_err, T.prev_pos_err = _lib.dptr(self.pos_err_soa), _lib.dptr(self.prev_pos_err_soa)
+        for i in range(18):
+            T.rp[i] = self._rp[i]
+        env.task_args = T
 
     def _update_progress(self):
         c = self.task_config.curriculum
@@ -124,6 +140,9 @@ class NavigationTask(BaseTask):
     def step(self, actions):
         env = self.sim_env
         transformed_action = self.action_transformation_function(actions)
+        if env.task_args is not None:
+            env.task_args.curriculum_progress = float(self.curriculum_progress_fraction)
+            env.task_args.episode_len = int(self.task_config.episode_len_steps)
         env.step(actions=transformed_action)
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
@@ -164,6 +183,9 @@ class NavigationTask(BaseTask):
     def compute_rewards_and_crashes(self, obs_dict):
         env = self.sim_env
         env._require_device()
+        if env._reward_fresh:  # produced by the fused epilogue of agx_env_step
+            env._reward_fresh = False
+            return self.rewards, self.terminations
         _lib.check(
             env._lib.agx_reward_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), self._rp,
                                            float(self.curriculum_progress_fraction), _lib.dptr(self.pos_err_soa),

@@ -49,6 +49,22 @@ class PositionSetpointTask(BaseTask):
             "rewards": torch.zeros((N, 1), device=dev),
         }
         self.infos = {}
+        self._fuse_with_env()
+
+    def _fuse_with_env(self):
+        """Ask the EnvManager to evaluate this task's reward / crash / truncation / reset set in the
+        env-step launch and its observation in the reset launch (2 launches per task.step())."""
+        env = self.sim_env
+        if env._buffers is None:
+            return
+        T = _lib.AgxTaskArgs()
+        T.kind = _lib.TASK_POSITION
+        T.episode_len = int(self.task_config.episode_len_steps)
+        T.reset_on_collision = int(env.cfg.env.reset_on_collision)
+        T.target = _lib.dptr(self.target_soa)
+        T.reward = _lib.dptr(self.rewards)
+        env.task_args = T
+        env.post_obs = (_lib.dptr(self.target_soa), _lib.dptr(self.task_obs["observations"]))
 
     def close(self):
         self.sim_env.delete_env()
@@ -72,6 +88,8 @@ class PositionSetpointTask(BaseTask):
         self.prev_actions[:] = self.actions
         self.actions = actions
         env = self.sim_env
+        if env.task_args is not None:
+            env.task_args.episode_len = int(self.task_config.episode_len_steps)
         env.step(actions=self.actions)
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
@@ -86,6 +104,9 @@ class PositionSetpointTask(BaseTask):
         """compute_reward + `truncations = sim_steps > episode_len` (reference :205-229,:172-174)."""
         env = self.sim_env
         env._require_device()
+        if env._reward_fresh:  # already produced by the fused epilogue of agx_env_step
+            env._reward_fresh = False
+            return self.rewards, self.terminations
         _lib.check(
             env._lib.agx_reward_position(env._buffers, env.num_envs, _lib.dptr(self.target_soa),
                                          int(self.task_config.episode_len_steps), int(env.cfg.env.reset_on_collision),
@@ -101,11 +122,14 @@ class PositionSetpointTask(BaseTask):
     def process_obs_for_task(self):
         env = self.sim_env
         env._require_device()
+        self.task_obs["rewards"] = self.rewards
+        self.task_obs["terminations"] = self.terminations
+        self.task_obs["truncations"] = self.truncations
+        if env._obs_fresh:  # already written by agx_post_step_position
+            env._obs_fresh = False
+            return
         _lib.check(
             env._lib.agx_obs_position(env._buffers, env.num_envs, _lib.dptr(self.target_soa),
                                       _lib.dptr(self.task_obs["observations"]), env._stream()),
             "agx_obs_position",
         )
-        self.task_obs["rewards"] = self.rewards
-        self.task_obs["terminations"] = self.terminations
-        self.task_obs["truncations"] = self.truncations

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 1
+#define AGX_ABI_VERSION 2
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -108,14 +108,18 @@ typedef struct AgxEnvBuffers {
   int32_t *sim_steps;    /* [N]   EnvManager.sim_steps                                */
   uint8_t *reset_mask;   /* [N]   envs to reset = crashes*reset_on_collision | truncations
                             (env_manager.py:364-371), written by the task reward kernels          */
-  int32_t *reset_flag;   /* [1]   device flag: zeroed by agx_dynamics_substeps, set by the
-                            task reward kernel when any env must reset, read by agx_reset_masked */
+  int32_t *reset_flag;   /* [2]   device flags, double buffered by env-step parity: the task reward
+                            (kernel or fused epilogue) ORs 1 into reset_flag[flag_parity] when any
+                            env must reset; agx_reset_masked / agx_post_step_* read that entry and
+                            clear the other one for the next step.  No host sync, no memset.     */
+  int32_t flag_parity;   /* 0 / 1, toggled by the host once per env step                         */
+  int32_t *episode_count;/* [N]   number of resets of each env (device RNG counter), or NULL     */
   float *bounds_min;     /* [3][N] (env_bounds_min)                                    */
   float *bounds_max;     /* [3][N] (env_bounds_max)                                    */
   /* optional inputs */
   const float *disturb;  /* [k][7][N] per sub-step (bernoulli, 6 x U01) or NULL       */
   float disturb_max[6];
-  const float *boxes;    /* [K][10][N] obstacle OBBs centre(3) quat(4) half(3) or NULL */
+  const float *boxes;    /* [K][11][N] obstacle OBBs centre(3) quat(4) half(3) bounding radius(1), or NULL */
   int32_t num_boxes;
 } AgxEnvBuffers;
 
@@ -134,6 +138,26 @@ int agx_abi_version(void);
  * actions_in: [N][A] row-major, exactly the tensor the policy hands to task.step().  */
 int agx_dynamics_substeps(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                           const float *actions_in, int k_substeps, void *stream);
+
+/* Task epilogue fused into the env step (same arithmetic as agx_reward_position /
+ * agx_reward_navigation, evaluated on the registers of the dynamics kernel).             */
+enum { AGX_TASK_NONE = 0, AGX_TASK_POSITION = 1, AGX_TASK_NAVIGATION = 2 };
+typedef struct AgxTaskArgs {
+  int32_t kind;               /* AGX_TASK_*                                                */
+  int32_t episode_len;        /* truncations = sim_steps > episode_len                     */
+  int32_t reset_on_collision; /* cfg.env.reset_on_collision                                */
+  float curriculum_progress;  /* navigation only                                           */
+  const float *target;        /* [3][N]                                                    */
+  float *reward;              /* [N]                                                       */
+  float *pos_err;             /* [3][N] navigation only (in/out)                           */
+  float *prev_pos_err;        /* [3][N] navigation only (out)                              */
+  float rp[18];               /* navigation reward parameters                              */
+} AgxTaskArgs;
+
+/* agx_env_step = agx_dynamics_substeps + the task's reward / crash / truncation / reset-set
+ * in ONE launch (task may be NULL or kind NONE).                                           */
+int agx_env_step(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
+                 const float *actions_in, int k_substeps, const AgxTaskArgs *task, void *stream);
 
 /* BaseMultirotor.update_states alone (base_multirotor.py:287-294). */
 int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
@@ -185,8 +209,12 @@ int agx_obs_navigation(const AgxEnvBuffers *buf, int num_envs, const float *targ
  * the reference refreshes every env's derived tensors whenever at least one env resets.
  * Nothing is touched when the flag is 0.
  * The uniform draws are inputs, in the AoS layout torch produces them:
- *   u_bounds_lo/hi [N][3], u_state [N][13], u_gains [N][12] (or NULL),
+ *   u_bounds_lo/hi [N][3], u_state [N][13], u_gains [N][12],
  *   u_tau_inc/u_tau_dec/u_thrust/u_kT [N][M].
+ * If u_state is NULL the kernel draws them itself with a counter-based generator
+ * (Philox4x32-10 keyed by `seed`, counter = (env, episode_count[env], stream, block)):
+ * the sync-free mode, reproducible (the parity tests restate the generator bit for bit).
+ * randomize_gains != 0 resamples the controller gains (randomize_params).
  * The reset set is buf->reset_mask.                                                   */
 typedef struct AgxResetArgs {
   const float *u_bounds_lo, *u_bounds_hi;
@@ -195,10 +223,28 @@ typedef struct AgxResetArgs {
   float min_state[13], max_state[13];
   float gains_min[12], gains_max[12];
   float tau_inc_min, tau_inc_max, tau_dec_min, tau_dec_max, kT_min, kT_max;
+  int32_t randomize_gains;
+  uint64_t seed;
 } AgxResetArgs;
 
 int agx_reset_masked(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                      const AgxResetArgs *args, void *stream);
+
+/* agx_reset_masked + agx_obs_position in one launch (the position task has no sensor to
+ * render between reset and observation).                                                  */
+int agx_post_step_position(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
+                           const AgxResetArgs *args, const float *target, float *obs, void *stream);
+
+/* Obstacle pose randomisation of the reset envs: AssetManager.reset_idx
+ * (asset_manager.py:51-71) incl. the half-obstacle resample of env_manager.py:283-295.
+ * u1/u2 [N][K][13] and u_sel [N] are the uniform draws (first / second rand_like and the
+ * bernoulli(0.15)); all NULL = device generator.  u_bounds as in AgxResetArgs (the new env
+ * bounds are needed before the robot reset kernel has stored them).  Assets with index
+ * >= the active count are parked at -1000 m.                                              */
+int agx_reset_assets(const AgxEnvBuffers *buf, int num_envs, int num_assets,
+                     const AgxResetArgs *args, const float *u1, const float *u2,
+                     const float *u_sel, const float *min_ratio, const float *max_ratio,
+                     int num_obstacles, int num_keep_in_env, float *asset_state, void *stream);
 
 /* ---- scene / ray-cast -------------------------------------------------------------
  * Scene = per-env triangle soup with a fixed topology: T triangles, each owned by one
@@ -220,7 +266,7 @@ int agx_bvh_build(int num_envs, int num_tris, const float *tri_world, const uint
                   float *nodes, void *stream);
 
 /* Obstacle OBBs for the collision test, from the same asset poses:
- * boxes [K][10][N] <- asset_state [N][K][13], half_extents [N][K][3].                  */
+ * boxes [K][11][N] <- asset_state [N][K][13], half_extents [N][K][3].                  */
 int agx_boxes_from_assets(int num_envs, int num_assets, const float *asset_state,
                           const float *half_extents, const uint8_t *mask, float *boxes,
                           void *stream);

@@ -347,3 +347,21 @@ def sensor_postprocess(pixels, min_range, max_range, far_oor, near_oor, normaliz
         C.c_float(max_range), C.c_float(far_oor), C.c_float(near_oor), int(bool(normalize)),
     )
     return pixels
+
+
+# ----------------------------------------------------------------------------- device-RNG restatement
+RNG_BOUNDS, RNG_STATE, RNG_GAINS, RNG_MOTOR, RNG_ASSET_SEL, RNG_ASSETS = 0, 1, 2, 3, 4, 16
+
+
+def rng_fill(seed, episodes, stream, count):
+    ep = np.ascontiguousarray(episodes, dtype=np.int32)
+    out = np.zeros((ep.shape[0], count), np.float32)
+    lib().orc_rng_fill(C.c_uint64(seed), ep.shape[0], _p(ep), int(stream), int(count), _p(out))
+    return out
+
+
+def reset_assets(mask, u, sel, min_ratio, max_ratio, bounds_min, bounds_max, num_obstacles, num_keep, asset_state):
+    n, K = asset_state.shape[0], asset_state.shape[1]
+    lib().orc_reset_assets(n, K, _p(np.ascontiguousarray(mask, np.uint8)), _p(_f(u)), _p(np.ascontiguousarray(sel, np.uint8)),
+                           _p(_f(min_ratio)), _p(_f(max_ratio)), _p(_f(bounds_min)), _p(_f(bounds_max)), int(num_obstacles),
+                           int(num_keep), _p(asset_state))

@@ -712,3 +712,55 @@ void orc_tf_apply(int n, const float *q, const float *t, const float *v, float *
     for (int k = 0; k < 3; ++k) o[3 * i + k] += t[3 * i + k];
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* Counter-based generator of the product's sync-free mode, restated:  */
+/* Philox4x32-10 (Salmon et al. 2011), counter = (env, episode,        */
+/* stream, j / 4), key = seed; uniform = top 24 bits / 2^24.           */
+/* ------------------------------------------------------------------ */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+/* out[i][j] = j-th uniform of `stream` for env i in its episodes[i]-th reset */
+void orc_rng_fill(uint64_t seed, int n, const int32_t *episodes, int stream, int count, float *out) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < count; ++j) {
+      uint32_t c[4] = {(uint32_t)i, (uint32_t)episodes[i], (uint32_t)stream, (uint32_t)(j >> 2)};
+      philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+      out[(size_t)i * count + j] = (float)(c[j & 3] >> 8) * (1.0f / 16777216.0f);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* AssetManager.reset_idx (asset_manager.py:51-71) with the half-       */
+/* obstacle resample of EnvManager.reset_idx (env_manager.py:283-295).  */
+/* u [N,K,13] is the draw each env actually uses, sel[N] the bernoulli  */
+/* outcome; bounds [N,3] are the env's (already resampled) bounds.      */
+/* ------------------------------------------------------------------ */
+void orc_reset_assets(int n, int K, const uint8_t *mask, const float *u, const uint8_t *sel, const float *min_ratio,
+                      const float *max_ratio, const float *bounds_min, const float *bounds_max, int num_obstacles,
+                      int num_keep, float *asset_state) {
+  for (int i = 0; i < n; ++i) {
+    if (!mask[i]) continue;
+    int n_full = num_obstacles > num_keep ? num_obstacles : num_keep;
+    int half_o = num_obstacles / 2, half_k = num_keep / 2;
+    int n_half = half_o > half_k ? half_o : half_k;
+    int n_active = sel[i] ? n_half : n_full;
+    for (int a = 0; a < K; ++a) {
+      size_t b = ((size_t)i * K + a) * 13;
+      float r[6];
+      for (int c = 0; c < 6; ++c) r[c] = (max_ratio[b + c] - min_ratio[b + c]) * u[b + c] + min_ratio[b + c];
+      float *st = asset_state + b;
+      for (int c = 0; c < 3; ++c)
+        st[c] = (a >= n_active) ? -1000.0f : bounds_min[3 * i + c] + (bounds_max[3 * i + c] - bounds_min[3 * i + c]) * r[c];
+      quat_from_euler_xyz(r[3], r[4], r[5], st + 3);
+    }
+  }
+}

@@ -41,7 +41,8 @@ class DynHarness:
         self.trunc = torch.zeros(n, dtype=torch.bool, device=dev)
         self.sim_steps = torch.zeros(n, dtype=torch.int32, device=dev)
         self.reset_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.reset_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.reset_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.episode_count = torch.zeros(n, dtype=torch.int32, device=dev)
         self.disturb = None
         self.boxes = None
         self.B = AgxEnvBuffers()
@@ -54,10 +55,12 @@ class DynHarness:
         B.gains, B.wrench_cmd = p(t["gains"]), p(t["wrench"])
         B.crashes, B.truncations, B.sim_steps = p(self.crashes), p(self.trunc), p(self.sim_steps)
         B.reset_mask, B.reset_flag = p(self.reset_mask), p(self.reset_flag)
+        B.flag_parity = 0
+        B.episode_count = p(self.episode_count)
         B.bounds_min, B.bounds_max = p(t["bmin"]), p(t["bmax"])
         B.disturb = p(self.disturb) if self.disturb is not None else None
         B.boxes = p(self.boxes) if self.boxes is not None else None
-        B.num_boxes = 0 if self.boxes is None else self.boxes.shape[0] // 10
+        B.num_boxes = 0 if self.boxes is None else self.boxes.shape[0] // 11
 
     def stream(self):
         return _lib.current_stream(self.dev)
@@ -80,10 +83,12 @@ class DynHarness:
         self.rebind()
 
     def set_boxes(self, boxes):
-        """boxes: [N, K, 10] -> SoA [K*10][N]"""
+        """boxes: [N, K, 10] -> SoA [K*11][N] (11th channel: bounding radius of the half extents)"""
         b = np.asarray(boxes, np.float32)
         n, k, _ = b.shape
-        self.boxes = torch.from_numpy(np.ascontiguousarray(b.reshape(n, k * 10).T)).to(self.dev)
+        rad = (np.sqrt((b[..., 7:10].astype(np.float32) ** 2).sum(-1, dtype=np.float32)) * np.float32(1.000001)).astype(np.float32)
+        b = np.concatenate([b, rad[..., None]], axis=-1)
+        self.boxes = torch.from_numpy(np.ascontiguousarray(b.reshape(n, k * 11).T)).to(self.dev)
         self.rebind()
 
     def substeps(self, action, k):
@@ -128,9 +133,14 @@ class DynHarness:
     def reset_masked(self, mask, u, ranges, min_state, max_state, bounds_cfg, gains_minmax=None):
         dev, n, M = self.dev, self.n, self.pd["num_motors"]
         self.reset_mask.copy_(torch.from_numpy(np.ascontiguousarray(mask, np.uint8)))
-        self.reset_flag.fill_(1 if np.any(mask) else 0)
+        self.reset_flag.zero_()
+        self.reset_flag[0] = 1 if np.any(mask) else 0
         R = AgxResetArgs()
+        R.randomize_gains = int(u.get("u_gains") is not None)
+        R.seed = int(u.get("seed", 0))
         keep = {}
+        if "randomize_gains" in u:
+            R.randomize_gains = int(u["randomize_gains"])
         for name in ("u_bounds_lo", "u_bounds_hi", "u_state", "u_gains", "u_tau_inc", "u_tau_dec", "u_thrust", "u_kT"):
             a = u.get(name)
             if a is None:

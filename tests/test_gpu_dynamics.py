@@ -141,7 +141,7 @@ def test_reward_obs_position(orc):
     trunc = (np.arange(n) % 7 + 498) > 500
     assert np.array_equal(H.trunc.cpu().numpy(), trunc)
     assert np.array_equal(H.reset_mask.cpu().numpy().astype(bool), g["crashes_out"] | trunc)
-    assert int(H.reset_flag.cpu()[0]) == 1
+    assert int(H.reset_flag.cpu()[0]) == 1 and int(H.reset_flag.cpu()[1]) == 0
     assert np.array_equal(H.obs_position(g["target"]), g["obs"])
 
 
@@ -236,3 +236,84 @@ def test_large_batch_properties(orc):
         orc.substep(P, st, act[sub], th, arrs["kT"][sub], arrs["tau_inc"][sub], arrs["tau_dec"][sub], g["Kp"][idx][sub],
                     g["Kv"][idx][sub], g["KR"][idx][sub], g["Kw"][idx][sub])
     assert rel_err(full[sub], st) < 3e-5
+
+
+def test_device_rng_reset_is_the_documented_philox_stream(orc):
+    """Sync-free mode: agx_reset_masked with NULL draw tensors == the same reset fed with the
+    oracle's restatement of Philox4x32-10 keyed by (seed; env, episode, stream)."""
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_octarotor_velocity")
+    pd = golden_params(g)
+    n, M = 96, 8
+    seed = 0x1234ABCD5678EF01
+    rng = np.random.default_rng(9)
+    mask = (rng.random(n) < 0.5).astype(np.uint8)
+    episodes = rng.integers(0, 50, n).astype(np.int32)
+    ranges = dict(tau_inc=(0.01, 0.03), tau_dec=(0.005, 0.005), kT=(1e-5, 2e-5))
+    gmin = np.arange(12, dtype=np.float32) * 0.1 + 1.0
+    gmax = gmin + 0.5
+    bounds_cfg = ([-2.0, -4.0, -3.0], [-1.0, -2.5, -2.0], [9.0, 2.5, 2.0], [10.0, 4.0, 3.0])
+    lo_s = np.array([0.1, 0.15, 0.15, 0, 0, -0.5, 1, -0.2, -0.2, -0.2, -0.2, -0.2, -0.2], np.float32)
+    hi_s = np.array([0.2, 0.85, 0.85, 0, 0, 0.5, 1, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2], np.float32)
+    st0 = g["state"][0][np.arange(n) % 64]
+    results = []
+    for device_rng in (True, False):
+        H = DynHarness(pd, n)
+        H.set(state=st0, thrust=np.ones((n, M), np.float32))
+        H.episode_count.copy_(torch.from_numpy(episodes))
+        if device_rng:
+            u = dict(seed=seed, randomize_gains=1)
+        else:
+            ub = orc.rng_fill(seed, episodes, orc.RNG_BOUNDS, 6)
+            mot = orc.rng_fill(seed, episodes, orc.RNG_MOTOR, 4 * M).reshape(n, M, 4)
+            u = dict(u_bounds_lo=ub[:, :3], u_bounds_hi=ub[:, 3:], u_state=orc.rng_fill(seed, episodes, orc.RNG_STATE, 13),
+                     u_gains=orc.rng_fill(seed, episodes, orc.RNG_GAINS, 12), u_tau_inc=mot[..., 0], u_tau_dec=mot[..., 1],
+                     u_thrust=mot[..., 2], u_kT=mot[..., 3])
+        H.reset_masked(mask, u, ranges, lo_s, hi_s, bounds_cfg, gains_minmax=(gmin, gmax))
+        results.append({k: H.get(k) for k in ("state", "thrust", "tau_inc", "tau_dec", "gains", "bmin", "bmax", "derived")})
+        ep = H.episode_count.cpu().numpy()
+        assert np.array_equal(ep, episodes + mask)
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k]), k
+    m = mask.astype(bool)
+    assert np.all(results[0]["bmin"][m, 0] <= -1.0) and np.all(results[0]["bmin"][m, 0] >= -2.0)
+    assert np.all(results[0]["bmin"][~m] == -1.0)  # untouched envs keep the harness default
+    # uniforms are in [0,1) and not degenerate
+    us = orc.rng_fill(seed, episodes, orc.RNG_STATE, 13)
+    assert us.min() >= 0.0 and us.max() < 1.0 and 0.4 < us.mean() < 0.6
+
+
+def test_fused_epilogue_equals_separate_kernels(orc):
+    """agx_env_step with the position-task epilogue == agx_dynamics_substeps + agx_reward_position."""
+    from aerial_gym_simulator_amd import _lib
+    from gpu_harness import DynHarness, to_soa
+
+    g = load_golden("step_quad_position")
+    pd = golden_params(g)
+    n = g["state"].shape[1]
+    out = []
+    for fused in (False, True):
+        H = DynHarness(pd, n)
+        st = g["state"][0].copy()
+        st[:8, 0] = 9.5  # beyond the 8 m crash radius
+        H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"], state=st, thrust=g["thrust_in"][0])
+        H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+        H.sim_steps.copy_(torch.arange(n, dtype=torch.int32) % 5 + 97)
+        tgt = to_soa(np.zeros((n, 3), np.float32), H.dev)
+        rew = torch.zeros(n, device=H.dev)
+        a = torch.from_numpy(g["action"][0]).to(H.dev)
+        if fused:
+            T = _lib.AgxTaskArgs()
+            T.kind, T.episode_len, T.reset_on_collision = _lib.TASK_POSITION, 100, 1
+            T.target, T.reward = _lib.dptr(tgt), _lib.dptr(rew)
+            _lib.check(H.lib.agx_env_step(H.P, H.B, n, _lib.dptr(a), 2, T, H.stream()))
+        else:
+            _lib.check(H.lib.agx_dynamics_substeps(H.P, H.B, n, _lib.dptr(a), 2, H.stream()))
+            _lib.check(H.lib.agx_reward_position(H.B, n, _lib.dptr(tgt), 100, 1, _lib.dptr(rew), H.stream()))
+        torch.cuda.synchronize()
+        out.append((H.get("state"), rew.cpu().numpy(), H.crashes.cpu().numpy(), H.trunc.cpu().numpy(),
+                    H.reset_mask.cpu().numpy(), H.reset_flag.cpu().numpy()))
+    for a_, b_ in zip(*out):
+        assert np.array_equal(a_, b_)
+    assert out[0][2][:8].all() and out[0][5][0] == 1

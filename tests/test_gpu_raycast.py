@@ -209,13 +209,15 @@ def test_boxes_from_assets_and_collision(orc):
     sc = random_box_scene(n, 100, seed=13)
     K = sc["asset_state"].shape[1]
     lib = _lib.load()
-    boxes = torch.zeros(K * 10, n, device=DEV)
+    boxes = torch.zeros(K * 11, n, device=DEV)
     tas, thalf = T(sc["asset_state"]), T(sc["half"])
     _lib.check(lib.agx_boxes_from_assets(n, K, _lib.dptr(tas), _lib.dptr(thalf), None,
                                          _lib.dptr(boxes), _lib.current_stream(DEV)))
     torch.cuda.synchronize()
     ref_boxes = np.concatenate([sc["asset_state"][..., :7], sc["half"]], axis=-1)
-    assert np.array_equal(to_aos(boxes).reshape(n, K, 10), ref_boxes)
+    got_boxes = to_aos(boxes).reshape(n, K, 11)
+    assert np.array_equal(got_boxes[..., :10], ref_boxes)
+    assert np.all(got_boxes[..., 10] >= np.linalg.norm(sc["half"].astype(np.float64), axis=-1))  # conservative bound
     g = load_golden("step_quad_position")
     pd = golden_params(g)
     H = DynHarness(pd, n)
@@ -231,3 +233,67 @@ def test_boxes_from_assets_and_collision(orc):
     crashes = np.zeros(n, np.uint8)
     orc.collide_sphere_boxes(pd["collision_radius"], H.get("state"), ref_boxes, crashes)
     assert np.array_equal(H.crashes.cpu().numpy(), crashes.astype(bool))
+
+
+@pytest.mark.parametrize("device_rng", [False, True])
+def test_reset_assets_vs_oracle(orc, device_rng):
+    """agx_reset_assets (asset_manager.py:51-71 + env_manager.py:283-295): host-tensor draws and the
+    device generator both reproduce the oracle's restatement bit for bit."""
+    from aerial_gym_simulator_amd import _lib
+    from aerial_gym_simulator_amd._lib import AgxEnvBuffers, AgxResetArgs
+
+    lib = _lib.load()
+    n, K, nk, n_obs = 24, 44, 9, 20
+    rng = np.random.default_rng(17)
+    seed = 0xDEADBEEF12345
+    mask = (rng.random(n) < 0.6).astype(np.uint8)
+    episodes = rng.integers(0, 9, n).astype(np.int32)
+    lo = np.zeros((n, K, 13), np.float32)
+    hi = np.zeros((n, K, 13), np.float32)
+    lo[..., :3], hi[..., :3] = 0.1, 0.9
+    lo[..., 3:6], hi[..., 3:6] = -np.pi, np.pi
+    bounds_cfg = ([-2.0, -4.0, -3.0], [-1.0, -2.5, -2.0], [9.0, 2.5, 2.0], [10.0, 4.0, 3.0])
+    if device_rng:
+        ub = orc.rng_fill(seed, episodes, orc.RNG_BOUNDS, 6)
+        sel = orc.rng_fill(seed, episodes, orc.RNG_ASSET_SEL, 1)[:, 0] < 0.15
+        u = np.stack([orc.rng_fill(seed, episodes, orc.RNG_ASSETS + a, 6) for a in range(K)], axis=1)
+        u = np.concatenate([u, np.zeros((n, K, 7), np.float32)], axis=2)
+        u1 = u2 = u
+    else:
+        ub = rng.random((n, 6)).astype(np.float32)
+        sel = rng.random(n) < 0.3
+        u1, u2 = rng.random((n, K, 13)).astype(np.float32), rng.random((n, K, 13)).astype(np.float32)
+        u = np.where(sel[:, None, None], u2, u1)
+    bmin = (np.array(bounds_cfg[1], np.float32) - np.array(bounds_cfg[0], np.float32)) * ub[:, :3] + np.array(bounds_cfg[0], np.float32)
+    bmax = (np.array(bounds_cfg[3], np.float32) - np.array(bounds_cfg[2], np.float32)) * ub[:, 3:] + np.array(bounds_cfg[2], np.float32)
+    ref = np.zeros((n, K, 13), np.float32)
+    ref[..., 6] = 1
+    init = ref.copy()
+    orc.reset_assets(mask, u, sel.astype(np.uint8), lo, hi, bmin.astype(np.float32), bmax.astype(np.float32), n_obs, nk, ref)
+    B, R = AgxEnvBuffers(), AgxResetArgs()
+    t_mask, t_flag, t_ep = T(mask), torch.tensor([1, 0], dtype=torch.int32, device=DEV), T(episodes)
+    B.reset_mask, B.reset_flag, B.flag_parity, B.episode_count = _lib.dptr(t_mask), _lib.dptr(t_flag), 0, _lib.dptr(t_ep)
+    for i in range(3):
+        R.lower_bound_min[i], R.lower_bound_max[i] = bounds_cfg[0][i], bounds_cfg[1][i]
+        R.upper_bound_min[i], R.upper_bound_max[i] = bounds_cfg[2][i], bounds_cfg[3][i]
+    R.seed = seed
+    keep = []
+    if not device_rng:
+        t_ulo, t_uhi, t_us = T(ub[:, :3]), T(ub[:, 3:]), torch.zeros(n, 13, device=DEV)
+        keep += [t_ulo, t_uhi, t_us]
+        R.u_bounds_lo, R.u_bounds_hi, R.u_state = _lib.dptr(t_ulo), _lib.dptr(t_uhi), _lib.dptr(t_us)
+    t_u1, t_u2, t_sel = T(u1), T(u2), T(sel.astype(np.float32))
+    t_lo, t_hi, t_st = T(lo), T(hi), T(init)
+    _lib.check(lib.agx_reset_assets(B, n, K, R, None if device_rng else _lib.dptr(t_u1), None if device_rng else _lib.dptr(t_u2),
+                                    None if device_rng else _lib.dptr(t_sel), _lib.dptr(t_lo), _lib.dptr(t_hi), n_obs, nk,
+                                    _lib.dptr(t_st), _lib.current_stream(DEV)))
+    torch.cuda.synchronize()
+    got = t_st.cpu().numpy()
+    assert np.array_equal(got[..., :3], ref[..., :3])           # positions: IEEE + - * only -> bit-exact
+    assert np.abs(got[..., 3:7] - ref[..., 3:7]).max() < 3e-7  # quaternions: device sincos vs libm
+    assert np.array_equal(got[..., 7:], ref[..., 7:])
+    m = mask.astype(bool)
+    assert np.array_equal(got[~m], init[~m])
+    parked = got[m][..., 0] == -1000.0
+    assert parked[:, :9].sum() < parked[:, 20:].sum()  # keep-in-env assets stay, the tail is parked
+    assert np.all(parked[:, n_obs:])
