@@ -37,8 +37,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
+    """extra_flags / lib_path: build an experimental variant next to the default library."""
     os.makedirs(LIB_DIR, exist_ok=True)
+    if lib_path is not None:
+        return _build_variant(extra_flags, lib_path, verbose)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "aerial_gym_hip.h"))
@@ -60,6 +63,23 @@ def build_library(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
     return LIB_PATH
+
+
+def _build_variant(extra_flags, lib_path, verbose):
+    hipcc = _hipcc()
+    objs = []
+    tag = os.path.splitext(os.path.basename(lib_path))[0]
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, f"{tag}_{os.path.splitext(src)[0]}.o")
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs, check=True)
+    for o in objs:
+        os.remove(o)
+    return lib_path
 
 
 if __name__ == "__main__":

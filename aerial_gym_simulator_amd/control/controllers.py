@@ -69,6 +69,11 @@ class BaseLeeController(BaseController):  # base_lee_controller.py:23-118
         self._env_binding = None  # (params struct, buffers struct) set by EnvManager
 
     def set_controller_gains(self, K_pos, K_vel, K_rot, K_angvel):
+        if not getattr(self, "_per_env_gains_bound", True):
+            raise RuntimeError(
+                "gains are bound as constants (randomize_params is False): build the env with "
+                "args={'per_env_gains': True} to set per-env gains at run time"
+            )
         self.K_pos_tensor_current[:] = K_pos
         self.K_linvel_tensor_current[:] = K_vel
         self.K_rot_tensor_current[:] = K_rot

@@ -11,6 +11,18 @@
 // No MFMA: there is no dense contraction in this path (the 6xM allocation products are
 // per-env matrix-vector products with constant matrices held in SGPRs).
 #include "agx_common.h"
+// The dynamics path is graded on a 1e-5 state tolerance, not on bits: let the compiler contract
+// a*b+c into v_fma_f32 in the hot device functions (fewer, and more accurate, operations).  The
+// predicates that must be bit-reproducible (collision, reset placement) switch it off again below.
+#ifndef AGX_DYN_CONTRACT
+#define AGX_DYN_CONTRACT 1
+#endif
+#ifndef AGX_DYN_WAVES
+#define AGX_DYN_WAVES 2
+#endif
+#if AGX_DYN_CONTRACT
+#pragma clang fp contract(fast)
+#endif
 #include "agx_device_math.h"
 
 namespace agx {
@@ -61,6 +73,14 @@ AGX_DEV Derived load_derived(const float *__restrict__ d, int n, int i) {
   x.vbody = V3{d[10 * n + i], d[11 * n + i], d[12 * n + i]};
   x.wbody = V3{d[13 * n + i], d[14 * n + i], d[15 * n + i]};
   return x;
+}
+AGX_DEV Gains uniform_gains(const AgxRobotParams &P) {
+  Gains k;
+  k.kp = V3{P.gains_uniform[0], P.gains_uniform[1], P.gains_uniform[2]};
+  k.kv = V3{P.gains_uniform[3], P.gains_uniform[4], P.gains_uniform[5]};
+  k.kr = V3{P.gains_uniform[6], P.gains_uniform[7], P.gains_uniform[8]};
+  k.kw = V3{P.gains_uniform[9], P.gains_uniform[10], P.gains_uniform[11]};
+  return k;
 }
 AGX_DEV Gains load_gains(const float *__restrict__ g, int n, int i) {
   Gains k;
@@ -284,11 +304,20 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
   s.w = w_new;
 }
 
+#pragma clang fp contract(off)  // everything below: one IEEE operation per + - * /
+
 // sphere (robot collision sphere, quad.urdf:16) vs obstacle OBBs; replaces the PhysX
 // contact-force test of env_manager.py:358-362.  The predicate uses only IEEE + - *
-// (bit-reproducible); the culling in front of it is conservative, so the flag is exact.
+// (bit-reproducible, written out here so no contracted helper is inlined); the culling in
+// front of it is conservative, so the flag is exact.
 AGX_DEV bool sphere_hits_box(V3 p, V3 c, Q4 q, V3 h, float r2) {
-  V3 l = quat_rotate_inverse(q, p - c);
+  // quat_rotate_inverse(q, p - c), utils/math.py:340-347
+  V3 v = V3{p.x - c.x, p.y - c.y, p.z - c.z};
+  float s = 2.0f * (q.w * q.w) - 1.0f;
+  V3 cr = V3{q.y * v.z - q.z * v.y, q.z * v.x - q.x * v.z, q.x * v.y - q.y * v.x};
+  float d = q.x * v.x + q.y * v.y + q.z * v.z;
+  V3 l = V3{v.x * s - cr.x * q.w * 2.0f + q.x * d * 2.0f, v.y * s - cr.y * q.w * 2.0f + q.y * d * 2.0f,
+            v.z * s - cr.z * q.w * 2.0f + q.z * d * 2.0f};
   float ex = fabsf(l.x) - h.x, ey = fabsf(l.y) - h.y, ez = fabsf(l.z) - h.z;
   float d2 = 0.0f;
   if (ex > 0.0f) d2 += ex * ex;
@@ -367,9 +396,12 @@ AGX_DEV float reward_navigation(const float *rp, float cpf, V3 pe, V3 ppe, float
 // The env step: k fused physics sub-steps + (optionally) the task's reward / crash /
 // truncation / reset set as an epilogue on the same registers.
 // ---------------------------------------------------------------------------------------
-template <int M, int CTRL>
-__global__ void __launch_bounds__(256) k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in,
-                                                  int k, AgxTaskArgs T) {
+// SINGLE: exactly one sub-step (empty_env, BASELINE config 1/2): straight-line code, no loop-
+// carried copies of the loop invariants.
+template <int M, int CTRL, bool SINGLE>
+__global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n,
+                                                                 const float *__restrict__ actions_in, int k_arg, AgxTaskArgs T) {
+  const int k = SINGLE ? 1 : k_arg;
   extern __shared__ float traj[];  // [k][3][blockDim] sub-step positions (only with obstacles)
   const int tid = threadIdx.x, bd = blockDim.x;
   const int i = blockIdx.x * bd + tid;
@@ -382,11 +414,11 @@ __global__ void __launch_bounds__(256) k_env_step(AgxRobotParams P, AgxEnvBuffer
     for (int j = 0; j < M; ++j) {
       u[j] = B.motor_thrust[j * n + i];
       kT[j] = P.use_rps ? B.motor_kT[j * n + i] : 1.0f;
-      tinc[j] = B.motor_tau_inc[j * n + i];
-      tdec[j] = B.motor_tau_dec[j * n + i];
+      tinc[j] = B.motor_tau_inc ? B.motor_tau_inc[j * n + i] : P.tau_inc_uniform;
+      tdec[j] = B.motor_tau_dec ? B.motor_tau_dec[j * n + i] : P.tau_dec_uniform;
     }
     Gains g{};
-    if (CTRL != AGX_CTRL_NONE) g = load_gains(B.gains, n, i);
+    if (CTRL != AGX_CTRL_NONE) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
     float a_in[AGX_MAX_ACTIONS], a_old[AGX_MAX_ACTIONS];
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
@@ -517,7 +549,7 @@ __global__ void __launch_bounds__(256) k_controller_wrench(AgxRobotParams P, Agx
   if (i >= n) return;
   EnvState s = load_state(B.state, n, i);
   Derived d = load_derived(B.derived, n, i);
-  Gains g = load_gains(B.gains, n, i);
+  Gains g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
   float a[AGX_MAX_ACTIONS];
 #pragma unroll
   for (int c = 0; c < AGX_MAX_ACTIONS; ++c)
@@ -667,18 +699,41 @@ AGX_DEV float u01_from_bits(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777
 
 enum { RNG_BOUNDS = 0, RNG_STATE = 1, RNG_GAINS = 2, RNG_MOTOR = 3, RNG_ASSET_SEL = 4, RNG_ASSETS = 16 };
 
-// j-th uniform of stream `stream` of env `env` in its `episode`-th reset
-AGX_DEV float rng_u01(uint64_t seed, int env, int episode, int stream, int j) {
-  U4 r = philox4x32_10((uint32_t)env, (uint32_t)episode, (uint32_t)stream, (uint32_t)(j >> 2), (uint32_t)seed, (uint32_t)(seed >> 32));
-  int l = j & 3;
-  return u01_from_bits(l == 0 ? r.x : (l == 1 ? r.y : (l == 2 ? r.z : r.w)));
+// Uniforms j = 4*blk .. 4*blk+3 of stream `stream` of env `env` in its `episode`-th reset: one
+// Philox evaluation yields four draws.
+struct F4 {
+  float v[4];
+};
+AGX_DEV F4 rng_block(uint64_t seed, int env, int episode, int stream, int blk) {
+  U4 r = philox4x32_10((uint32_t)env, (uint32_t)episode, (uint32_t)stream, (uint32_t)blk, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return F4{{u01_from_bits(r.x), u01_from_bits(r.y), u01_from_bits(r.z), u01_from_bits(r.w)}};
+}
+// COUNT uniforms of one stream into a register array (COUNT is a compile-time constant)
+template <int COUNT>
+AGX_DEV void rng_fill(uint64_t seed, int env, int episode, int stream, float (&out)[COUNT]) {
+#pragma unroll
+  for (int b = 0; b < (COUNT + 3) / 4; ++b) {
+    F4 f = rng_block(seed, env, episode, stream, b);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (4 * b + l < COUNT) out[4 * b + l] = f.v[l];
+  }
 }
 
 AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin[3], float bmax[3]) {
+  float ub[6];
+  if (R.u_state) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ub[c] = R.u_bounds_lo[(size_t)i * 3 + c];
+      ub[3 + c] = R.u_bounds_hi[(size_t)i * 3 + c];
+    }
+  } else {
+    rng_fill<6>(R.seed, i, episode, RNG_BOUNDS, ub);
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float ulo = R.u_state ? R.u_bounds_lo[(size_t)i * 3 + c] : rng_u01(R.seed, i, episode, RNG_BOUNDS, c);
-    float uhi = R.u_state ? R.u_bounds_hi[(size_t)i * 3 + c] : rng_u01(R.seed, i, episode, RNG_BOUNDS, 3 + c);
+    float ulo = ub[c], uhi = ub[3 + c];
     bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
     bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
   }
@@ -698,35 +753,44 @@ AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int 
     B.bounds_min[c * n + i] = bmin[c];
     B.bounds_max[c * n + i] = bmax[c];
   }
-  float r[13];
+  float r[13], us[13];
+  if (R.u_state) {
 #pragma unroll
-  for (int c = 0; c < 13; ++c) {
-    float u = R.u_state ? R.u_state[(size_t)i * 13 + c] : rng_u01(R.seed, i, ep, RNG_STATE, c);
-    r[c] = (R.max_state[c] - R.min_state[c]) * u + R.min_state[c];
+    for (int c = 0; c < 13; ++c) us[c] = R.u_state[(size_t)i * 13 + c];
+  } else {
+    rng_fill<13>(R.seed, i, ep, RNG_STATE, us);
   }
+#pragma unroll
+  for (int c = 0; c < 13; ++c) r[c] = (R.max_state[c] - R.min_state[c]) * us[c] + R.min_state[c];
   s.p = V3{bmin[0] + (bmax[0] - bmin[0]) * r[0], bmin[1] + (bmax[1] - bmin[1]) * r[1], bmin[2] + (bmax[2] - bmin[2]) * r[2]};
   s.q = quat_from_euler(r[3], r[4], r[5]);
   s.v = V3{r[7], r[8], r[9]};
   s.w = V3{r[10], r[11], r[12]};
   store_state(B.state, n, i, s);
   if (R.randomize_gains) {
+    float ug[12];
+    if (R.u_state) {
 #pragma unroll
-    for (int c = 0; c < 12; ++c) {
-      float u = R.u_state ? R.u_gains[(size_t)i * 12 + c] : rng_u01(R.seed, i, ep, RNG_GAINS, c);
-      B.gains[c * n + i] = (R.gains_max[c] - R.gains_min[c]) * u + R.gains_min[c];
+      for (int c = 0; c < 12; ++c) ug[c] = R.u_gains[(size_t)i * 12 + c];
+    } else {
+      rng_fill<12>(R.seed, i, ep, RNG_GAINS, ug);
     }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) B.gains[c * n + i] = (R.gains_max[c] - R.gains_min[c]) * ug[c] + R.gains_min[c];
   }
 #pragma unroll
   for (int j = 0; j < M; ++j) {
     size_t k = (size_t)i * M + j;
-    float u0 = R.u_state ? R.u_tau_inc[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 0);
-    float u1 = R.u_state ? R.u_tau_dec[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 1);
-    float u2 = R.u_state ? R.u_thrust[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 2);
-    B.motor_tau_inc[j * n + i] = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
-    B.motor_tau_dec[j * n + i] = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
+    F4 um{};
+    if (!R.u_state) um = rng_block(R.seed, i, ep, RNG_MOTOR, j);  // (tau_inc, tau_dec, thrust, kT) of motor j
+    float u0 = R.u_state ? R.u_tau_inc[k] : um.v[0];
+    float u1 = R.u_state ? R.u_tau_dec[k] : um.v[1];
+    float u2 = R.u_state ? R.u_thrust[k] : um.v[2];
+    if (B.motor_tau_inc) B.motor_tau_inc[j * n + i] = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
+    if (B.motor_tau_dec) B.motor_tau_dec[j * n + i] = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
     B.motor_thrust[j * n + i] = (P.max_thrust - P.min_thrust) * u2 + P.min_thrust;
     if (P.use_rps) {
-      float u3 = R.u_state ? R.u_kT[k] : rng_u01(R.seed, i, ep, RNG_MOTOR, 4 * j + 3);
+      float u3 = R.u_state ? R.u_kT[k] : um.v[3];
       B.motor_kT[j * n + i] = (R.kT_max - R.kT_min) * u3 + R.kT_min;
     }
   }
@@ -765,19 +829,22 @@ __global__ void __launch_bounds__(256) k_reset_assets(AgxEnvBuffers B, int n, in
   if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[env] == 0) return;
   const int ep = B.episode_count ? B.episode_count[env] : 0;
   const bool host_rng = u1 != nullptr;
-  float usel = host_rng ? u_sel[env] : rng_u01(R.seed, env, ep, RNG_ASSET_SEL, 0);
+  float usel = host_rng ? u_sel[env] : rng_block(R.seed, env, ep, RNG_ASSET_SEL, 0).v[0];
   // strict mode hands over the bernoulli outcome (0/1); the device generator thresholds at 0.15
   const bool sel = host_rng ? (usel > 0.0f) : (usel < 0.15f);
   const int n_active = sel ? max(num_obstacles / 2, nk / 2) : max(num_obstacles, nk);
   float bmin[3], bmax[3];
   sample_bounds(R, env, ep, bmin, bmax);
   const size_t base = ((size_t)env * K + a) * 13;
-  float ratio[6];
+  float ratio[6], ua[6];
+  if (host_rng) {
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    float u = host_rng ? (sel ? u2[base + c] : u1[base + c]) : rng_u01(R.seed, env, ep, RNG_ASSETS + a, c);
-    ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * u + min_ratio[base + c];
+    for (int c = 0; c < 6; ++c) ua[c] = sel ? u2[base + c] : u1[base + c];
+  } else {
+    rng_fill<6>(R.seed, env, ep, RNG_ASSETS + a, ua);
   }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * ua[c] + min_ratio[base + c];
   float *st = asset_state + base;
   if (a >= n_active) {
     st[0] = -1000.0f; st[1] = -1000.0f; st[2] = -1000.0f;
@@ -840,10 +907,9 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   AGX_REQUIRE(P != nullptr, "null params");
   AGX_REQUIRE(actions_in != nullptr, "null actions");
   AGX_REQUIRE(k >= 0 && k <= AGX_MAX_SUBSTEPS, "k_substeps out of range: %d", k);
-  AGX_REQUIRE(B->state && B->derived && B->actions && B->prev_actions && B->motor_thrust && B->motor_tau_inc &&
-                  B->motor_tau_dec && B->crashes && B->truncations && B->sim_steps,
+  AGX_REQUIRE(B->state && B->derived && B->actions && B->prev_actions && B->motor_thrust && B->crashes && B->truncations &&
+                  B->sim_steps,
               "null env buffer");
-  AGX_REQUIRE(P->controller == AGX_CTRL_NONE || B->gains, "null gains");
   AGX_REQUIRE(!P->use_rps || B->motor_kT, "null motor_kT with use_rps");
   AgxTaskArgs T{};
   if (task) T = *task;
@@ -855,8 +921,14 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   const int block = pick_block(n);
   const size_t lds = B->boxes ? (size_t)k * 3 * block * sizeof(float) : 0;
   AGX_DISPATCH_M(P->num_motors,
-                 AGX_DISPATCH_CTRL(P->controller, hipLaunchKernelGGL((k_env_step<kM, kC>), dim3(blocks_for(n, block)), dim3(block),
-                                                                     lds, (hipStream_t)stream, *P, *B, n, actions_in, k, T)));
+                 AGX_DISPATCH_CTRL(P->controller, {
+                   if (k == 1)
+                     hipLaunchKernelGGL((k_env_step<kM, kC, true>), dim3(blocks_for(n, block)), dim3(block), lds,
+                                        (hipStream_t)stream, *P, *B, n, actions_in, k, T);
+                   else
+                     hipLaunchKernelGGL((k_env_step<kM, kC, false>), dim3(blocks_for(n, block)), dim3(block), lds,
+                                        (hipStream_t)stream, *P, *B, n, actions_in, k, T);
+                 }));
   return check_launch("agx_env_step");
 }
 
@@ -877,7 +949,7 @@ extern "C" int agx_controller_wrench(const AgxRobotParams *P, const AgxEnvBuffer
                                      void *stream) {
   if (int e = check_common(P, B, n)) return e;
   AGX_REQUIRE(P && P->controller != AGX_CTRL_NONE, "controller required");
-  AGX_REQUIRE(action && B->state && B->derived && B->gains && B->wrench_cmd, "null buffer");
+  AGX_REQUIRE(action && B->state && B->derived && B->wrench_cmd, "null buffer");
   const int block = pick_block(n);
   hipLaunchKernelGGL(k_controller_wrench, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *P, *B, n, action);
   return check_launch("agx_controller_wrench");
@@ -961,6 +1033,13 @@ extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffe
   AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, true>), dim3(blocks_for(n, block)), dim3(block), 0,
                                                    (hipStream_t)stream, *P, *B, n, *R, target, obs));
   return check_launch("agx_post_step_position");
+}
+
+extern "C" int agx_position_task_step(const AgxPositionStepPlan *plan, const float *actions_in, void *stream) {
+  AGX_REQUIRE(plan && plan->params && plan->buf && plan->task && plan->reset, "null plan member");
+  plan->buf->flag_parity ^= 1;  // new env step: the flag the previous step's reset kernel cleared
+  if (int e = agx_env_step(plan->params, plan->buf, plan->num_envs, actions_in, plan->k_substeps, plan->task, stream)) return e;
+  return agx_post_step_position(plan->params, plan->buf, plan->num_envs, plan->reset, plan->target, plan->obs, stream);
 }
 
 extern "C" int agx_reset_assets(const AgxEnvBuffers *B, int n, int K, const AgxResetArgs *R, const float *u1, const float *u2,

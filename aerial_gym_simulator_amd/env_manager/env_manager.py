@@ -153,9 +153,24 @@ class EnvManager(BaseManager):
         B.state, B.derived = p(g["robot_state_soa"]), p(g["robot_derived_soa"])
         B.actions, B.prev_actions = p(g["robot_actions_soa"]), p(g["robot_prev_actions_soa"])
         B.motor_thrust, B.motor_kT = p(mm.thrust_soa), p(mm.kT_soa)
-        B.motor_tau_inc, B.motor_tau_dec = p(mm.tau_inc_soa), p(mm.tau_dec_soa)
-        B.gains = p(g.get("controller_gains_soa"))
-        B.wrench_cmd = p(g.get("controller_wrench_soa"))
+        # parameters that are not randomised (min == max in the config) travel as constants
+        # in AgxRobotParams instead of [*, N] buffers: fewer HBM reads per env step
+        ctrl, params = robot.controller, robot.params
+        rng = mm.ranges
+        uniform_tau = rng["tau_inc"][0] == rng["tau_inc"][1] and rng["tau_dec"][0] == rng["tau_dec"][1]
+        uniform_tau = uniform_tau and not self.env_args.get("per_env_motor_constants", False)
+        params.tau_inc_uniform, params.tau_dec_uniform = rng["tau_inc"][0], rng["tau_dec"][0]
+        B.motor_tau_inc = None if uniform_tau else p(mm.tau_inc_soa)
+        B.motor_tau_dec = None if uniform_tau else p(mm.tau_dec_soa)
+        has_gains = g.get("controller_gains_soa") is not None
+        per_env_gains = has_gains and (bool(getattr(ctrl.cfg, "randomize_params", False))
+                                       or bool(self.env_args.get("per_env_gains", False)))
+        if has_gains:
+            for i in range(12):
+                params.gains_uniform[i] = (ctrl.gains_min[i] + ctrl.gains_max[i]) / 2.0
+            ctrl._per_env_gains_bound = per_env_gains
+        B.gains = p(g["controller_gains_soa"]) if per_env_gains else None
+        B.wrench_cmd = None  # only the stand-alone controller call stores the wrench
         B.crashes, B.truncations = p(g["crashes"]), p(g["truncations"])
         B.sim_steps, B.reset_mask, B.reset_flag = p(g["sim_steps"]), p(g["reset_mask"]), p(g["reset_flag"])
         B.flag_parity = self._parity
@@ -229,8 +244,13 @@ class EnvManager(BaseManager):
     def controller_wrench(self, action):
         self._require_device()
         a = action.to(dtype=torch.float32).contiguous()
-        _lib.check(self._lib.agx_controller_wrench(self._params, self._buffers, self.num_envs, _lib.dptr(a), self._stream()),
-                   "agx_controller_wrench")
+        B = self._buffers
+        B.wrench_cmd = _lib.dptr(self.global_tensor_dict["controller_wrench_soa"])
+        try:
+            _lib.check(self._lib.agx_controller_wrench(self._params, B, self.num_envs, _lib.dptr(a), self._stream()),
+                       "agx_controller_wrench")
+        finally:
+            B.wrench_cmd = None
         return self.robot_manager.robot.controller.wrench_command
 
     # ------------------------------------------------------------------ reset

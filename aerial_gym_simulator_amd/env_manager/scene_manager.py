@@ -48,19 +48,33 @@ class SceneManager:
         lo = np.zeros((N, K, 13), np.float32)
         hi = np.zeros((N, K, 13), np.float32)
         sem = np.zeros((N, K), np.int64)
-        rngs = [np.random.default_rng(scene_seed_base + semantic_offset // max(K, 1) + i) for i in range(N)]
+        nk, nf = len(keep_slots), len(free_slots)
+        # per-slot constant tables (slot = one asset instance of one type), gathered per env below
+        slots = keep_slots + free_slots
+        slot_lo = np.array([t.min_state_ratio for t in slots], np.float32)
+        slot_hi = np.array([t.max_state_ratio for t in slots], np.float32)
+        slot_sem = np.array([t.semantic_id for t in slots], np.int64)
+        slot_random = np.array([t.random_box_size_range is not None for t in slots])
+        slot_rlo = np.array([t.random_box_size_range[0] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
+        slot_rhi = np.array([t.random_box_size_range[1] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
+        max_choices = max(len(t.box_sizes) if t.box_sizes else 1 for t in slots)
+        slot_nchoice = np.array([len(t.box_sizes) if t.box_sizes else 1 for t in slots])
+        slot_choices = np.zeros((len(slots), max_choices, 3), np.float32)
+        for j, t in enumerate(slots):
+            if t.box_sizes:
+                slot_choices[j, : len(t.box_sizes)] = t.box_sizes
+        free_idx = list(range(nk, nk + nf))
         for i in range(N):
-            order = list(range(len(free_slots)))
+            rng = np.random.default_rng(scene_seed_base + semantic_offset // max(K, 1) + i)
+            order = free_idx[:]
             random.shuffle(order)  # python `random`, like asset_loader.py:181
-            slots = keep_slots + [free_slots[j] for j in order]
-            for k, t in enumerate(slots):
-                if t.random_box_size_range is not None:
-                    a, b = t.random_box_size_range
-                    size[i, k] = rngs[i].uniform(a, b)
-                else:
-                    size[i, k] = t.box_sizes[int(rngs[i].integers(len(t.box_sizes)))]
-                lo[i, k], hi[i, k] = t.min_state_ratio, t.max_state_ratio
-                sem[i, k] = t.semantic_id
+            perm = np.array(list(range(nk)) + order)
+            u = rng.uniform(0.0, 1.0, (K, 3)).astype(np.float32)
+            pick = (rng.integers(0, 1 << 30, K) % slot_nchoice[perm])
+            fixed = slot_choices[perm, pick]
+            rand = slot_rlo[perm] + (slot_rhi[perm] - slot_rlo[perm]) * u
+            size[i] = np.where(slot_random[perm][:, None], rand, fixed)
+            lo[i], hi[i], sem[i] = slot_lo[perm], slot_hi[perm], slot_sem[perm]
         # env_manager.py:147,212 + warp_env_manager.py:74-95: global counter from 100, one per asset
         counter = 100 + semantic_offset + np.arange(N * K).reshape(N, K)
         sem = np.where(sem < 0, counter, sem)

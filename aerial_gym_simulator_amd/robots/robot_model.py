@@ -139,4 +139,7 @@ def pack_robot_params(d):
     P.linear_damping, P.angular_damping = d["linear_damping"], d["angular_damping"]
     P.max_linear_velocity, P.max_angular_velocity = d["max_linear_velocity"], d["max_angular_velocity"]
     P.collision_radius = d["collision_radius"]
+    _fill(P.gains_uniform, d.get("gains_uniform", [0.0] * 12))
+    P.tau_inc_uniform = d.get("tau_inc_uniform", 0.0)
+    P.tau_dec_uniform = d.get("tau_dec_uniform", 0.0)
     return P

@@ -49,6 +49,7 @@ class PositionSetpointTask(BaseTask):
             "rewards": torch.zeros((N, 1), device=dev),
         }
         self.infos = {}
+        self._plan = None
         self._fuse_with_env()
 
     def _fuse_with_env(self):
@@ -65,6 +66,25 @@ class PositionSetpointTask(BaseTask):
         T.reward = _lib.dptr(self.rewards)
         env.task_args = T
         env.post_obs = (_lib.dptr(self.target_soa), _lib.dptr(self.task_obs["observations"]))
+        self._plan = None
+        e = env.cfg.env
+        simple = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and not env.strict_rng
+                  and not env.robot_manager.robot.cfg.disturbance.enable_disturbance
+                  and e.num_physics_steps_per_env_step_std == 0 and not self.task_config.return_state_before_reset)
+        if simple:
+            # whole task.step() = one host call launching two kernels (agx_position_task_step)
+            import ctypes as C
+
+            plan = _lib.AgxPositionStepPlan()
+            plan.params, plan.buf = C.pointer(env._params), C.pointer(env._buffers)
+            plan.task, plan.reset = C.pointer(T), C.pointer(env._reset_args)
+            plan.target, plan.obs = env.post_obs
+            plan.num_envs, plan.k_substeps = env.num_envs, int(e.num_physics_steps_per_env_step_mean)
+            self._plan = plan
+            self._plan_fn = env._lib.agx_position_task_step
+            self.task_obs["rewards"] = self.rewards
+            self.task_obs["terminations"] = self.terminations
+            self.task_obs["truncations"] = self.truncations
 
     def close(self):
         self.sim_env.delete_env()
@@ -85,7 +105,19 @@ class PositionSetpointTask(BaseTask):
 
     def step(self, actions):
         self.counter += 1
-        self.prev_actions[:] = self.actions
+        if self._plan is not None and actions.dtype is torch.float32 and actions.is_contiguous() and actions.is_cuda:
+            # fast path: same two launches as the general path below, one host call
+            self.prev_actions = self.actions  # previous step's tensor (no copy; the reward does not read it)
+            self.actions = actions
+            env = self.sim_env
+            self._plan.task.contents.episode_len = self.task_config.episode_len_steps
+            rc = self._plan_fn(self._plan, actions.data_ptr(), env._stream())
+            if rc != 0:
+                _lib.check(rc, "agx_position_task_step")
+            env._parity = env._buffers.flag_parity
+            env.step_counter += 1
+            return (self.task_obs, self.rewards, self.terminations, self.truncations, self.infos)
+        self.prev_actions = self.actions
         self.actions = actions
         env = self.sim_env
         if env.task_args is not None:

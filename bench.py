@@ -28,7 +28,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # algorithmic bytes per env per env-step, dynamics-only quad (A=4, M=4, obs 13, k=1)
 #   4*(13 state in + 4 action + 4 thrust in + 13 state out + 4 thrust out) = 152 B   -> agx_dynamics_substeps
 #   4*(13 obs + 1 reward) + 2 flags                                       =  58 B   -> reward / obs kernels
-BYTES_DYNAMICS_KERNEL = 152
+#   fused: k_env_step moves 152 + 4 (reward) + 2 (flags) = 158 B, k_reset_masked<.., obs> the 52 B observation
+BYTES_DYNAMICS_KERNEL = 158
 BYTES_ENV_STEP = 210
 
 
@@ -58,7 +59,7 @@ def make_task(workload, num_envs, device, strict_rng):
         return task_registry.make_task("position_setpoint_task", seed=1, num_envs=num_envs, headless=True)
     cfg = navigation_task_config
     cfg.device = device
-    cfg.args = {"strict_rng": True}
+    cfg.args = {"strict_rng": strict_rng}
     if workload == "lidar":
         cfg.robot_name = "base_octarotor_with_lidar_32x512"
         cfg.controller_name = "octarotor_velocity_control"
@@ -70,9 +71,9 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None):
 
     def one(i):
         obs, rew, term, trunc, _ = task.step(actions[i % len(actions)])
-        if gather_buf is not None:
-            packed = torch.cat([obs["observations"], rew.unsqueeze(1), term.unsqueeze(1).float(), trunc.unsqueeze(1).float()], dim=1)
-            dist.all_gather_into_tensor(gather_buf, packed)
+        if gather_buf is not None:  # one RCCL all-gather of the packed step outputs per env step
+            gather_buf.pack(obs["observations"], rew, term, trunc)
+            gather_buf.gather()
 
     for i in range(warmup):
         one(i)
@@ -91,6 +92,18 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>_pmc_traffic.json, written by profiles/collect_pmc.py); None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get(tag)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def kernel_time_dynamics(task, actions, reps=400):
@@ -113,7 +126,7 @@ def kernel_time_dynamics(task, actions, reps=400):
         start.record()
         s = env._stream()
         for _ in range(reps):
-            lib.agx_dynamics_substeps(P, B, n, ptr, k, s)
+            lib.agx_env_step(P, B, n, ptr, k, env.task_args, s)
         stop.record()
         torch.cuda.synchronize()
         ms = start.elapsed_time(stop) / reps
@@ -175,10 +188,16 @@ def main():
         raise SystemExit("bench.py needs a HIP GPU (no CPU fallback); use gpurun")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(device))  # RCCL over xGMI
+        if world == 1:  # debugging aid: exercise the collective path on a single GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl")  # RCCL over xGMI; rank / world size / master from the env
     n_gpus = max(world, 1)
     task = make_task(args.workload, args.num_envs, device, args.strict_rng)
     task.reset()
@@ -186,9 +205,10 @@ def main():
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
     gather_buf = None
-    if world > 1:
-        obs_dim = task.task_obs["observations"].shape[1]
-        gather_buf = torch.zeros(world * N, obs_dim + 3, device=device)
+    if use_dist:
+        from aerial_gym_simulator_amd.sharding import StepGather
+
+        gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device)
     dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf)
     value = n_gpus * N * args.steps / dt
     out = {
@@ -211,7 +231,7 @@ def main():
             "num_envs_per_gpu": N,
             "num_envs_total": n_gpus * N,
             "sharding": f"envs x{n_gpus}, 1 all_gather/step" if world > 1 else "single GPU",
-            "rng": "strict (reference stream, host sync/step)" if (args.strict_rng or args.workload != "dynamics") else "sync-free (draw every step)",
+            "rng": "strict (reference torch stream, host sync/step)" if args.strict_rng else "sync-free (device Philox4x32-10)",
         },
     }
     if rank == 0 and args.workload == "dynamics":
@@ -219,12 +239,12 @@ def main():
         achieved = BYTES_DYNAMICS_KERNEL * k * N / kt / 1e9
         out["roofline"] = {
             "bound": "hbm",
-            "kernel": "k_dynamics_substeps<4>",
+            "kernel": "k_env_step<4, position> (k sub-steps + reward epilogue)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic("k_env_step_8192"),
             "launch_us": kt * 1e6,
             "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N,
             "note": "8192 envs move 1.2 MB per launch: launch-latency bound, see roofline_at_scale for the same kernel at 2^21 envs",
@@ -249,7 +269,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
         out["cpu_baseline"] = cpu_baseline_dynamics(N)
     if rank == 0 and world == 1 and args.with_depth and args.workload == "dynamics":
-        t2 = make_task("depth", args.num_envs, device, True)
+        t2 = make_task("depth", args.num_envs, device, args.strict_rng)
         t2.reset()
         a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
         s2 = max(args.steps // 20, 20)
@@ -258,7 +278,7 @@ def main():
                              "rays_per_s": N * s2 * 64 * 48 / dt2}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -86,6 +86,10 @@ typedef struct AgxRobotParams {
   float linear_damping, angular_damping;
   float max_linear_velocity, max_angular_velocity;
   float collision_radius;
+  /* values used when the corresponding per-env buffer pointer in AgxEnvBuffers is NULL
+   * (parameter not randomised: min == max in the config) -- saves the HBM reads          */
+  float gains_uniform[12];              /* K_pos K_vel K_rot K_angvel                     */
+  float tau_inc_uniform, tau_dec_uniform;
 } AgxRobotParams;
 
 /* Per-env device buffers of the dynamics path (all SoA, fp32 unless noted).
@@ -99,10 +103,10 @@ typedef struct AgxEnvBuffers {
   float *prev_actions;   /* [A][N] (robot_prev_actions)                               */
   float *motor_thrust;   /* [M][N] MotorModel.current_motor_thrust                    */
   float *motor_kT;       /* [M][N] motor_thrust_constant (use_rps only)               */
-  float *motor_tau_inc;  /* [M][N] motor_time_constants_increasing                    */
-  float *motor_tau_dec;  /* [M][N] motor_time_constants_decreasing                    */
-  float *gains;          /* [12][N] K_pos K_vel K_rot K_angvel (current values)       */
-  float *wrench_cmd;     /* [6][N]  controller output of the LAST sub-step (may be 0)  */
+  float *motor_tau_inc;  /* [M][N] motor_time_constants_increasing, or NULL (uniform)   */
+  float *motor_tau_dec;  /* [M][N] motor_time_constants_decreasing, or NULL (uniform)   */
+  float *gains;          /* [12][N] K_pos K_vel K_rot K_angvel (current values), or NULL (uniform) */
+  float *wrench_cmd;     /* [6][N]  controller output of the LAST sub-step, or NULL     */
   uint8_t *crashes;      /* [N] bool (crashes)                                        */
   uint8_t *truncations;  /* [N] bool (truncations)                                    */
   int32_t *sim_steps;    /* [N]   EnvManager.sim_steps                                */
@@ -234,6 +238,22 @@ int agx_reset_masked(const AgxRobotParams *params, const AgxEnvBuffers *buf, int
  * render between reset and observation).                                                  */
 int agx_post_step_position(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                            const AgxResetArgs *args, const float *target, float *obs, void *stream);
+
+/* One task.step() of the position-setpoint task as a single host call (two launches:
+ * agx_env_step with the position epilogue, then agx_post_step_position).  Toggles
+ * buf->flag_parity first, exactly like the host does once per env step.  `plan` only bundles
+ * arguments the caller would otherwise pass to those two entry points; nothing is retained.   */
+typedef struct AgxPositionStepPlan {
+  const AgxRobotParams *params;
+  AgxEnvBuffers *buf;
+  const AgxTaskArgs *task;
+  const AgxResetArgs *reset;
+  const float *target; /* [3][N] */
+  float *obs;          /* [N][13] */
+  int32_t num_envs;
+  int32_t k_substeps;
+} AgxPositionStepPlan;
+int agx_position_task_step(const AgxPositionStepPlan *plan, const float *actions_in, void *stream);
 
 /* Obstacle pose randomisation of the reset envs: AssetManager.reset_idx
  * (asset_manager.py:51-71) incl. the half-obstacle resample of env_manager.py:283-295.

@@ -1,0 +1,37 @@
+"""Workload for the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE): a handful of launches of
+  - k_update_states at 2^21 envs   (calibration: known 52 B read + 64 B written per env,
+                                     same 4 B/lane coalesced SoA pattern as the step kernel)
+  - k_env_step<4,position> at 8192 and 2^21 envs
+  - (with --nav) one navigation step at 2048 envs for k_raycast
+Run:  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python profiles/pmc_probe.py
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+dev = "cuda:0"
+for n in (8192, 1 << 21):
+    task = bench.make_task("dynamics", n, dev, False)
+    task.reset()
+    a = torch.rand(n, 4, device=dev) * 2 - 1
+    for _ in range(5):
+        task.step(a)
+    env = task.sim_env
+    torch.cuda.synchronize()
+    for _ in range(5):
+        env.update_states()
+    torch.cuda.synchronize()
+    del task
+if "--nav" in sys.argv:
+    t = bench.make_task("depth", 2048, dev, False)
+    t.reset()
+    a = torch.rand(2048, 4, device=dev) * 2 - 1
+    for _ in range(3):
+        t.step(a)
+    torch.cuda.synchronize()
+print("pmc probe done")
