@@ -365,3 +365,18 @@ def reset_assets(mask, u, sel, min_ratio, max_ratio, bounds_min, bounds_max, num
     lib().orc_reset_assets(n, K, _p(np.ascontiguousarray(mask, np.uint8)), _p(_f(u)), _p(np.ascontiguousarray(sel, np.uint8)),
                            _p(_f(min_ratio)), _p(_f(max_ratio)), _p(_f(bounds_min)), _p(_f(bounds_max)), int(num_obstacles),
                            int(num_keep), _p(asset_state))
+
+
+def obs_navigation(state, euler, qveh, vbody, wbody, actions, target, u_vec, u_euler, pixels, obs_dim, gh=8, gw=8):
+    n = state.shape[0]
+    obs = np.zeros((n, obs_dim), np.float32)
+    actions = _f(actions)
+    if pixels is not None:
+        pixels = _f(pixels)
+        ns, H, W = pixels.shape[1], pixels.shape[2], pixels.shape[3]
+    else:
+        ns = H = W = 0
+    lib().orc_obs_navigation(n, _p(_f(state)), _p(_f(euler)), _p(_f(qveh)), _p(_f(vbody)), _p(_f(wbody)), _p(actions),
+                             actions.shape[1], _p(_f(target)), _p(_f(u_vec)), _p(_f(u_euler)), _p(pixels), ns, H, W, gh, gw,
+                             obs_dim, _p(obs))
+    return obs

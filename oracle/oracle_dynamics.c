@@ -764,3 +764,43 @@ void orc_reset_assets(int n, int K, const uint8_t *mask, const float *u, const u
     }
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* Navigation task observation, navigation_task.py:369-393.            */
+/* u_vec / u_euler [N,3] are the two rand_like draws.  Slots 17.. hold  */
+/* the gh x gw min-pooled depth image of sensor 0 (stands in for the    */
+/* VAE latents, which are outside the simulation path).                 */
+/* ------------------------------------------------------------------ */
+void orc_obs_navigation(int n, const float *state, const float *euler, const float *qveh, const float *vbody,
+                        const float *wbody, const float *actions, int num_actions, const float *target,
+                        const float *u_vec, const float *u_euler, const float *pixels, int ns, int H, int W, int gh,
+                        int gw, int obs_dim, float *obs) {
+  for (int i = 0; i < n; ++i) {
+    const float *p = state + 13 * i;
+    float d[3] = {target[3 * i] - p[0], target[3 * i + 1] - p[1], target[3 * i + 2] - p[2]};
+    float v[3];
+    quat_rotate_inverse(qveh + 4 * i, d, v);
+    float dist = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float *o = obs + (size_t)i * obs_dim;
+    for (int k = 0; k < 3; ++k) o[k] = (v[k] + 0.1f * 2.0f * u_vec[3 * i + k]) / dist;
+    o[3] = dist;
+    o[4] = ssa(euler[3 * i]) + 0.1f * (u_euler[3 * i] - 0.5f);
+    o[5] = ssa(euler[3 * i + 1]) + 0.1f * (u_euler[3 * i + 1] - 0.5f);
+    o[6] = 0.0f;
+    for (int k = 0; k < 3; ++k) { o[7 + k] = vbody[3 * i + k]; o[10 + k] = wbody[3 * i + k]; }
+    for (int k = 0; k < 4; ++k) o[13 + k] = actions[num_actions * i + k];
+    if (pixels) {
+      const float *img = pixels + (size_t)i * ns * H * W;
+      int ch = (H + gh - 1) / gh, cw = (W + gw - 1) / gw;
+      for (int cy = 0; cy < gh; ++cy)
+        for (int cx = 0; cx < gw; ++cx) {
+          float m = INFINITY;
+          for (int y = cy * ch; y < (cy + 1) * ch && y < H; ++y)
+            for (int x = cx * cw; x < (cx + 1) * cw && x < W; ++x)
+              if (img[y * W + x] < m) m = img[y * W + x];
+          int cell = cy * gw + cx;
+          if (17 + cell < obs_dim) o[17 + cell] = m;
+        }
+    }
+  }
+}

@@ -1,0 +1,170 @@
+"""GPU: BASELINE config 3 end to end at small N -- navigation task (10 sub-steps, 100 boxes + 6 walls,
+64x48 depth + segmentation camera) through the Task API in the sync-free mode, checked step by step
+against the CPU oracle (teacher-forced on the product's pre-step buffers, so every comparison is a
+one-step prediction): dynamics, collision flags, reward, truncation, reset set, obstacle reset (device
+Philox stream), scene transform, ray-cast image + segmentation, post-processing, observation."""
+import numpy as np
+import pytest
+import torch
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class RecordingSource:
+    """TorchRandomSource that remembers every draw (by tag) so the oracle can replay it."""
+
+    def __init__(self, device, seed):
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.log = {}
+
+    def _rec(self, tag, t):
+        self.log.setdefault(tag, []).append(t.detach().clone())
+        return t
+
+    def rand(self, *shape, tag=""):
+        return self._rec(tag, torch.rand(*shape, device=self.device, generator=self.gen))
+
+    def rand_into(self, out, tag=""):
+        out.uniform_(0.0, 1.0, generator=self.gen)
+        self._rec(tag, out)
+        return out
+
+    def bernoulli(self, p, *shape, tag=""):
+        return self._rec(tag, torch.bernoulli(torch.full(shape, float(p), device=self.device), generator=self.gen))
+
+    def normal_into(self, out, tag=""):
+        out.normal_(0.0, 1.0, generator=self.gen)
+        self._rec(tag, out)
+        return out
+
+    def gauss(self, mean, std):
+        return mean
+
+    def last(self, tag):
+        return self.log[tag][-1].cpu().numpy()
+
+
+def npy(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def test_navigation_task_step_by_step_vs_oracle(orc):
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    n, T, seed = 12, 45, 0xC0FFEE1234
+    rs = RecordingSource(DEV, 77)
+    cfg.device, cfg.episode_len_steps = DEV, 12
+    cfg.robot_name, cfg.controller_name = "base_quadrotor_with_camera_64x48", "lee_velocity_control"
+    cfg.args = {"strict_rng": False, "random_source": rs, "rng_seed": seed}
+    try:
+        task = task_registry.make_task("navigation_task", seed=3, num_envs=n, headless=True)
+        env = task.sim_env
+        g, sc = env.global_tensor_dict, env.scene
+        sensor = env.robot_manager.warp_sensor
+        K, nk = sc.num_assets, env.keep_in_env
+        P = orc.make_params(env.robot_manager.robot.params_dict)
+        pd = env.robot_manager.robot.params_dict
+        ctrl = env.robot_manager.robot.controller
+        gains = [np.tile(((np.array(ctrl.gains_min) + np.array(ctrl.gains_max)) / 2)[3 * k:3 * k + 3].astype(np.float32), (n, 1))
+                 for k in range(4)]
+        mm = env.robot_manager.robot.control_allocator.motor_model
+        tri_local, tri_asset, tri_seg, half = npy(sc.tri_local), npy(sc.tri_asset), npy(sc.tri_seg), npy(sc.half_extents)
+        lo_r, hi_r = npy(g["asset_min_state_ratio"]), npy(g["asset_max_state_ratio"])
+        e = env.cfg.env
+        bcfg = [np.array(x, np.float32) for x in (e.lower_bound_min, e.lower_bound_max, e.upper_bound_min, e.upper_bound_max)]
+        kinv, cx, cy = orc.camera_kinv(64, 48, 87.0)
+        frame = orc.quat_from_euler(np.deg2rad(np.array([[-90.0, 0.0, -90.0]], np.float32)))[0]
+        rp = np.array([cfg.reward_parameters[k] for k in cfg.REWARD_PARAMETER_ORDER], np.float32)
+        robot = env.robot_manager.robot
+
+        def snapshot():
+            return dict(state=npy(g["robot_state_tensor"]), thrust=npy(mm.current_motor_thrust), kT=npy(mm.motor_thrust_constant),
+                        tau_inc=npy(mm.motor_time_constants_increasing), tau_dec=npy(mm.motor_time_constants_decreasing),
+                        asset=npy(sc.asset_state), target=npy(task.target_position), pos_err=npy(task.pos_error_vehicle_frame),
+                        actions=npy(g["robot_actions"]), steps=npy(g["sim_steps"]), ep=npy(g["episode_count"]),
+                        bmin=npy(g["env_bounds_min"]), bmax=npy(g["env_bounds_max"]), tri_world=npy(sc.tri_world),
+                        euler=npy(g["robot_euler_angles"]), qveh=npy(g["robot_vehicle_orientation"]),
+                        vbody=npy(g["robot_body_linvel"]), wbody=npy(g["robot_body_angvel"]))
+
+        def boxes_of(asset):
+            return np.ascontiguousarray(np.concatenate([asset[..., :7], half], axis=-1))
+
+        task.reset()
+        torch.cuda.synchronize()
+        agen = torch.Generator(device=DEV).manual_seed(5)
+        n_resets = n_crashes = 0
+        for t in range(T):
+            pre = snapshot()
+            action = torch.rand(n, 4, device=DEV, generator=agen) * 2 - 1
+            obs, rew, term, trunc, info = task.step(action)
+            torch.cuda.synchronize()
+            post = snapshot()
+            # ---------------- oracle: one env step from the product's pre-step buffers
+            a_tr = npy(cfg.action_transformation_function(action))
+            st, th = pre["state"].copy(), pre["thrust"].copy()
+            crashes = np.zeros(n, np.uint8)
+            boxes = boxes_of(pre["asset"])
+            for _ in range(10):
+                o = orc.substep(P, st, a_tr, th, pre["kT"], pre["tau_inc"], pre["tau_dec"], *gains)
+                orc.collide_sphere_boxes(pd["collision_radius"], st, boxes, crashes)
+            pe, ppe = pre["pos_err"].copy(), np.zeros((n, 3), np.float32)
+            r_ref = orc.reward_navigation(st, o.qveh, pre["target"], a_tr, a_tr, task.curriculum_progress_fraction, rp, pe, ppe, crashes)
+            trunc_ref = (pre["steps"] + 1) > cfg.episode_len_steps
+            reset_ref = (crashes > 0) | trunc_ref
+            assert np.array_equal(npy(term), crashes.astype(bool)), t                     # crash flags: bit-exact
+            assert np.array_equal(npy(trunc), trunc_ref), t
+            assert np.array_equal(npy(g["reset_mask"]).astype(bool), reset_ref), t
+            assert rel_err(npy(rew), r_ref) < 2e-5, t
+            keep = ~reset_ref
+            assert rel_err(post["state"][keep], st[keep]) < 5e-5, t                          # 10 fused sub-steps
+            assert rel_err(post["thrust"][keep], th[keep]) < 5e-5, t
+            n_resets += int(reset_ref.sum())
+            n_crashes += int(crashes.sum())
+            # ---------------- reset of the flagged envs (device Philox streams)
+            asset_ref, bmin_ref, bmax_ref = pre["asset"].copy(), pre["bmin"].copy(), pre["bmax"].copy()
+            if reset_ref.any():
+                ub = orc.rng_fill(seed, pre["ep"], orc.RNG_BOUNDS, 6)
+                nb_min = (bcfg[1] - bcfg[0]) * ub[:, :3] + bcfg[0]
+                nb_max = (bcfg[3] - bcfg[2]) * ub[:, 3:] + bcfg[2]
+                bmin_ref[reset_ref], bmax_ref[reset_ref] = nb_min[reset_ref], nb_max[reset_ref]
+                sel = orc.rng_fill(seed, pre["ep"], orc.RNG_ASSET_SEL, 1)[:, 0] < 0.15
+                u = np.stack([orc.rng_fill(seed, pre["ep"], orc.RNG_ASSETS + a, 6) for a in range(K)], axis=1)
+                u = np.concatenate([u, np.zeros((n, K, 7), np.float32)], axis=2)
+                orc.reset_assets(reset_ref.astype(np.uint8), u, sel.astype(np.uint8), lo_r, hi_r, nb_min.astype(np.float32),
+                                 nb_max.astype(np.float32), int(g["num_obstacles_in_env"]), nk, asset_ref)
+                us = orc.rng_fill(seed, pre["ep"], orc.RNG_STATE, 13)
+                st_reset = post["state"].copy()
+                orc.reset_robot_state(reset_ref.astype(np.uint8), us, np.array(robot.min_init_state, np.float32),
+                                      np.array(robot.max_init_state, np.float32), nb_min.astype(np.float32), nb_max.astype(np.float32),
+                                      st_reset)
+                assert rel_err(post["state"][reset_ref], st_reset[reset_ref]) < 1e-6, t
+                assert np.array_equal(post["ep"], pre["ep"] + reset_ref), t
+                assert np.all(post["steps"][reset_ref] == 0)
+            assert np.array_equal(post["bmin"], bmin_ref) and np.array_equal(post["bmax"], bmax_ref), t
+            assert np.array_equal(post["asset"][..., :3], asset_ref[..., :3]), t            # obstacle positions: bit-exact
+            assert np.abs(post["asset"][..., 3:7] - asset_ref[..., 3:7]).max() < 3e-7, t
+            # ---------------- scene + sensor on the product's post-reset buffers (bit-exact path)
+            tris_ref = orc.scene_transform(tri_local, tri_asset, post["asset"])
+            assert np.array_equal(post["tri_world"], tris_ref), t
+            lpos, lquat = npy(sensor.sensor_local_position), npy(sensor.sensor_local_orientation)
+            spos, squat = orc.sensor_pose(post["state"], lpos, lquat, frame)
+            assert np.array_equal(npy(sensor.sensor_position), spos) and np.array_equal(npy(sensor.sensor_orientation), squat), t
+            px_ref, seg_ref = orc.raycast_camera(64, 48, kinv, 10.0, cx, cy, "depth", spos, squat, tris_ref, tri_seg)
+            px_ref = orc.sensor_postprocess(px_ref, 0.2, 10.0, 10.0, -10.0, True)
+            assert np.array_equal(npy(g["segmentation_pixels"]), seg_ref), t                # segmentation ids: bit-exact
+            assert np.array_equal(npy(g["depth_range_pixels"]), px_ref), t                  # normalised depth: bit-exact
+            # ---------------- observation (fresh derived tensors of reset steps come from update_states)
+            obs_ref = orc.obs_navigation(post["state"], post["euler"], post["qveh"], post["vbody"], post["wbody"], post["actions"],
+                                         post["target"], rs.last("obs_vec"), rs.last("obs_euler"), px_ref, cfg.observation_space_dim)
+            assert rel_err(npy(obs["observations"]), obs_ref) < 1e-5, t
+            if reset_ref.any():  # the reference refreshes EVERY env's derived tensors when any env resets
+                eu, qv, vv, vb, wb = orc.update_states(post["state"])
+                assert rel_err(post["vbody"], vb) < 1e-5 and rel_err(post["qveh"], qv) < 1e-5, t
+        assert n_resets >= 2 * n and n_crashes >= 1, (n_resets, n_crashes)  # the run exercised truncations and collisions
+    finally:
+        cfg.args, cfg.episode_len_steps = {}, 100
