@@ -87,6 +87,9 @@ class AgxEnvBuffers(C.Structure):
         ("bounds_max", C.c_void_p),
         ("disturb", C.c_void_p),
         ("disturb_max", C.c_float * 6),
+        ("disturb_prob", C.c_float),
+        ("step_counter", C.c_int32),
+        ("rng_seed", C.c_uint64),
         ("boxes", C.c_void_p),
         ("num_boxes", C.c_int32),
     ]

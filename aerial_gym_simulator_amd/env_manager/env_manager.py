@@ -179,6 +179,9 @@ class EnvManager(BaseManager):
         B.disturb = None
         for i, v in enumerate(robot.max_force_and_torque_disturbance):
             B.disturb_max[i] = v
+        B.disturb_prob = 0.0
+        B.rng_seed = self.rng_seed
+        B.step_counter = 0
         B.boxes = p(self.scene.boxes_soa) if self.scene.num_assets > 0 else None
         B.num_boxes = self.scene.num_assets
         self._buffers = B
@@ -339,6 +342,11 @@ class EnvManager(BaseManager):
         robot = self.robot_manager.robot
         if not robot.cfg.disturbance.enable_disturbance or k == 0:
             self._buffers.disturb = None
+            return
+        if not self.strict_rng:  # drawn inside the kernel (Philox keyed by env, step, sub-step)
+            self._buffers.disturb = None
+            self._buffers.disturb_prob = float(robot.cfg.disturbance.prob_apply_disturbance)
+            self._buffers.step_counter = self.step_counter & 0x7FFFFFFF
             return
         N, rs = self.num_envs, self.random_source
         if self._disturb_buf is None or self._disturb_buf.shape[0] < k:

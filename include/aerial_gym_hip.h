@@ -121,8 +121,13 @@ typedef struct AgxEnvBuffers {
   float *bounds_min;     /* [3][N] (env_bounds_min)                                    */
   float *bounds_max;     /* [3][N] (env_bounds_max)                                    */
   /* optional inputs */
-  const float *disturb;  /* [k][7][N] per sub-step (bernoulli, 6 x U01) or NULL       */
+  const float *disturb;  /* [k][7][N] per sub-step (bernoulli outcome, 6 x U01), or NULL:
+                            with disturb_prob > 0 the kernel then draws them itself (Philox,
+                            counter = (env, step_counter, sub-step))                        */
   float disturb_max[6];
+  float disturb_prob;    /* cfg.disturbance.prob_apply_disturbance, 0 = disabled           */
+  int32_t step_counter;  /* env steps taken so far (host increments once per env step)      */
+  uint64_t rng_seed;     /* key of the device generator                                     */
   const float *boxes;    /* [K][11][N] obstacle OBBs centre(3) quat(4) half(3) bounding radius(1), or NULL */
   int32_t num_boxes;
 } AgxEnvBuffers;

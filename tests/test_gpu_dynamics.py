@@ -317,3 +317,37 @@ def test_fused_epilogue_equals_separate_kernels(orc):
     for a_, b_ in zip(*out):
         assert np.array_equal(a_, b_)
     assert out[0][2][:8].all() and out[0][5][0] == 1
+
+
+def test_device_disturbance_stream(orc):
+    """apply_disturbance with in-kernel draws == oracle sub-steps fed with the restated Philox stream."""
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_octarotor_velocity")
+    pd = golden_params(g)
+    n, K, seed, step, prob = g["state"].shape[1], 4, 0xABCDEF0123, 321, 0.3
+    P = orc.make_params(pd)
+    H = DynHarness(pd, n)
+    H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"], state=g["state"][0], thrust=g["thrust_in"][0])
+    H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+    for i in range(6):
+        H.B.disturb_max[i] = float(g["disturb_max"][i])
+    H.B.disturb_prob, H.B.step_counter, H.B.rng_seed = prob, step, seed
+    st, th = g["state"][0].copy(), g["thrust_in"][0].copy()
+    occ_total = 0
+    for s in range(K):
+        u = orc.rng_fill(seed, np.full(n, step, np.int32), (1 << 20) + s, 7)
+        d = u.copy()
+        d[:, 0] = (u[:, 0] < prob).astype(np.float32)
+        occ_total += int(d[:, 0].sum())
+        orc.substep(P, st, g["action"][0], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"], g["Kw"],
+                    disturb=d, disturb_max=g["disturb_max"])
+    H.substeps(g["action"][0], K)
+    assert occ_total > 10
+    assert rel_err(H.get("state"), st) < 3e-5
+    # and it really was applied: without disturbance the result differs
+    H2 = DynHarness(pd, n)
+    H2.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"], state=g["state"][0], thrust=g["thrust_in"][0])
+    H2.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+    H2.substeps(g["action"][0], K)
+    assert rel_err(H2.get("state"), st) > 1e-4

@@ -118,3 +118,31 @@ def test_sync_free_mode_runs_and_resets():
         assert float(p.abs().max()) < 20.0
     finally:
         cfg.episode_len_steps = 500
+
+
+def test_config4_octarotor_lidar_task_runs():
+    """BASELINE config 4 at small N: base_octarotor + octarotor_velocity_control + 32x512 LiDAR
+    (range + segmentation), 10 sub-steps, disturbances on, sync-free."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    old = (cfg.robot_name, cfg.controller_name, cfg.args)
+    cfg.device, cfg.robot_name, cfg.controller_name, cfg.args = DEV, "base_octarotor_with_lidar_32x512", "octarotor_velocity_control", {}
+    try:
+        n = 64
+        task = task_registry.make_task("navigation_task", seed=2, num_envs=n, headless=True)
+        task.reset()
+        a = torch.rand(n, 4, device=DEV) * 2 - 1
+        for _ in range(30):
+            obs, rew, term, trunc, _ = task.step(a)
+        px, seg = task.obs_dict["depth_range_pixels"], task.obs_dict["segmentation_pixels"]
+        assert px.shape == (n, 1, 32, 512) and seg.shape == (n, 1, 32, 512)
+        assert torch.isfinite(px).all() and torch.isfinite(obs["observations"]).all() and torch.isfinite(rew).all()
+        assert float(px.max()) <= 1.0 and float(px.min()) >= -1.0
+        hit = (seg != -2).float().mean()
+        assert hit > 0.9  # the walls enclose the env
+        assert int(task.sim_env.global_tensor_dict["episode_count"].sum()) >= n  # resets happened
+    finally:
+        cfg.robot_name, cfg.controller_name, cfg.args = old
+        cfg.robot_name, cfg.controller_name = "base_quadrotor_with_camera_64x48", "lee_velocity_control"
