@@ -3,9 +3,11 @@
 // Replaces the Warp kernels of aerial_gym/sensors/warp/warp_kernels/{warp_camera_kernels,
 // warp_lidar_kernels}.py and wp.mesh_query_ray.  Design (CDNA4-first, not a Warp port):
 //
-//   * one workgroup per (env, sensor); the env's BVH nodes (64 B each, both child boxes
-//     inline) and triangles (36 B each) are staged ONCE into LDS (<= 160 KiB / CU) with
-//     16-byte coalesced loads, so HBM sees each scene exactly once per frame;
+//   * one workgroup per (env, sensor); the env's BVH nodes (64 B each, both child boxes inline)
+//     and triangles (36 B each) are read through wave-uniform addresses, i.e. one L2 request
+//     (scalar load) per visited node for the whole packet; the env's tree (127 KB) stays in the
+//     XCD's L2 for the frame, so HBM sees each scene once per frame.  (An LDS-staged variant of
+//     the same traversal is kept behind AGX_RAY_USE_LDS; it is slower here, see below.)
 //   * a wavefront (64 lanes) owns an 8x8 pixel tile and walks the tree as ONE packet:
 //     every node fetch is a wave-uniform LDS broadcast, lanes vote with __ballot on which
 //     children to visit and in which order (majority near-first), and the packet's
@@ -26,7 +28,17 @@
 
 namespace agx {
 
-constexpr int kRayThreads = 512;  // 8 waves per workgroup
+// Measured on MI355X (profiles/r01_raycast_variants.txt, config 3, 8192 envs): traversing straight from
+// L2 with wave-uniform (scalar) node loads at full occupancy beats staging the tree in LDS, because
+// the 127 KB LDS footprint caps a CU at one workgroup:   LDS/512 thr 4.74 ms, LDS/1024 thr 3.39 ms,
+// L2/512 thr 2.62 ms, L2/256 thr 2.54 ms per env step.  The LDS path is kept for A/B runs.
+#ifndef AGX_RAY_THREADS
+#define AGX_RAY_THREADS 256
+#endif
+#ifndef AGX_RAY_USE_LDS
+#define AGX_RAY_USE_LDS 0
+#endif
+constexpr int kRayThreads = AGX_RAY_THREADS;  // waves per workgroup = kRayThreads / 64
 constexpr int kStackDepth = 64;
 constexpr float kNoHitRay = 1000.0f;  // warp_camera_kernels.py:3
 constexpr int kNoHitSeg = -2;         // warp_camera_kernels.py:4
@@ -51,6 +63,13 @@ AGX_DEV float diff_product(float a, float b, float c, float d) {
   float error = fmaf(-c, d, cd);
   return diff + error;
 }
+
+#ifdef AGX_RAY_STATS  // experimental builds only (profiles/raystats.py): traversal counters
+__device__ unsigned long long g_ray_stats[8];
+#define AGX_STAT(i, v) if ((threadIdx.x & 63) == 0) atomicAdd(&g_ray_stats[i], (unsigned long long)(v))
+#else
+#define AGX_STAT(i, v)
+#endif
 
 struct Ray {
   V3 o, d, rcp;
@@ -154,7 +173,9 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
   int node = 0;
   int stack = 0;
   const int lane = threadIdx.x & 63;
+  AGX_STAT(0, 1);  // packets
   while (true) {
+    AGX_STAT(1, 1);  // node visits
     const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 16);
     float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
@@ -163,11 +184,11 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
     unsigned long long ml = __ballot(hl), mr = __ballot(hr);
     if (cl < 0) {
-      if (ml) test_leaf(r, tris, ~cl, hl);
+      if (ml) { test_leaf(r, tris, ~cl, hl); AGX_STAT(2, 1); AGX_STAT(3, __popcll(ml)); }
       ml = 0;
     }
     if (cr < 0) {
-      if (mr) test_leaf(r, tris, ~cr, hr);
+      if (mr) { test_leaf(r, tris, ~cr, hr); AGX_STAT(2, 1); AGX_STAT(3, __popcll(mr)); }
       mr = 0;
     }
     int next = -1;
@@ -363,7 +384,7 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
     attr_set = true;
   }
   dim3 grid(n, ns);
-  if (lds <= 160 * 1024) {
+  if (AGX_RAY_USE_LDS && lds <= 160 * 1024) {
     hipLaunchKernelGGL((k_raycast<LIDAR, true>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors, pos,
                        quat, tri_world, tri_seg, nodes, nt, pixels, seg);
   } else {  // scene does not fit LDS: traverse from L2 / HBM
@@ -376,6 +397,17 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
 }  // namespace agx
 
 using namespace agx;
+
+#ifdef AGX_RAY_STATS
+extern "C" int agx_debug_ray_stats(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(g_ray_stats));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int agx_sensor_pose(const AgxEnvBuffers *B, int n, int ns, const float *local_pos, const float *local_quat,
                                const float *frame_quat, float *pos, float *quat, void *stream) {
