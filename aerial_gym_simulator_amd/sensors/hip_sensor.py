@@ -114,29 +114,44 @@ class HipSensor:
         self.sensor_local_orientation[:] = torch.where(mask, quat, self.sensor_local_orientation)
 
     def update(self):
+        """WarpSensor.update (warp_sensor.py:177-200): pose -> ray-cast -> noise / range limits / normalise."""
+        self.compose_pose()
+        self.raycast()
+        self.postprocess()
+
+    def compose_pose(self):
         env = self.g["env_manager"]
-        lib, stream, p, cfg, sc = env._lib, env._stream(), _lib.dptr, self.cfg, self.scene
-        N, S = self.num_envs, self.num_sensors
+        p = _lib.dptr
         _lib.check(
-            lib.agx_sensor_pose(env._buffers, N, S, p(self.sensor_local_position), p(self.sensor_local_orientation),
-                                self.frame_quat, p(self.sensor_position), p(self.sensor_orientation), stream),
+            env._lib.agx_sensor_pose(env._buffers, self.num_envs, self.num_sensors, p(self.sensor_local_position),
+                                     p(self.sensor_local_orientation), self.frame_quat, p(self.sensor_position),
+                                     p(self.sensor_orientation), env._stream()),
             "agx_sensor_pose",
         )
+
+    def raycast(self, stream=None):
+        env = self.g["env_manager"]
+        lib, p, cfg, sc = env._lib, _lib.dptr, self.cfg, self.scene
+        stream = stream if stream is not None else env._stream()
+        N, S = self.num_envs, self.num_sensors
         seg = p(self.segmentation_pixels) if self.segmentation_pixels is not None else None
         if self.is_lidar:
-            _lib.check(
+            return _lib.check(
                 lib.agx_raycast_lidar(N, S, cfg.width, cfg.height, p(self.ray_vectors), float(cfg.max_range), self.mode,
                                       p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
                                       p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
                 "agx_raycast_lidar",
             )
-        else:
-            _lib.check(
-                lib.agx_raycast_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), self.c_x, self.c_y,
-                                       self.mode, p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world),
-                                       p(sc.tri_seg), p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
-                "agx_raycast_camera",
-            )
+        return _lib.check(
+            lib.agx_raycast_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), self.c_x, self.c_y, self.mode,
+                                   p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
+                                   p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
+            "agx_raycast_camera",
+        )
+
+    def postprocess(self):
+        env = self.g["env_manager"]
+        lib, p, cfg = env._lib, _lib.dptr, self.cfg
         if cfg.return_pointcloud:
             self._postprocess_pointcloud()
             return
@@ -151,7 +166,7 @@ class HipSensor:
                                        float(getattr(sn, "std_b", 0.0)), float(getattr(sn, "std_c", 0.0)),
                                        float(getattr(sn, "mean_offset", 0.0)), float(sn.pixel_dropout_prob),
                                        float(cfg.min_range), float(cfg.max_range), float(cfg.far_out_of_range_value),
-                                       float(cfg.near_out_of_range_value), int(bool(cfg.normalize_range)), stream),
+                                       float(cfg.near_out_of_range_value), int(bool(cfg.normalize_range)), env._stream()),
             "agx_sensor_postprocess",
         )
 

@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
     ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar"])
-    ap.add_argument("--with-depth", action="store_true", help="also time the +depth config (extra keys)")
+    ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
     return ap.parse_args()
@@ -132,6 +132,37 @@ def kernel_time_dynamics(task, actions, reps=400):
         ms = start.elapsed_time(stop) / reps
         best = ms if best is None else min(best, ms)
     return best * 1e-3, k
+
+
+def kernel_time_raycast(task, reps=20):
+    """Average duration of one ray-cast launch (all envs, one frame), HIP events on the launch stream."""
+    env = task.sim_env
+    sensor = env.robot_manager.warp_sensor
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        start.record()
+        s = env._stream()
+        for _ in range(reps):
+            sensor.raycast(s)
+        stop.record()
+        torch.cuda.synchronize()
+        ms = start.elapsed_time(stop) / reps
+        best = ms if best is None else min(best, ms)
+    return best * 1e-3
+
+
+def raycast_bytes_per_env(task):
+    """scene read once (12 V + 12 T + 4 V + 32 (2T - 1)) + pose 28 S + image 4 H W S (+ 4 H W S seg)."""
+    sc = task.sim_env.scene
+    cfg = task.sim_env.robot_manager.warp_sensor.cfg
+    K, T = sc.num_assets, sc.num_tris
+    V = 8 * K
+    scene = 12 * V + 12 * T + 4 * V + 32 * (2 * T - 1)
+    S, H, W = cfg.num_sensors, cfg.height, cfg.width
+    img = 4 * H * W * S * (2 if cfg.segmentation_camera else 1) * (3 if cfg.return_pointcloud else 1)
+    return scene + 28 * S + img
 
 
 def cpu_baseline_dynamics(num_envs, budget_s=12.0):
@@ -249,6 +280,17 @@ def main():
             "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N,
             "note": "8192 envs move 1.2 MB per launch: launch-latency bound, see roofline_at_scale for the same kernel at 2^21 envs",
         }
+    if rank == 0 and args.workload != "dynamics":
+        kt = kernel_time_raycast(task)
+        per_env = raycast_bytes_per_env(task)
+        achieved = per_env * N / kt / 1e9
+        cfgs = task.sim_env.robot_manager.warp_sensor.cfg
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_raycast (one frame, all envs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_raycast_%s_%d" % (args.workload, N)), "launch_us": kt * 1e6,
+            "algorithmic_bytes_per_launch": per_env * N, "rays_per_s": N * cfgs.num_sensors * cfgs.height * cfgs.width / kt,
+            "note": "ray traversal is latency / VALU bound, not HBM bound: the scene (127 KB/env) is read once per frame",
+        }
     if rank == 0 and args.workload == "dynamics" and world == 1:
         # same kernel where the roofline is meaningful (N = 2^21 envs, 319 MB per launch)
         try:
@@ -268,14 +310,23 @@ def main():
             out["roofline_at_scale"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
         out["cpu_baseline"] = cpu_baseline_dynamics(N)
-    if rank == 0 and world == 1 and args.with_depth and args.workload == "dynamics":
+    if rank == 0 and world == 1 and not args.no_depth and args.workload == "dynamics":
+        # the "+depth sensor" half of the metric: BASELINE configs[2] on the same GPU (fewer steps: ~3 ms each)
+        del task
+        torch.cuda.empty_cache()
         t2 = make_task("depth", args.num_envs, device, args.strict_rng)
         t2.reset()
         a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
-        s2 = max(args.steps // 20, 20)
-        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 20, 5), 1)
+        s2 = min(max(args.steps // 10, 20), 300)
+        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 10, 5), 1)
+        kt2 = kernel_time_raycast(t2)
+        per_env = raycast_bytes_per_env(t2)
         out["plus_depth"] = {"value": N * s2 / dt2, "unit": "env-steps/s", "steps": s2, "ms_per_step": 1e3 * dt2 / s2,
-                             "rays_per_s": N * s2 * 64 * 48 / dt2}
+                             "workload": "navigation_task, 8192 envs, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step",
+                             "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
+                             "raycast_roofline": {"bound": "hbm", "achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS,
+                                                  "unit": "GB/s", "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS,
+                                                  "algorithmic_bytes_per_launch": per_env * N}}
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -2,7 +2,7 @@
   - k_update_states at 2^21 envs   (calibration: known 52 B read + 64 B written per env,
                                      same 4 B/lane coalesced SoA pattern as the step kernel)
   - k_env_step<4,position> at 8192 and 2^21 envs
-  - (with --nav) one navigation step at 2048 envs for k_raycast
+  - (with --nav) three navigation steps at 8192 envs for k_raycast / k_env_step<4,velocity,10 sub-steps>
 Run:  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o p -- python profiles/pmc_probe.py
 """
 import os
@@ -28,9 +28,9 @@ for n in (8192, 1 << 21):
     torch.cuda.synchronize()
     del task
 if "--nav" in sys.argv:
-    t = bench.make_task("depth", 2048, dev, False)
+    t = bench.make_task("depth", 8192, dev, False)
     t.reset()
-    a = torch.rand(2048, 4, device=dev) * 2 - 1
+    a = torch.rand(8192, 4, device=dev) * 2 - 1
     for _ in range(3):
         t.step(a)
     torch.cuda.synchronize()
