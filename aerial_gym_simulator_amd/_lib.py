@@ -92,6 +92,8 @@ class AgxEnvBuffers(C.Structure):
         ("rng_seed", C.c_uint64),
         ("boxes", C.c_void_p),
         ("num_boxes", C.c_int32),
+        ("step_rows", C.c_void_p * 2),
+        ("step_reward", C.c_void_p),
     ]
 
 
@@ -225,7 +227,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.agx_abi_version() != 2:
+    if lib.agx_abi_version() != 3:
         raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
     _lib = lib
     return lib

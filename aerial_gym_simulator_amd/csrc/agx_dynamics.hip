@@ -643,18 +643,30 @@ __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n,
 }
 
 // position_setpoint_task.py:194-203, obs [N][13] row-major (what the policy network consumes)
-AGX_DEV void write_obs_position(int n, int i, const float *__restrict__ target, float *__restrict__ obs, const EnvState &s,
-                                const Derived &d) {
+// reward | terminated | truncated behind the observation in the exchange row (header: step_rows)
+AGX_DEV void write_step_row_tail(const AgxEnvBuffers &B, int i, float *__restrict__ row, int obs_dim) {
+  row[obs_dim] = B.step_reward[i];
+  row[obs_dim + 1] = B.crashes[i] ? 1.0f : 0.0f;
+  row[obs_dim + 2] = B.truncations[i] ? 1.0f : 0.0f;
+}
+AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target, float *__restrict__ obs,
+                                const EnvState &s, const Derived &d) {
+  float v[13] = {target[0 * n + i] - s.p.x, target[1 * n + i] - s.p.y, target[2 * n + i] - s.p.z, s.q.x, s.q.y, s.q.z, s.q.w,
+                 d.vbody.x, d.vbody.y, d.vbody.z, d.wbody.x, d.wbody.y, d.wbody.z};
   float *o = obs + (size_t)i * 13;
-  o[0] = target[0 * n + i] - s.p.x; o[1] = target[1 * n + i] - s.p.y; o[2] = target[2 * n + i] - s.p.z;
-  o[3] = s.q.x; o[4] = s.q.y; o[5] = s.q.z; o[6] = s.q.w;
-  o[7] = d.vbody.x; o[8] = d.vbody.y; o[9] = d.vbody.z;
-  o[10] = d.wbody.x; o[11] = d.wbody.y; o[12] = d.wbody.z;
+#pragma unroll
+  for (int c = 0; c < 13; ++c) o[c] = v[c];
+  if (float *rows = B.step_rows[B.flag_parity]) {
+    float *r = rows + (size_t)i * 16;
+#pragma unroll
+    for (int c = 0; c < 13; ++c) r[c] = v[c];
+    write_step_row_tail(B, i, r, 13);
+  }
 }
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  write_obs_position(n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
 }
 
 struct NavParams {
@@ -696,6 +708,7 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
   float *o = obs + (size_t)i * obs_dim;
+  float *row = B.step_rows[B.flag_parity] ? B.step_rows[B.flag_parity] + (size_t)i * (obs_dim + 3) : nullptr;
   if (lane == 0) {
     V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
     Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
@@ -713,6 +726,10 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
     o[7] = B.derived[10 * n + i]; o[8] = B.derived[11 * n + i]; o[9] = B.derived[12 * n + i];
     o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
     o[13] = B.actions[0 * n + i]; o[14] = B.actions[1 * n + i]; o[15] = B.actions[2 * n + i]; o[16] = B.actions[3 * n + i];
+    if (row) {
+      for (int c = 0; c < 17 && c < obs_dim; ++c) row[c] = o[c];  // this lane's own stores
+      write_step_row_tail(B, i, row, obs_dim);
+    }
   }
   if (pixels) {
     const float *img = pixels + (size_t)i * ns * H * W;  // sensor 0
@@ -722,7 +739,10 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
       float m = INFINITY;
       for (int y = cy * ch; y < min((cy + 1) * ch, H); ++y)
         for (int x = cx * cw; x < min((cx + 1) * cw, W); ++x) m = fminf(m, img[(size_t)y * W + x]);
-      if (17 + cell < obs_dim) o[17 + cell] = m;
+      if (17 + cell < obs_dim) {
+        o[17 + cell] = m;
+        if (row) row[17 + cell] = m;
+      }
     }
   }
 }
@@ -819,14 +839,14 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
   if (i >= n) return;
   if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
-    if (WITH_OBS) write_obs_position(n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+    if (WITH_OBS) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
     return;
   }
   EnvState s = reset_env<M>(P, B, n, R, i);
   // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
   Derived d = update_states(s);
   store_derived(B.derived, n, i, d);
-  if (WITH_OBS) write_obs_position(n, i, target, obs, s, d);
+  if (WITH_OBS) write_obs_position(B, n, i, target, obs, s, d);
 }
 
 // AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295)
@@ -900,6 +920,9 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   AGX_REQUIRE(B != nullptr, "null buffers");
   AGX_REQUIRE(n > 0, "num_envs must be > 0 (got %d)", n);
   AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
+  AGX_REQUIRE((!B->step_rows[0] && !B->step_rows[1]) ||
+                  (B->step_rows[0] && B->step_rows[1] && B->step_reward && B->crashes && B->truncations),
+              "step_rows needs both parity buffers, step_reward, crashes and truncations");
   if (P) {
     AGX_REQUIRE(P->num_motors >= 1 && P->num_motors <= AGX_MAX_MOTORS, "num_motors out of range");
     AGX_REQUIRE(P->num_actions >= 1 && P->num_actions <= AGX_MAX_ACTIONS, "num_actions out of range");

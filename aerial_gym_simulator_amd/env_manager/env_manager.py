@@ -125,7 +125,7 @@ class EnvManager(BaseManager):
         g["gravity"] = torch.tensor(sim_cfg.sim.gravity, device=dev).expand(N, -1)
         g["dt"] = sim_cfg.sim.dt
         # obstacles: which boxes live in which env (asset_loader.py:148-194 semantics)
-        self.scene = SceneManager(env_cfg, N, dev, self.random_source)
+        self.scene = SceneManager(env_cfg, N, dev, self.random_source, shard_rank=int(self.env_args.get("shard_rank", 0)))
         self.keep_in_env = self.scene.keep_in_env_num
         g["num_obstacles_in_env"] = self.scene.num_assets
         self.robot_manager = RobotManagerHIP(self.global_tensor_dict, self.cfg, self.robot_name, self.controller_name, dev)
@@ -228,6 +228,15 @@ class EnvManager(BaseManager):
         R.tau_dec_min, R.tau_dec_max = rng["tau_dec"]
         R.kT_min, R.kT_max = rng["kT"]
         self._reset_args = R
+
+    def bind_step_rows(self, rows, reward):
+        """Multi-GPU exchange rows (sharding.StepGather): `rows` [2, N, obs_dim + 3], one per step
+        parity, written by the observation kernels next to the observation itself."""
+        self._require_device()
+        B = self._buffers
+        B.step_rows[0], B.step_rows[1] = _lib.dptr(rows[0]), _lib.dptr(rows[1])
+        B.step_reward = _lib.dptr(reward)
+        self._step_rows = (rows, reward)  # keep alive
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

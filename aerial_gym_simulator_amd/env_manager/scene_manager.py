@@ -16,6 +16,8 @@ import random
 import numpy as np
 import torch
 
+from ..sharding import semantic_id_offset
+
 # trimesh.creation.box: vertices = ({0,1}^3 - 0.5) * extents in this order, 12 faces
 _BOX_VERTS = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]], dtype=np.float32) - 0.5
 _BOX_FACES = np.array(
@@ -25,9 +27,9 @@ _BOX_FACES = np.array(
 
 
 class SceneManager:
-    def __init__(self, env_cfg, num_envs, device, random_source, semantic_offset=0, scene_seed_base=1000):
+    def __init__(self, env_cfg, num_envs, device, random_source, shard_rank=0, scene_seed_base=1000):
         self.cfg, self.num_envs, self.device = env_cfg, num_envs, device
-        self.semantic_offset = semantic_offset  # sharding: global asset counter start
+        self.shard_rank = shard_rank  # this process owns global envs [rank * N, (rank + 1) * N)  
         N = num_envs
         types = []
         for name, acfg in env_cfg.env_config.asset_type_to_dict_map.items():
@@ -42,6 +44,8 @@ class SceneManager:
         self.keep_in_env_num = len(keep_slots)
         K = self.num_assets = len(keep_slots) + len(free_slots)
         self.num_tris = 12 * K
+        # sharding: start of this rank's slice of the global asset counter
+        semantic_offset = self.semantic_offset = semantic_id_offset(shard_rank, N, K)
         if K == 0:
             return
         size = np.zeros((N, K, 3), np.float32)
@@ -65,7 +69,7 @@ class SceneManager:
                 slot_choices[j, : len(t.box_sizes)] = t.box_sizes
         free_idx = list(range(nk, nk + nf))
         for i in range(N):
-            rng = np.random.default_rng(scene_seed_base + semantic_offset // max(K, 1) + i)
+            rng = np.random.default_rng(scene_seed_base + shard_rank * N + i)  # seeded by GLOBAL env index
             order = free_idx[:]
             random.shuffle(order)  # python `random`, like asset_loader.py:181
             perm = np.array(list(range(nk)) + order)

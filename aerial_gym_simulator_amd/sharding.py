@@ -4,8 +4,12 @@ truncation rows).  The simulator itself needs no communication: envs never read 
 (SURVEY.md section 8e); the reference has no distributed path at all.
 
 Payload per rank and step: N_local * (obs_dim + 3) * 4 B  (8192 envs, 13-D obs: 0.5 MB), i.e.
-latency bound on a fully connected xGMI node -- hence a single fused buffer, not one collective
-per tensor.
+latency bound on a fully connected xGMI node -- hence
+  * a single fused buffer, not one collective per tensor;
+  * the send rows are written by the observation kernel itself (AgxEnvBuffers.step_rows), so
+    the exchange adds no launch to the step;
+  * rows and receive buffers are double buffered by step parity and the collective runs
+    asynchronously on RCCL's own stream: the gather of step t overlaps the kernels of step t+1.
 """
 import torch
 import torch.distributed as dist
@@ -25,30 +29,61 @@ def semantic_id_offset(rank, envs_per_rank, assets_per_env):
 
 
 class StepGather:
-    """Packs (obs, reward, terminated, truncated) into one [N_local, obs_dim + 3] fp32 buffer and
-    all-gathers it; `unpack` returns views of the gathered [world * N_local, ...] result."""
+    """All-gathers [N_local, obs_dim + 3] fp32 rows (obs | reward | terminated | truncated) once
+    per env step.
 
-    def __init__(self, num_envs_local, obs_dim, device, group=None):
+    With `env` (an EnvManager on a HIP device) the rows are produced by the observation kernels;
+    without, the caller fills them with `pack()` (host-logic tests, custom tasks).
+
+    exchange(parity, overlap):
+      overlap=False  the returned views hold THIS step's rows of all ranks (stream-ordered);
+      overlap=True   this step's collective is left in flight and the views of the PREVIOUS
+                     step are returned (None on the first call) -- asynchronous samplers such
+                     as the reference's Sample Factory recipe tolerate the one-step delay.
+    """
+
+    def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n, self.obs_dim = num_envs_local, obs_dim
-        self.packed = torch.zeros(num_envs_local, obs_dim + 3, device=device)
-        self.gathered = torch.zeros(self.world * num_envs_local, obs_dim + 3, device=device)
+        self.rows = torch.zeros(2, num_envs_local, obs_dim + 3, device=device)
+        self.gathered = torch.zeros(2, self.world * num_envs_local, obs_dim + 3, device=device) if self.world > 1 else self.rows
+        self._work = [None, None]
+        self._last = None
+        if env is not None:
+            env.bind_step_rows(self.rows, reward)
 
-    def pack(self, obs, reward, terminated, truncated):
-        p, d = self.packed, self.obs_dim
+    def pack(self, parity, obs, reward, terminated, truncated):
+        p, d = self.rows[parity], self.obs_dim
         p[:, :d] = obs
         p[:, d] = reward
         p[:, d + 1] = terminated
         p[:, d + 2] = truncated
         return p
 
-    def gather(self, async_op=False):
-        if self.world == 1:
-            self.gathered.copy_(self.packed)
+    def exchange(self, parity, overlap=False):
+        if self.world > 1:
+            self._work[parity] = dist.all_gather_into_tensor(self.gathered[parity], self.rows[parity], group=self.group,
+                                                             async_op=True)
+        if not overlap:
+            self.wait(parity)
+            return self.unpack(parity)
+        prev, self._last = self._last, parity
+        if prev is None:
             return None
-        return dist.all_gather_into_tensor(self.gathered, self.packed, group=self.group, async_op=async_op)
+        # the next step writes rows[prev] again: its collective must have drained (stream wait, no host block)
+        self.wait(prev)
+        return self.unpack(prev)
 
-    def unpack(self):
-        g, d = self.gathered, self.obs_dim
+    def wait(self, parity):
+        w, self._work[parity] = self._work[parity], None
+        if w is not None:
+            w.wait()
+
+    def flush(self):
+        self.wait(0)
+        self.wait(1)
+
+    def unpack(self, parity):
+        g, d = self.gathered[parity], self.obs_dim
         return g[:, :d], g[:, d], g[:, d + 1] > 0.5, g[:, d + 2] > 0.5

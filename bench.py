@@ -42,11 +42,12 @@ def parse():
     ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar"])
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step")
     ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
     return ap.parse_args()
 
 
-def make_task(workload, num_envs, device, strict_rng):
+def make_task(workload, num_envs, device, strict_rng, rank=0):
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -55,34 +56,42 @@ def make_task(workload, num_envs, device, strict_rng):
         cfg = position_setpoint_task_config
         cfg.controller_name = "lee_position_control"
         cfg.device = device
-        cfg.args = {"strict_rng": strict_rng}
-        return task_registry.make_task("position_setpoint_task", seed=1, num_envs=num_envs, headless=True)
+        cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
+        return task_registry.make_task("position_setpoint_task", seed=1 + rank, num_envs=num_envs, headless=True)
     cfg = navigation_task_config
     cfg.device = device
-    cfg.args = {"strict_rng": strict_rng}
+    cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}  # rank: own scenes, RNG stream and semantic-id range
     if workload == "lidar":
         cfg.robot_name = "base_octarotor_with_lidar_32x512"
         cfg.controller_name = "octarotor_velocity_control"
-    return task_registry.make_task("navigation_task", seed=1, num_envs=num_envs, headless=True)
+    return task_registry.make_task("navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
 
 
-def timed_steps(task, actions, steps, warmup, world, gather_buf=None):
+def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=True):
     import torch.distributed as dist
 
+    env = task.sim_env
+
     def one(i):
-        obs, rew, term, trunc, _ = task.step(actions[i % len(actions)])
-        if gather_buf is not None:  # one RCCL all-gather of the packed step outputs per env step
-            gather_buf.pack(obs["observations"], rew, term, trunc)
-            gather_buf.gather()
+        task.step(actions[i % len(actions)])
+        if gather_buf is not None:
+            # ONE RCCL all-gather per env step of the rows the observation kernel wrote (obs | reward |
+            # terminated | truncated of every env of every rank); with `overlap` it stays in flight
+            # while the next step computes and the previous step's result is handed out
+            gather_buf.exchange(env._parity, overlap=overlap)
 
     for i in range(warmup):
         one(i)
+    if gather_buf is not None:
+        gather_buf.flush()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         one(i)
+    if gather_buf is not None:
+        gather_buf.flush()  # the last collective is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -230,7 +239,7 @@ def main():
         else:
             dist.init_process_group("nccl")  # RCCL over xGMI; rank / world size / master from the env
     n_gpus = max(world, 1)
-    task = make_task(args.workload, args.num_envs, device, args.strict_rng)
+    task = make_task(args.workload, args.num_envs, device, args.strict_rng, rank)
     task.reset()
     N, A = task.num_envs, task.task_config.action_space_dim
     g = torch.Generator(device=device).manual_seed(1234 + rank)
@@ -239,8 +248,8 @@ def main():
     if use_dist:
         from aerial_gym_simulator_amd.sharding import StepGather
 
-        gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device)
-    dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf)
+        gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards)
+    dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf, overlap=not args.sync_gather)
     value = n_gpus * N * args.steps / dt
     out = {
         "metric": "env-steps/sec at N_envs=8192 per GPU (" + ("dynamics-only" if args.workload == "dynamics" else "+" + args.workload + " sensor") + ")",
@@ -261,7 +270,8 @@ def main():
                          "lidar": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes, 32x512 LiDAR range+seg (BASELINE configs[3])"}[args.workload],
             "num_envs_per_gpu": N,
             "num_envs_total": n_gpus * N,
-            "sharding": f"envs x{n_gpus}, 1 all_gather/step" if world > 1 else "single GPU",
+            "sharding": (f"envs x{n_gpus}, 1 RCCL all_gather/step of [N, obs_dim+3] rows, "
+                         + ("synchronous" if args.sync_gather else "overlapped with the next step")) if use_dist else "single GPU",
             "rng": "strict (reference torch stream, host sync/step)" if args.strict_rng else "sync-free (device Philox4x32-10)",
         },
     }
@@ -332,6 +342,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
+        dist.barrier()  # rank 0 may still have been timing kernels for the roofline keys
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 2
+#define AGX_ABI_VERSION 3
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -130,6 +130,14 @@ typedef struct AgxEnvBuffers {
   uint64_t rng_seed;     /* key of the device generator                                     */
   const float *boxes;    /* [K][11][N] obstacle OBBs centre(3) quat(4) half(3) bounding radius(1), or NULL */
   int32_t num_boxes;
+  /* optional multi-GPU exchange rows (ONE gather per env step).  When step_rows[p] is
+     set, every kernel that writes the task observation (agx_post_step_position, agx_obs_position,
+     agx_obs_navigation) also writes row i of step_rows[flag_parity] =
+       obs(obs_dim) | reward | terminated (crashes) | truncated     ([N][obs_dim + 3] row-major)
+     so the send buffer of the collective costs no extra launch.  Double buffered by step parity so
+     the gather of step t may overlap step t+1.                                                 */
+  float *step_rows[2];
+  const float *step_reward; /* [N] the task's reward buffer (required when step_rows is set)     */
 } AgxEnvBuffers;
 
 const char *agx_last_error(void);

@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/aerial_gym_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     L = _lib.load()
-    assert L.agx_abi_version() == 2
+    assert L.agx_abi_version() == 3
     # links only against the HIP runtime / libc: no torch, no python in the C ABI library
     needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
     libs = re.findall(r"Shared library: \[(.*?)\]", needed)
@@ -143,6 +143,21 @@ def test_scene_manager_semantics():
     assert (env2.scene.num_assets, env2.scene.keep_in_env_num) == (44, 9)  # 3 panels + 35 objects + 6 walls
 
 
+def test_sharded_scenes_are_slices_of_the_global_scene_set():
+    """Rank r of a sharded run owns global envs [r*N, (r+1)*N): same boxes, same semantic ids
+    as the un-sharded run's slice."""
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    name = ("base_sim", "env_with_random_boxes", "base_quadrotor_with_camera_64x48", "lee_velocity_control", "cpu")
+    full = SimBuilder().build_env(*name, num_envs=6).scene
+    for rank in (0, 1, 2):
+        part = SimBuilder().build_env(*name, num_envs=2, args={"shard_rank": rank}).scene
+        sl = slice(2 * rank, 2 * rank + 2)
+        assert torch.equal(part.asset_semantic_id, full.asset_semantic_id[sl])
+        assert torch.equal(part.half_extents, full.half_extents[sl])
+        assert torch.equal(part.tri_seg, full.tri_seg[sl])
+
+
 def test_navigation_action_transform_matches_reference():
     from aerial_gym_simulator_amd.config.task_config import navigation_task_config as cfg
 
@@ -163,11 +178,24 @@ def _gather_worker(rank, world, port, ret):
     lo, hi = shard_range(total, rank, world)
     full_obs = torch.arange(total * obs_dim, dtype=torch.float32).view(total, obs_dim)
     sg = StepGather(hi - lo, obs_dim, "cpu")
-    sg.pack(full_obs[lo:hi], torch.arange(lo, hi).float(), torch.arange(lo, hi) % 2 == 0, torch.arange(lo, hi) % 3 == 0)
-    sg.gather()
-    obs, rew, term, trunc = sg.unpack()
-    ok = torch.equal(obs, full_obs) and torch.equal(rew, torch.arange(total).float())
-    ok = ok and torch.equal(term, torch.arange(total) % 2 == 0) and torch.equal(trunc, torch.arange(total) % 3 == 0)
+    ids = torch.arange(total)
+
+    def fill(step):  # what the observation kernel writes into rows[parity] of this rank's envs
+        par = step & 1
+        sg.pack(par, full_obs[lo:hi] + step, ids[lo:hi].float() * (step + 1), (ids[lo:hi] + step) % 2 == 0, (ids[lo:hi] + step) % 3 == 0)
+        return par
+
+    def expect(out, step):
+        obs, rew, term, trunc = out
+        return (torch.equal(obs, full_obs + step) and torch.equal(rew, ids.float() * (step + 1))
+                and torch.equal(term, (ids + step) % 2 == 0) and torch.equal(trunc, (ids + step) % 3 == 0))
+
+    ok = expect(sg.exchange(fill(0)), 0)  # synchronous: this step's rows of every rank
+    ok = ok and sg.exchange(fill(1), overlap=True) is None  # pipelined: first call has nothing to hand back
+    for step in range(2, 7):
+        ok = ok and expect(sg.exchange(fill(step), overlap=True), step - 1)
+    sg.flush()
+    ok = ok and expect(sg.unpack(6 & 1), 6)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -146,3 +146,40 @@ def test_config4_octarotor_lidar_task_runs():
     finally:
         cfg.robot_name, cfg.controller_name, cfg.args = old
         cfg.robot_name, cfg.controller_name = "base_quadrotor_with_camera_64x48", "lee_velocity_control"
+
+
+@pytest.mark.parametrize("which", ["position", "navigation"])
+def test_exchange_rows_written_by_the_obs_kernels(which):
+    """AgxEnvBuffers.step_rows: the observation kernels also write obs | reward | terminated |
+    truncated into the send buffer of the per-step all-gather (bit-identical copies)."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    cfg = position_setpoint_task_config if which == "position" else navigation_task_config
+    old = (cfg.episode_len_steps, cfg.args, getattr(cfg, "controller_name", None))
+    cfg.device, cfg.episode_len_steps, cfg.args = DEV, 7, {}
+    if which == "position":
+        cfg.controller_name = "lee_position_control"
+    try:
+        n = 200
+        task = task_registry.make_task(which + ("_setpoint_task" if which == "position" else "_task"), seed=3, num_envs=n, headless=True)
+        task.reset()
+        d = task.task_obs["observations"].shape[1]
+        sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards)
+        a = torch.rand(n, 4, device=DEV) * 2 - 1
+        seen_trunc = 0
+        for step in range(20):
+            obs, rew, term, trunc, _ = task.step(a)
+            got = sg.exchange(task.sim_env._parity)  # world size 1: views of this step's rows
+            assert torch.equal(got[0], obs["observations"]) and torch.equal(got[1], rew)
+            assert torch.equal(got[2], term.bool()) and torch.equal(got[3], trunc.bool())
+            seen_trunc += int(trunc.sum())
+            other = sg.rows[task.sim_env._parity ^ 1]
+            assert step == 0 or not torch.equal(other, sg.rows[task.sim_env._parity])  # the other parity holds the previous step
+        assert seen_trunc >= n  # the flags were exercised
+    finally:
+        cfg.episode_len_steps, cfg.args = old[0], old[1]
+        if old[2] is not None:
+            cfg.controller_name = old[2]
