@@ -35,19 +35,21 @@ class StepGather:
     With `env` (an EnvManager on a HIP device) the rows are produced by the observation kernels;
     without, the caller fills them with `pack()` (host-logic tests, custom tasks).
 
-    exchange(parity, overlap):
-      overlap=False  the returned views hold THIS step's rows of all ranks (stream-ordered);
-      overlap=True   this step's collective is left in flight and the views of the PREVIOUS
-                     step are returned (None on the first call) -- asynchronous samplers such
+    exchange(parity, overlap) returns the gathered [world * N_local, obs_dim + 3] buffer (no
+    device work besides the collective; `unpack` slices it):
+      overlap=False  THIS step's rows of all ranks (stream-ordered);
+      overlap=True   this step's collective is left in flight and the buffer of the PREVIOUS
+                     step is returned (None on the first call) -- asynchronous samplers such
                      as the reference's Sample Factory recipe tolerate the one-step delay.
     """
 
     def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized()  # a world of one still goes through RCCL (bench debugging aid)
+        self.world = dist.get_world_size(group) if self.collective else 1
         self.n, self.obs_dim = num_envs_local, obs_dim
         self.rows = torch.zeros(2, num_envs_local, obs_dim + 3, device=device)
-        self.gathered = torch.zeros(2, self.world * num_envs_local, obs_dim + 3, device=device) if self.world > 1 else self.rows
+        self.gathered = torch.zeros(2, self.world * num_envs_local, obs_dim + 3, device=device) if self.collective else self.rows
         self._work = [None, None]
         self._last = None
         if env is not None:
@@ -62,18 +64,18 @@ class StepGather:
         return p
 
     def exchange(self, parity, overlap=False):
-        if self.world > 1:
+        if self.collective:
             self._work[parity] = dist.all_gather_into_tensor(self.gathered[parity], self.rows[parity], group=self.group,
                                                              async_op=True)
         if not overlap:
             self.wait(parity)
-            return self.unpack(parity)
+            return self.gathered[parity]
         prev, self._last = self._last, parity
         if prev is None:
             return None
         # the next step writes rows[prev] again: its collective must have drained (stream wait, no host block)
         self.wait(prev)
-        return self.unpack(prev)
+        return self.gathered[prev]
 
     def wait(self, parity):
         w, self._work[parity] = self._work[parity], None
@@ -84,6 +86,7 @@ class StepGather:
         self.wait(0)
         self.wait(1)
 
-    def unpack(self, parity):
-        g, d = self.gathered[parity], self.obs_dim
-        return g[:, :d], g[:, d], g[:, d + 1] > 0.5, g[:, d + 2] > 0.5
+    def unpack(self, buf):
+        """(obs, reward, terminated, truncated) of a buffer returned by exchange()."""
+        d = self.obs_dim
+        return buf[:, :d], buf[:, d], buf[:, d + 1] > 0.5, buf[:, d + 2] > 0.5

@@ -103,6 +103,21 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=Tr
     return dt
 
 
+def hbm_copy_gbs(device, nbytes=1 << 30, reps=10):
+    """Measured HBM bandwidth of a device-to-device copy (read + write bytes / time) on this box:
+    the achievable ceiling next to the 8 TB/s vendor peak."""
+    a = torch.empty(nbytes // 4, device=device)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        b.copy_(a)
+    stop.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (start.elapsed_time(stop) * 1e-3) / 1e9
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/<round>_pmc_traffic.json, written by profiles/collect_pmc.py); None if absent."""
@@ -245,9 +260,9 @@ def main():
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
     gather_buf = None
-    if use_dist:
-        from aerial_gym_simulator_amd.sharding import StepGather
+    from aerial_gym_simulator_amd.sharding import StepGather
 
+    if use_dist:
         gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards)
     dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf, overlap=not args.sync_gather)
     value = n_gpus * N * args.steps / dt
@@ -287,6 +302,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic("k_env_step_8192"),
             "launch_us": kt * 1e6,
+            "peak_measured_copy": hbm_copy_gbs(device),
             "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N,
             "note": "8192 envs move 1.2 MB per launch: launch-latency bound, see roofline_at_scale for the same kernel at 2^21 envs",
         }
@@ -320,23 +336,32 @@ def main():
             out["roofline_at_scale"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
         out["cpu_baseline"] = cpu_baseline_dynamics(N)
-    if rank == 0 and world == 1 and not args.no_depth and args.workload == "dynamics":
-        # the "+depth sensor" half of the metric: BASELINE configs[2] on the same GPU (fewer steps: ~3 ms each)
-        del task
+    if not args.no_depth and args.workload == "dynamics":
+        # the "+depth sensor" half of the metric: BASELINE configs[2] on every GPU (= configs[4] when N > 1:
+        # 8192 envs per rank + the per-step all-gather); fewer steps: ~2.5 ms each
+        del task, gather_buf
         torch.cuda.empty_cache()
-        t2 = make_task("depth", args.num_envs, device, args.strict_rng)
+        t2 = make_task("depth", args.num_envs, device, args.strict_rng, rank)
         t2.reset()
         a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
         s2 = min(max(args.steps // 10, 20), 300)
-        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 10, 5), 1)
-        kt2 = kernel_time_raycast(t2)
-        per_env = raycast_bytes_per_env(t2)
-        out["plus_depth"] = {"value": N * s2 / dt2, "unit": "env-steps/s", "steps": s2, "ms_per_step": 1e3 * dt2 / s2,
-                             "workload": "navigation_task, 8192 envs, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step",
-                             "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                             "raycast_roofline": {"bound": "hbm", "achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS,
-                                                  "unit": "GB/s", "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS,
-                                                  "algorithmic_bytes_per_launch": per_env * N}}
+        gb2 = None
+        if use_dist:
+            gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards)
+        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 10, 5), world, gb2, overlap=not args.sync_gather)
+        if rank == 0:
+            out["plus_depth"] = {"value": n_gpus * N * s2 / dt2, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": s2,
+                                 "ms_per_step": 1e3 * dt2 / s2,
+                                 "workload": "navigation_task, 8192 envs per GPU, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step"
+                                             + (" (BASELINE configs[4] sharding, 1 all_gather/step)" if world > 1 else "")}
+        if rank == 0 and world == 1:
+            kt2 = kernel_time_raycast(t2)
+            per_env = raycast_bytes_per_env(t2)
+            out["plus_depth"].update({
+                "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
+                "raycast_roofline": {"bound": "hbm", "achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N,
+                                     "traffic": pmc_traffic("k_raycast_depth_%d" % N)}})
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

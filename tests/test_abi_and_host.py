@@ -185,8 +185,8 @@ def _gather_worker(rank, world, port, ret):
         sg.pack(par, full_obs[lo:hi] + step, ids[lo:hi].float() * (step + 1), (ids[lo:hi] + step) % 2 == 0, (ids[lo:hi] + step) % 3 == 0)
         return par
 
-    def expect(out, step):
-        obs, rew, term, trunc = out
+    def expect(buf, step):
+        obs, rew, term, trunc = sg.unpack(buf)
         return (torch.equal(obs, full_obs + step) and torch.equal(rew, ids.float() * (step + 1))
                 and torch.equal(term, (ids + step) % 2 == 0) and torch.equal(trunc, (ids + step) % 3 == 0))
 
@@ -195,7 +195,7 @@ def _gather_worker(rank, world, port, ret):
     for step in range(2, 7):
         ok = ok and expect(sg.exchange(fill(step), overlap=True), step - 1)
     sg.flush()
-    ok = ok and expect(sg.unpack(6 & 1), 6)
+    ok = ok and expect(sg.gathered[6 & 1], 6)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -172,7 +172,7 @@ def test_exchange_rows_written_by_the_obs_kernels(which):
         seen_trunc = 0
         for step in range(20):
             obs, rew, term, trunc, _ = task.step(a)
-            got = sg.exchange(task.sim_env._parity)  # world size 1: views of this step's rows
+            got = sg.unpack(sg.exchange(task.sim_env._parity))  # world size 1: this step's rows
             assert torch.equal(got[0], obs["observations"]) and torch.equal(got[1], rew)
             assert torch.equal(got[2], term.bool()) and torch.equal(got[3], trunc.bool())
             seen_trunc += int(trunc.sum())
