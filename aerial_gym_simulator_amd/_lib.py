@@ -187,6 +187,11 @@ _SIGNATURES = {
         [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
          C.c_int, _P, _P, _P],
     ),
+    "agx_raycast_stereo_camera": (
+        C.c_int,
+        [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P,
+         _P, _P, C.c_int, _P, _P, _P],
+    ),
     "agx_raycast_lidar": (
         C.c_int,
         [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P],
@@ -195,6 +200,11 @@ _SIGNATURES = {
         C.c_int,
         [C.c_size_t, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
          C.c_float, C.c_int, _P],
+    ),
+    "agx_sensor_postprocess_points": (
+        C.c_int,
+        [C.c_size_t, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+         C.c_float, C.c_int, C.c_int, _P],
     ),
     "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
 }

@@ -3,7 +3,14 @@
 constants of resources/robots/{quad,octarotor}/*.urdf as data (``robot_model``)."""
 import numpy as np
 
-from .sensor_config import BaseDepthCameraConfig, BaseLidarConfig, DepthCamera64x48Config, Lidar32x512Config
+from .sensor_config import (
+    BaseDepthCameraConfig,
+    BaseLidarConfig,
+    BaseNormalFaceIDCameraConfig,
+    DepthCamera64x48Config,
+    Lidar32x512Config,
+    StereoCameraConfig,
+)
 
 _PI = float(np.pi)
 
@@ -111,6 +118,18 @@ class BaseQuadWithLidarCfg(BaseQuadCfg):
     class sensor_config(BaseQuadCfg.sensor_config):
         enable_lidar = True
         lidar_config = BaseLidarConfig
+
+
+class BaseQuadWithFaceIDNormalCameraCfg(BaseQuadCfg):  # base_quad_config.py:220-223
+    class sensor_config(BaseQuadCfg.sensor_config):
+        enable_camera = True
+        camera_config = BaseNormalFaceIDCameraConfig
+
+
+class BaseQuadWithStereoCameraCfg(BaseQuadCfg):  # base_quad_config.py:225-228
+    class sensor_config(BaseQuadCfg.sensor_config):
+        enable_camera = True
+        camera_config = StereoCameraConfig
 
 
 _S = 0.17320508075688776

@@ -44,6 +44,20 @@ class DepthCamera64x48Config(BaseDepthCameraConfig):
     height, width = 48, 64
 
 
+class StereoCameraConfig(BaseDepthCameraConfig):  # stereo_camera_config.py:4-9
+    sensor_type = "stereo_camera"
+    height, width = 270, 480
+    baseline = -0.095  # distance from the left to the right camera in metres, +y is positive
+
+
+class BaseNormalFaceIDCameraConfig(BaseDepthCameraConfig):  # base_normal_faceID_camera_config.py:7-45
+    sensor_type = "normal_faceID_camera"
+    height, width = 270, 480
+    return_pointcloud = True  # normal information comes in the form of a point cloud
+    normal_in_world_frame = True
+    randomize_placement = False
+
+
 class BaseLidarConfig(BaseSensorConfig):  # base_lidar_config.py:5-76
     sensor_type = "lidar"
     height, width = 128, 512
@@ -71,6 +85,17 @@ class Lidar32x512Config(BaseLidarConfig):
     """BASELINE config 4: 32 beams x 512 points."""
 
     height, width = 32, 512
+
+    class sensor_noise(BaseLidarConfig.sensor_noise):
+        enable_sensor_noise = False
+
+
+class BaseNormalFaceIDLidarConfig(BaseLidarConfig):
+    """sensor_type the reference's WarpSensor accepts (warp_sensor.py:63-70) without shipping a config."""
+
+    sensor_type = "normal_faceID_lidar"
+    return_pointcloud = True
+    normal_in_world_frame = True
 
     class sensor_noise(BaseLidarConfig.sensor_noise):
         enable_sensor_noise = False

@@ -137,12 +137,19 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   return true;
 }
 
+// ANY: occlusion query -- the first accepted hit retires the lane (it stops voting in ray_box)
+template <bool ANY>
 AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want) {
   if (!want) return;
   const float *t = tris + (size_t)f * 9;
   float th;
   if (ray_tri(r, V3{t[0], t[1], t[2]}, V3{t[3], t[4], t[5]}, V3{t[6], t[7], t[8]}, th)) {
-    if (th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
+    if (ANY) {
+      if (th >= 0.0f && th < r.best) {
+        r.face = f;
+        r.active = false;
+      }
+    } else if (th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
       r.best = th;
       r.face = f;
     }
@@ -164,9 +171,10 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
 
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
+template <bool ANY = false>
 AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
   if (nt == 1) {
-    test_leaf(r, tris, 0, r.active);
+    test_leaf<ANY>(r, tris, 0, r.active);
     return;
   }
   int sp = 0;
@@ -184,11 +192,11 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
     unsigned long long ml = __ballot(hl), mr = __ballot(hr);
     if (cl < 0) {
-      if (ml) { test_leaf(r, tris, ~cl, hl); AGX_STAT(2, 1); AGX_STAT(3, __popcll(ml)); }
+      if (ml) { test_leaf<ANY>(r, tris, ~cl, hl); AGX_STAT(2, 1); AGX_STAT(3, __popcll(ml)); }
       ml = 0;
     }
     if (cr < 0) {
-      if (mr) { test_leaf(r, tris, ~cr, hr); AGX_STAT(2, 1); AGX_STAT(3, __popcll(mr)); }
+      if (mr) { test_leaf<ANY>(r, tris, ~cr, hr); AGX_STAT(2, 1); AGX_STAT(3, __popcll(mr)); }
       mr = 0;
     }
     int next = -1;
@@ -220,6 +228,7 @@ struct CamArgs {
   float k00, k02, k11, k12;
   float far_plane;
   int c_x, c_y, mode;
+  float baseline;  // stereo partner at cam_pos + R(q) (-baseline, 0, 0)
 };
 
 struct LidarArgs {
@@ -228,7 +237,15 @@ struct LidarArgs {
   int mode;
 };
 
-template <bool LIDAR, bool USE_LDS>
+// VARIANT: what happens after the closest hit is known
+//   RAY_BASIC   depth / range / point cloud (+ segmentation)             warp_camera_kernels.py:176-282, warp_lidar_kernels.py
+//   RAY_NORMAL  geometric normal + face index                           warp_camera_kernels.py:70-121, warp_lidar_kernels.py:90-126
+//   RAY_STEREO  BASIC, valid only where the stereo partner sees the point too (second, any-hit ray)
+//                                                                       warp_stereo_camera_kernels.py:13-299
+enum { RAY_BASIC = 0, RAY_NORMAL = 1, RAY_STEREO = 2 };
+constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
+
+template <bool LIDAR, bool USE_LDS, int VARIANT>
 __global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
                                                           const float *__restrict__ sensor_pos,
                                                           const float *__restrict__ sensor_quat,
@@ -268,6 +285,8 @@ __global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs L
     if (mode >= AGX_RAY_POINTCLOUD) uvp = wp_normalize(uvp);
     rdp = wp_normalize(wp_quat_rotate(sq, uvp));
   }
+  V3 partner = ro;
+  if (VARIANT == RAY_STEREO) partner = ro + wp_quat_rotate(sq, V3{-CA.baseline, 0.0f, 0.0f});
   const int tiles_x = (width + 7) >> 3, tiles_y = (height + 7) >> 3;
   for (int tile = wave; tile < tiles_x * tiles_y; tile += kRayThreads / 64) {
     const int x = (tile % tiles_x) * 8 + (lane & 7), y = (tile / tiles_x) * 8 + (lane >> 3);
@@ -290,14 +309,51 @@ __global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs L
     Ray r;
     ray_setup(r, ro, rd, max_t, active);
     traverse(r, nodes, tris, nt);
-    if (active) {
-      float dist = kNoHitRay;
-      int sv = kNoHitSeg;
-      if (r.face >= 0) {
-        dist = (!LIDAR && mode <= AGX_RAY_DEPTH) ? mult * r.best : r.best;
-        if (seg) sv = tri_seg[(size_t)env * nt + r.face];
+    const size_t px = ((sidx * height) + y) * width + x;
+    if (VARIANT == RAY_NORMAL) {
+      // miss: zero normal, face -1 (the reference's `n`, `f` stay at their initial values)
+      V3 nrm = V3{0.0f, 0.0f, 0.0f};
+      if (active && r.face >= 0) {
+        const float *t = tris + (size_t)r.face * 9;
+        const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
+        nrm = wp_normalize(cross(b - a, c - a));  // warp intersect.h out_normal, mesh.h normalize(min_normal)
       }
-      const size_t px = ((sidx * height) + y) * width + x;
+      if (mode == AGX_RAY_NORMAL) {
+        if (LIDAR) {
+          nrm = wp_normalize(wp_quat_rotate(Q4{-sq.x, -sq.y, -sq.z, sq.w}, nrm));  // quat_inverse(lidar_quaternion)
+        } else {
+          nrm = V3{dot(nrm, rdp), dot(nrm, cross(rdp, V3{0.0f, 0.0f, 1.0f})), dot(nrm, cross(rdp, V3{0.0f, 1.0f, 0.0f}))};
+        }
+      }
+      if (active) {
+        pixels[3 * px] = nrm.x;
+        pixels[3 * px + 1] = nrm.y;
+        pixels[3 * px + 2] = nrm.z;
+        if (seg) seg[px] = r.face;
+      }
+      continue;
+    }
+    const bool hit = r.face >= 0;
+    bool visible = true;
+    if (VARIANT == RAY_STEREO) {
+      // ro + rd * t*0.999  |  ro + rd * far_plane / multiplier  (point clouds: no multiplier)
+      V3 endpoint = hit ? ro + (rd * r.best) * 0.999f : (mode <= AGX_RAY_DEPTH ? ro + (rd * far_plane) / mult : ro + rd * far_plane);
+      V3 back = partner - endpoint;
+      Ray r2;
+      ray_setup(r2, endpoint, wp_normalize(back), sqrtf(dot(back, back)), active);
+      traverse<true>(r2, nodes, tris, nt);
+      visible = r2.face < 0;
+    }
+    if (active) {
+      float dist = VARIANT == RAY_STEREO ? kInvalidPixel : kNoHitRay;
+      int sv = kNoHitSeg;
+      if (visible) {
+        if (VARIANT == RAY_STEREO) dist = kNoHitRay;
+        if (hit) {
+          dist = (!LIDAR && mode <= AGX_RAY_DEPTH) ? mult * r.best : r.best;
+          if (seg) sv = tri_seg[(size_t)env * nt + r.face];
+        }
+      }
       if (mode <= AGX_RAY_DEPTH) {
         pixels[px] = dist;
       } else if (mode == AGX_RAY_POINTCLOUD_WORLD) {
@@ -351,6 +407,41 @@ __global__ void __launch_bounds__(256) k_sensor_postprocess(size_t count, float 
   }
 }
 
+// point-cloud branch of the same three functions: noise / dropout per component, range limits on
+// the point's norm (all three components replaced); `limits` = 0 for world-frame clouds
+__global__ void __launch_bounds__(256) k_sensor_postprocess_points(size_t count, float *__restrict__ pixels,
+                                                                    const float *__restrict__ z_normal,
+                                                                    const float *__restrict__ u_dropout, float std_a,
+                                                                    float std_b, float std_c, float mean_offset,
+                                                                    float dropout_prob, float min_range, float max_range,
+                                                                    float far_oor, float near_oor, int limits, int normalize) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (size_t)gridDim.x * blockDim.x) {
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float p = pixels[3 * k + c];
+      if (z_normal) {
+        float sd = std_a * (p * p) + std_b * p + std_c;
+        p = (p - mean_offset) + sd * z_normal[3 * k + c];
+        if (u_dropout && u_dropout[3 * k + c] < dropout_prob) p = near_oor;
+      }
+      v[c] = p;
+    }
+    if (limits) {
+      float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm > max_range) v[0] = v[1] = v[2] = far_oor;
+      nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm < min_range) v[0] = v[1] = v[2] = near_oor;
+      if (normalize) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = v[c] / max_range;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pixels[3 * k + c] = v[c];
+  }
+}
+
 // NavigationTask.post_image_reward_addition (navigation_task.py:351-357): per-env min of 10*img
 // with negative pixels replaced by 10.  One wave per env.
 __global__ void __launch_bounds__(256) k_image_min(int n, int ppe, const float *__restrict__ pixels, float *__restrict__ out) {
@@ -371,25 +462,25 @@ static size_t ray_lds_bytes(int nt) {
   return (size_t)(nt - 1) * 64 + (size_t)nt * 36 + 16;
 }
 
-template <bool LIDAR>
+template <bool LIDAR, int VARIANT>
 static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *ray_vectors, const float *pos, const float *quat,
                           const float *tri_world, const int32_t *tri_seg, const float *nodes, int nt, float *pixels,
                           int32_t *seg, void *stream) {
   const int n = LIDAR ? LA.n : CA.n, ns = LIDAR ? LA.ns : CA.ns;
   size_t lds = ray_lds_bytes(nt);
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_raycast<LIDAR, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+  if (AGX_RAY_USE_LDS && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_raycast<LIDAR, true, VARIANT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(n, ns);
   if (AGX_RAY_USE_LDS && lds <= 160 * 1024) {
-    hipLaunchKernelGGL((k_raycast<LIDAR, true>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors, pos,
-                       quat, tri_world, tri_seg, nodes, nt, pixels, seg);
-  } else {  // scene does not fit LDS: traverse from L2 / HBM
-    hipLaunchKernelGGL((k_raycast<LIDAR, false>), grid, dim3(kRayThreads), 0,
-                       (hipStream_t)stream, CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+    hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors,
+                       pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+  } else {  // default: traverse from L2 with wave-uniform loads
+    hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, ray_vectors,
+                       pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
   }
   return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
 }
@@ -424,24 +515,41 @@ extern "C" int agx_raycast_camera(int n, int ns, int width, int height, const fl
                                   const int32_t *tri_seg, const float *nodes, int nt, float *pixels, int32_t *seg,
                                   void *stream) {
   AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
+  AGX_REQUIRE(mode >= AGX_RAY_RANGE && mode <= AGX_RAY_NORMAL_WORLD, "bad mode %d", mode);
+  AGX_REQUIRE(kinv && cam_pos && cam_quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
+  AGX_REQUIRE(!seg || tri_seg || mode >= AGX_RAY_NORMAL, "segmentation output needs tri_seg");
+  CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode, 0.0f};  // kinv: HOST pointer
+  LidarArgs LA{};
+  if (mode >= AGX_RAY_NORMAL)
+    return launch_raycast<false, RAY_NORMAL>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<false, RAY_BASIC>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+}
+
+extern "C" int agx_raycast_stereo_camera(int n, int ns, int width, int height, const float *kinv, float far_plane, float baseline,
+                                         int c_x, int c_y, int mode, const float *cam_pos, const float *cam_quat,
+                                         const float *tri_world, const int32_t *tri_seg, const float *nodes, int nt,
+                                         float *pixels, int32_t *seg, void *stream) {
+  AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
   AGX_REQUIRE(mode >= AGX_RAY_RANGE && mode <= AGX_RAY_POINTCLOUD_WORLD, "bad mode %d", mode);
   AGX_REQUIRE(kinv && cam_pos && cam_quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
   AGX_REQUIRE(!seg || tri_seg, "segmentation output needs tri_seg");
-  CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode};  // kinv: HOST pointer
+  CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode, baseline};
   LidarArgs LA{};
-  return launch_raycast<false>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<false, RAY_STEREO>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
 }
 
 extern "C" int agx_raycast_lidar(int n, int ns, int width, int height, const float *ray_vectors, float far_plane, int mode,
                                  const float *pos, const float *quat, const float *tri_world, const int32_t *tri_seg,
                                  const float *nodes, int nt, float *pixels, int32_t *seg, void *stream) {
   AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
-  AGX_REQUIRE(mode == AGX_RAY_RANGE || mode == AGX_RAY_POINTCLOUD || mode == AGX_RAY_POINTCLOUD_WORLD, "bad mode %d", mode);
+  AGX_REQUIRE(mode == AGX_RAY_RANGE || (mode >= AGX_RAY_POINTCLOUD && mode <= AGX_RAY_NORMAL_WORLD), "bad mode %d", mode);
   AGX_REQUIRE(ray_vectors && pos && quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
-  AGX_REQUIRE(!seg || tri_seg, "segmentation output needs tri_seg");
+  AGX_REQUIRE(!seg || tri_seg || mode >= AGX_RAY_NORMAL, "segmentation output needs tri_seg");
   CamArgs CA{};
   LidarArgs LA{n, ns, width, height, far_plane, mode};
-  return launch_raycast<true>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  if (mode >= AGX_RAY_NORMAL)
+    return launch_raycast<true, RAY_NORMAL>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<true, RAY_BASIC>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
 }
 
 extern "C" int agx_sensor_postprocess(size_t count, float *pixels, const float *z_normal, const float *u_dropout, float std_a,
@@ -453,6 +561,19 @@ extern "C" int agx_sensor_postprocess(size_t count, float *pixels, const float *
   hipLaunchKernelGGL(k_sensor_postprocess, dim3(blocks), dim3(256), 0, (hipStream_t)stream, count, pixels, z_normal, u_dropout,
                      std_a, std_b, std_c, mean_offset, dropout_prob, min_range, max_range, far_oor, near_oor, normalize);
   return check_launch("agx_sensor_postprocess");
+}
+
+extern "C" int agx_sensor_postprocess_points(size_t count, float *pixels, const float *z_normal, const float *u_dropout,
+                                             float std_a, float std_b, float std_c, float mean_offset, float dropout_prob,
+                                             float min_range, float max_range, float far_oor, float near_oor, int limits,
+                                             int normalize, void *stream) {
+  AGX_REQUIRE(pixels && count > 0, "null buffer");
+  int blocks = (int)((count + 255) / 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(k_sensor_postprocess_points, dim3(blocks), dim3(256), 0, (hipStream_t)stream, count, pixels, z_normal,
+                     u_dropout, std_a, std_b, std_c, mean_offset, dropout_prob, min_range, max_range, far_oor, near_oor, limits,
+                     normalize);
+  return check_launch("agx_sensor_postprocess_points");
 }
 
 extern "C" int agx_image_min(int n, int ppe, const float *pixels, float *min_pixel, void *stream) {

@@ -5,7 +5,9 @@ from ..config.robot_config import (
     BaseQuadCfg,
     BaseQuadWithCamera64x48Cfg,
     BaseQuadWithCameraCfg,
+    BaseQuadWithFaceIDNormalCameraCfg,
     BaseQuadWithLidarCfg,
+    BaseQuadWithStereoCameraCfg,
 )
 from ..registry.robot_registry import robot_registry
 from .base_multirotor import BaseMultirotor
@@ -16,3 +18,5 @@ robot_registry.register("base_quadrotor_with_camera", BaseMultirotor, BaseQuadWi
 robot_registry.register("base_quadrotor_with_camera_64x48", BaseMultirotor, BaseQuadWithCamera64x48Cfg)
 robot_registry.register("base_quadrotor_with_lidar", BaseMultirotor, BaseQuadWithLidarCfg)
 robot_registry.register("base_octarotor_with_lidar_32x512", BaseMultirotor, BaseOctarotorWithLidar32x512Cfg)
+robot_registry.register("base_quadrotor_with_faceid_normal_camera", BaseMultirotor, BaseQuadWithFaceIDNormalCameraCfg)
+robot_registry.register("base_quadrotor_with_stereo_camera", BaseMultirotor, BaseQuadWithStereoCameraCfg)

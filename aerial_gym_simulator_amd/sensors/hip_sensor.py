@@ -1,6 +1,7 @@
-"""Ray-cast sensor front-end: WarpSensor + WarpCam + WarpLidar of the reference
-(sensors/warp/warp_sensor.py:83-249, warp_cam.py:31-182, warp_lidar.py:40-191) on the HIP
-kernels.  Capture = agx_sensor_pose -> agx_raycast_{camera,lidar} -> agx_sensor_postprocess."""
+"""Ray-cast sensor front-end: WarpSensor + WarpCam / WarpStereoCam / WarpLidar /
+WarpNormalFaceID{Cam,Lidar} of the reference (sensors/warp/warp_sensor.py:26-249, warp_cam.py:31-182,
+warp_stereo_cam.py, warp_lidar.py:40-191, warp_normal_faceID_{cam,lidar}.py) on the HIP kernels.
+Capture = agx_sensor_pose -> agx_raycast_{camera,stereo_camera,lidar} -> agx_sensor_postprocess[_points]."""
 import ctypes as C
 import math
 
@@ -9,7 +10,8 @@ import torch
 from .. import _lib
 from ..utils.math import quat_from_euler_xyz, quat_from_euler_xyz_tensor
 
-RAY_MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3}
+RAY_MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "normal": 4, "normal_world": 5}
+SENSOR_TYPES = ("camera", "stereo_camera", "lidar", "normal_faceID_camera", "normal_faceID_lidar")  # warp_sensor.py:36-81
 
 
 class HipSensor:
@@ -17,18 +19,25 @@ class HipSensor:
         self.cfg, self.num_envs, self.scene, self.device = sensor_config, num_envs, scene, device
         self.num_sensors = sensor_config.num_sensors
         cfg = sensor_config
-        if cfg.sensor_type not in ("camera", "lidar"):
-            raise NotImplementedError(f"sensor_type {cfg.sensor_type} is not supported yet (SURVEY f1)")
-        self.is_lidar = cfg.sensor_type == "lidar"
-        if self.is_lidar:
+        if cfg.sensor_type not in SENSOR_TYPES:
+            raise NotImplementedError(f"sensor_type {cfg.sensor_type}")  # like warp_sensor.py:80-81
+        self.is_lidar = cfg.sensor_type in ("lidar", "normal_faceID_lidar")
+        self.is_normal = cfg.sensor_type.startswith("normal_faceID")
+        self.is_stereo = cfg.sensor_type == "stereo_camera"
+        if self.is_normal:
+            # normals come as a "point cloud"; the segmentation image carries face indices
+            if not cfg.return_pointcloud:
+                raise ValueError("normal_faceID sensors need return_pointcloud = True (pixels are vec3)")
+            self.mode = RAY_MODE["normal_world" if cfg.normal_in_world_frame else "normal"]
+        elif cfg.return_pointcloud:
+            self.mode = RAY_MODE["pointcloud_world" if cfg.pointcloud_in_world_frame else "pointcloud"]
+        elif self.is_lidar:
             self.mode = RAY_MODE["range"]
-            if cfg.return_pointcloud:
-                self.mode = RAY_MODE["pointcloud_world" if cfg.pointcloud_in_world_frame else "pointcloud"]
-            self._init_ray_table()
         else:
             self.mode = RAY_MODE["depth" if cfg.calculate_depth else "range"]
-            if cfg.return_pointcloud:
-                self.mode = RAY_MODE["pointcloud_world" if cfg.pointcloud_in_world_frame else "pointcloud"]
+        if self.is_lidar:
+            self._init_ray_table()
+        else:
             self._init_intrinsics()
 
     # warp_cam.py:31-64
@@ -142,6 +151,14 @@ class HipSensor:
                                       p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
                 "agx_raycast_lidar",
             )
+        if self.is_stereo:
+            return _lib.check(
+                lib.agx_raycast_stereo_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), float(cfg.baseline),
+                                              self.c_x, self.c_y, self.mode, p(self.sensor_position), p(self.sensor_orientation),
+                                              p(sc.tri_world), p(sc.tri_seg), p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg,
+                                              stream),
+                "agx_raycast_stereo_camera",
+            )
         return _lib.check(
             lib.agx_raycast_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), self.c_x, self.c_y, self.mode,
                                    p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
@@ -150,37 +167,34 @@ class HipSensor:
         )
 
     def postprocess(self):
+        """apply_noise for every sensor type; apply_range_limits + normalize_observation only for
+        camera / lidar / stereo_camera (warp_sensor.py:197-200)."""
         env = self.g["env_manager"]
         lib, p, cfg = env._lib, _lib.dptr, self.cfg
-        if cfg.return_pointcloud:
-            self._postprocess_pointcloud()
-            return
         zn = ud = None
         sn = cfg.sensor_noise
         if sn.enable_sensor_noise:
             rs = self.g["random_source"]
             zn = p(rs.normal_into(self._noise_z, tag="sensor_noise_z"))
             ud = p(rs.rand_into(self._noise_u, tag="sensor_noise_u"))
+        elif self.is_normal or (cfg.return_pointcloud and cfg.pointcloud_in_world_frame):
+            return  # nothing to do: no noise, and these images are neither range-limited nor normalised
+        noise = (float(getattr(sn, "std_a", 0.0)), float(getattr(sn, "std_b", 0.0)), float(getattr(sn, "std_c", 0.0)),
+                 float(getattr(sn, "mean_offset", 0.0)), float(sn.pixel_dropout_prob))
+        limits = (float(cfg.min_range), float(cfg.max_range), float(cfg.far_out_of_range_value), float(cfg.near_out_of_range_value))
+        if cfg.return_pointcloud:
+            use_limits = not self.is_normal and not cfg.pointcloud_in_world_frame
+            _lib.check(
+                lib.agx_sensor_postprocess_points(self.pixels.numel() // 3, p(self.pixels), zn, ud, *noise, *limits,
+                                                  int(use_limits), int(bool(cfg.normalize_range)), env._stream()),
+                "agx_sensor_postprocess_points",
+            )
+            return
         _lib.check(
-            lib.agx_sensor_postprocess(self.pixels.numel(), p(self.pixels), zn, ud, float(getattr(sn, "std_a", 0.0)),
-                                       float(getattr(sn, "std_b", 0.0)), float(getattr(sn, "std_c", 0.0)),
-                                       float(getattr(sn, "mean_offset", 0.0)), float(sn.pixel_dropout_prob),
-                                       float(cfg.min_range), float(cfg.max_range), float(cfg.far_out_of_range_value),
-                                       float(cfg.near_out_of_range_value), int(bool(cfg.normalize_range)), env._stream()),
+            lib.agx_sensor_postprocess(self.pixels.numel(), p(self.pixels), zn, ud, *noise, *limits,
+                                       int(bool(cfg.normalize_range)), env._stream()),
             "agx_sensor_postprocess",
         )
-
-    def _postprocess_pointcloud(self):
-        """warp_sensor.py:202-227 point-cloud branch (rare path, kept in torch on device)."""
-        cfg = self.cfg
-        if cfg.pointcloud_in_world_frame:
-            return
-        nrm = self.pixels.norm(dim=4, keepdim=True).expand(-1, -1, -1, -1, 3)
-        self.pixels[nrm > cfg.max_range] = cfg.far_out_of_range_value
-        nrm = self.pixels.norm(dim=4, keepdim=True).expand(-1, -1, -1, -1, 3)
-        self.pixels[nrm < cfg.min_range] = cfg.near_out_of_range_value
-        if cfg.normalize_range:
-            self.pixels[:] = self.pixels / cfg.max_range
 
     def get_observation(self):
         return self.pixels, self.segmentation_pixels

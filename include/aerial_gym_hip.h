@@ -310,7 +310,13 @@ int agx_sensor_pose(const AgxEnvBuffers *buf, int num_envs, int num_sensors,
                     const float *local_pos, const float *local_quat, const float *frame_quat,
                     float *pos, float *quat, void *stream);
 
-enum { AGX_RAY_RANGE = 0, AGX_RAY_DEPTH = 1, AGX_RAY_POINTCLOUD = 2, AGX_RAY_POINTCLOUD_WORLD = 3 };
+enum {
+  AGX_RAY_RANGE = 0, AGX_RAY_DEPTH = 1, AGX_RAY_POINTCLOUD = 2, AGX_RAY_POINTCLOUD_WORLD = 3,
+  /* draw_optimized_kernel_normal_faceID (warp_camera_kernels.py:70-121, warp_lidar_kernels.py:90-126):
+   * pixels [..][3] = geometric normal of the hit face in the sensor / world frame (0 on a miss),
+   * seg = face index (-1 on a miss; tri_seg is not read)                                          */
+  AGX_RAY_NORMAL = 4, AGX_RAY_NORMAL_WORLD = 5
+};
 
 /* DepthCameraWarpKernels.draw_optimized_kernel_{depth_range,depth_range_segmentation,
  * pointcloud,pointcloud_segmentation} (warp_camera_kernels.py:176-282, 13-66, 125-172).
@@ -321,6 +327,16 @@ int agx_raycast_camera(int num_envs, int num_sensors, int width, int height, con
                        const float *cam_quat, const float *tri_world, const int32_t *tri_seg,
                        const float *nodes, int num_tris, float *pixels, int32_t *seg,
                        void *stream);
+
+/* StereoCameraWarpKernels.* (warp_stereo_camera_kernels.py:13-299): as agx_raycast_camera
+ * (modes 0..3), but a pixel is valid only if the stereo partner at cam_pos + R(cam_quat)
+ * (-baseline, 0, 0) also sees the hit point (second, any-hit ray from 0.999 t).  Occluded:
+ * -1 / seg -2; a missed ray whose far-plane point the partner sees: 1000, else -1.            */
+int agx_raycast_stereo_camera(int num_envs, int num_sensors, int width, int height,
+                              const float *kinv, float far_plane, float baseline, int c_x, int c_y,
+                              int mode, const float *cam_pos, const float *cam_quat,
+                              const float *tri_world, const int32_t *tri_seg, const float *nodes,
+                              int num_tris, float *pixels, int32_t *seg, void *stream);
 
 /* LidarWarpKernels.draw_optimized_kernel_{range,range_segmentation,pointcloud,
  * pointcloud_segmentation} (warp_lidar_kernels.py:167-194,130-163,13-86).
@@ -337,6 +353,15 @@ int agx_sensor_postprocess(size_t count, float *pixels, const float *z_normal,
                            float mean_offset, float dropout_prob, float min_range,
                            float max_range, float far_oor, float near_oor, int normalize,
                            void *stream);
+
+/* Point-cloud branch of the same three functions: pixels [count][3]; noise / dropout act on
+ * every component, the range limits on the point's norm (all three components replaced).
+ * limits = 0 for world-frame clouds, which the reference neither limits nor normalises.     */
+int agx_sensor_postprocess_points(size_t count, float *pixels, const float *z_normal,
+                                  const float *u_dropout, float std_a, float std_b, float std_c,
+                                  float mean_offset, float dropout_prob, float min_range,
+                                  float max_range, float far_oor, float near_oor, int limits,
+                                  int normalize, void *stream);
 
 /* NavigationTask.post_image_reward_addition's min over the image
  * (navigation_task.py:351-357): min_pixel[N] = min(10*img, with img<0 -> 10).          */

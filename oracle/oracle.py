@@ -282,7 +282,7 @@ def camera_kinv(width, height, hfov_deg):
     return np.array([1.0 / au, -u0 / au, 1.0 / av, -v0 / av], dtype=np.float32), int(u0), int(v0)
 
 
-MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3}
+MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "normal": 4, "normal_world": 5}
 
 
 def raycast_camera(width, height, kinv, far_plane, c_x, c_y, mode, cam_pos, cam_quat, tris, tri_seg,
@@ -296,6 +296,23 @@ def raycast_camera(width, height, kinv, far_plane, c_x, c_y, mode, cam_pos, cam_
     ts = np.ascontiguousarray(tri_seg, dtype=np.int32)
     lib().orc_raycast_camera(
         n, ns, width, height, _p(_f(kinv)), C.c_float(far_plane), c_x, c_y, m, _p(_f(cam_pos)),
+        _p(_f(cam_quat)), _p(_f(tris)), _p(ts), nt, int(use_bvh), _p(pixels), _p(seg),
+    )
+    return pixels, seg
+
+
+def raycast_stereo_camera(width, height, kinv, far_plane, baseline, c_x, c_y, mode, cam_pos, cam_quat, tris, tri_seg,
+                          want_seg=True, use_bvh=False):
+    """warp_stereo_camera_kernels.py: occlusion-checked depth / range / point cloud (mode 0..3)."""
+    n, ns = cam_pos.shape[0], cam_pos.shape[1]
+    nt = tris.shape[1]
+    m = MODE[mode] if isinstance(mode, str) else mode
+    shape = (n, ns, height, width) if m <= 1 else (n, ns, height, width, 3)
+    pixels = np.zeros(shape, np.float32)
+    seg = np.zeros((n, ns, height, width), np.int32) if want_seg else None
+    ts = np.ascontiguousarray(tri_seg, dtype=np.int32)
+    lib().orc_raycast_stereo_camera(
+        n, ns, width, height, _p(_f(kinv)), C.c_float(far_plane), C.c_float(baseline), c_x, c_y, m, _p(_f(cam_pos)),
         _p(_f(cam_quat)), _p(_f(tris)), _p(ts), nt, int(use_bvh), _p(pixels), _p(seg),
     )
     return pixels, seg
@@ -345,6 +362,19 @@ def sensor_postprocess(pixels, min_range, max_range, far_oor, near_oor, normaliz
         C.c_size_t(pixels.size), _p(pixels), _p(zn), _p(ud), C.c_float(std_a), C.c_float(std_b),
         C.c_float(std_c), C.c_float(mean_offset), C.c_float(dropout_prob), C.c_float(min_range),
         C.c_float(max_range), C.c_float(far_oor), C.c_float(near_oor), int(bool(normalize)),
+    )
+    return pixels
+
+
+def sensor_postprocess_points(pixels, min_range, max_range, far_oor, near_oor, limits, normalize, z_normal=None,
+                              u_dropout=None, std_a=0.0, std_b=0.0, std_c=0.0, mean_offset=0.0, dropout_prob=0.0):
+    assert pixels.dtype == np.float32 and pixels.flags["C_CONTIGUOUS"] and pixels.shape[-1] == 3
+    zn = _f(z_normal) if z_normal is not None else None
+    ud = _f(u_dropout) if u_dropout is not None else None
+    lib().orc_sensor_postprocess_points(
+        C.c_size_t(pixels.size // 3), _p(pixels), _p(zn), _p(ud), C.c_float(std_a), C.c_float(std_b),
+        C.c_float(std_c), C.c_float(mean_offset), C.c_float(dropout_prob), C.c_float(min_range),
+        C.c_float(max_range), C.c_float(far_oor), C.c_float(near_oor), int(bool(limits)), int(bool(normalize)),
     )
     return pixels
 

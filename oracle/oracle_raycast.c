@@ -44,6 +44,21 @@ static v3 v3_normalize(v3 a) {
   return r;
 }
 
+static v3 v3_sub(v3 a, v3 b) { v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static v3 v3_add(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+static v3 v3_scale(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }
+static v3 v3_div(v3 a, float s) { v3 r = {a.x / s, a.y / s, a.z / s}; return r; }
+static v3 v3_cross(v3 a, v3 b) {
+  v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return r;
+}
+/* geometric normal mesh_query_ray reports: normalize(cross(b - a, c - a)) of the hit face
+ * (warp intersect.h intersect_ray_tri_woop out_normal, mesh.h mesh_query_ray)          */
+static v3 face_normal(const float *tri) {
+  v3 a = {tri[0], tri[1], tri[2]}, b = {tri[3], tri[4], tri[5]}, c = {tri[6], tri[7], tri[8]};
+  return v3_normalize(v3_cross(v3_sub(b, a), v3_sub(c, a)));
+}
+
 /* warp quat.h quat_rotate(q, x):
  *   c = 2 w^2 - 1 ; d = 2 (q.xyz . x)
  *   x c + q.xyz d + (q.xyz X x) w 2                                        */
@@ -339,9 +354,106 @@ void orc_raycast_camera(int n, int ns, int width, int height, const float *kinv,
           int32_t sv = NO_HIT_SEG_VAL;
           float t;
           int f;
+          size_t px = (((size_t)i * ns + s) * height + y) * width + x;
+          if (mode >= 4) {
+            /* draw_optimized_kernel_normal_faceID (warp_camera_kernels.py:70-121): miss -> zero
+             * normal, face -1; 4 = camera frame spanned by rd_principal, 5 = world frame */
+            v3 nrm = {0.0f, 0.0f, 0.0f};
+            int32_t face = -1;
+            if (closest_hit(ro, rd, far_plane, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
+              nrm = face_normal(etris + 9 * f);
+              face = f;
+            }
+            if (mode == 4) {
+              v3 ez = {0.0f, 0.0f, 1.0f}, ey = {0.0f, 1.0f, 0.0f};
+              v3 o = {v3_dot(nrm, rdp), v3_dot(nrm, v3_cross(rdp, ez)), v3_dot(nrm, v3_cross(rdp, ey))};
+              nrm = o;
+            }
+            pixels[3 * px + 0] = nrm.x;
+            pixels[3 * px + 1] = nrm.y;
+            pixels[3 * px + 2] = nrm.z;
+            if (seg) seg[px] = face;
+            continue;
+          }
           if (closest_hit(ro, rd, max_t, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
             dist = (mode <= 1) ? mult * t : t;
             sv = tri_seg[(size_t)i * nt + f];
+          }
+          if (mode <= 1) {
+            pixels[px] = dist;
+          } else if (mode == 3) {
+            pixels[3 * px + 0] = ro.x + dist * rd.x;
+            pixels[3 * px + 1] = ro.y + dist * rd.y;
+            pixels[3 * px + 2] = ro.z + dist * rd.z;
+          } else {
+            pixels[3 * px + 0] = dist * uv.x;
+            pixels[3 * px + 1] = dist * uv.y;
+            pixels[3 * px + 2] = dist * uv.z;
+          }
+          if (seg) seg[px] = sv;
+        }
+    }
+    if (use_bvh) free(bvh.nodes);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* f1: stereo camera, warp_stereo_camera_kernels.py:13-299.  The pixel */
+/* is valid only if the hit point is also visible from the stereo      */
+/* partner at cam_pos + R(q) (-baseline, 0, 0): a second (any-hit) ray  */
+/* from 0.999 t along the first ray towards the partner.  Occluded ->  */
+/* -1 (INVALID_PIXEL_VAL), seg -2.  First ray misses: the far-plane     */
+/* point is tested the same way; visible -> 1000, else -1.              */
+/* mode: 0 range, 1 depth (uv NOT normalised, :188-189), 2/3 point      */
+/* cloud sensor/world frame (uv normalised, :43-46).                    */
+/* ------------------------------------------------------------------ */
+#define INVALID_PIXEL_VAL (-1.0f) /* warp_stereo_camera_kernels.py:3 */
+void orc_raycast_stereo_camera(int n, int ns, int width, int height, const float *kinv,
+                               float far_plane, float baseline, int c_x, int c_y, int mode,
+                               const float *cam_pos, const float *cam_quat, const float *tris,
+                               const int32_t *tri_seg, int nt, int use_bvh, float *pixels,
+                               int32_t *seg) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int i = 0; i < n; ++i) {
+    const float *etris = tris + (size_t)i * nt * 9;
+    OrcBvh bvh = {0, NULL};
+    if (use_bvh) bvh_build(&bvh, etris, nt);
+    const OrcBvh *bp = use_bvh ? &bvh : NULL;
+    for (int s = 0; s < ns; ++s) {
+      const float *cp = cam_pos + ((size_t)i * ns + s) * 3;
+      const float *cq = cam_quat + ((size_t)i * ns + s) * 4;
+      v3 ro = {cp[0], cp[1], cp[2]};
+      v3 off = {-baseline, 0.0f, 0.0f};
+      v3 partner = v3_add(ro, wp_quat_rotate(cq, off));
+      v3 uvp = {kinv[0] * (float)c_x + kinv[1], kinv[2] * (float)c_y + kinv[3], 1.0f};
+      if (mode >= 2) uvp = v3_normalize(uvp);
+      v3 rdp = v3_normalize(wp_quat_rotate(cq, uvp));
+      for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+          v3 uv = {kinv[0] * (float)x + kinv[1], kinv[2] * (float)y + kinv[3], 1.0f};
+          if (mode >= 2) uv = v3_normalize(uv);
+          v3 rd = v3_normalize(wp_quat_rotate(cq, uv));
+          float mult = 1.0f;
+          if (mode == 1) mult = v3_dot(rd, rdp);
+          float max_t = (mode <= 1) ? far_plane / mult : far_plane;
+          float dist = INVALID_PIXEL_VAL;
+          int32_t sv = NO_HIT_SEG_VAL;
+          float t, t2;
+          int f, f2;
+          if (closest_hit(ro, rd, max_t, etris, nt, bp, &t, &f)) {
+            v3 endpoint = v3_add(ro, v3_scale(v3_scale(rd, t), 0.999f)); /* ro + rd * t*0.999 */
+            v3 back = v3_sub(partner, endpoint);
+            float d2 = sqrtf(v3_dot(back, back));
+            if (!closest_hit(endpoint, v3_normalize(back), d2, etris, nt, bp, &t2, &f2)) {
+              dist = (mode <= 1) ? t * mult : t;
+              sv = tri_seg[(size_t)i * nt + f];
+            }
+          } else {
+            /* ro + rd * far_plane / multiplier (point clouds: no multiplier) */
+            v3 endpoint = (mode <= 1) ? v3_add(ro, v3_div(v3_scale(rd, far_plane), mult)) : v3_add(ro, v3_scale(rd, far_plane));
+            v3 back = v3_sub(partner, endpoint);
+            float d2 = sqrtf(v3_dot(back, back));
+            if (!closest_hit(endpoint, v3_normalize(back), d2, etris, nt, bp, &t2, &f2)) dist = NO_HIT_RAY_VAL;
           }
           size_t px = (((size_t)i * ns + s) * height + y) * width + x;
           if (mode <= 1) {
@@ -392,11 +504,30 @@ void orc_raycast_lidar(int n, int ns, int width, int height, const float *ray_ve
           int32_t sv = NO_HIT_SEG_VAL;
           float t;
           int f;
+          size_t px = (((size_t)i * ns + s) * height + y) * width + x;
+          if (mode >= 4) {
+            /* draw_optimized_kernel_normal_faceID (warp_lidar_kernels.py:90-126): 4 = sensor
+             * frame normalize(quat_rotate(quat_inverse(q), n)), 5 = world frame            */
+            v3 nrm = {0.0f, 0.0f, 0.0f};
+            int32_t face = -1;
+            if (closest_hit(ro, rd, far_plane, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
+              nrm = face_normal(etris + 9 * f);
+              face = f;
+            }
+            if (mode == 4) {
+              float qi[4] = {-lq[0], -lq[1], -lq[2], lq[3]};
+              nrm = v3_normalize(wp_quat_rotate(qi, nrm));
+            }
+            pixels[3 * px + 0] = nrm.x;
+            pixels[3 * px + 1] = nrm.y;
+            pixels[3 * px + 2] = nrm.z;
+            if (seg) seg[px] = face;
+            continue;
+          }
           if (closest_hit(ro, rd, far_plane, etris, nt, use_bvh ? &bvh : NULL, &t, &f)) {
             dist = t;
             sv = tri_seg[(size_t)i * nt + f];
           }
-          size_t px = (((size_t)i * ns + s) * height + y) * width + x;
           if (mode == 0) {
             pixels[px] = dist;
           } else if (mode == 3) {
@@ -437,5 +568,37 @@ void orc_sensor_postprocess(size_t count, float *pixels, const float *z_normal,
     if (p < min_range) p = near_oor;
     if (normalize) p = p / max_range;
     pixels[k] = p;
+  }
+}
+
+/* Point-cloud branch of WarpSensor.apply_noise / apply_range_limits / normalize_observation
+ * (warp_sensor.py:202-247): noise and dropout act on every component, the range limits on
+ * the point's norm (all three components replaced), `limits` = 0 for world-frame clouds
+ * (neither limited nor normalised, :203-205,223).  count = number of points.            */
+void orc_sensor_postprocess_points(size_t count, float *pixels, const float *z_normal,
+                                   const float *u_dropout, float std_a, float std_b, float std_c,
+                                   float mean_offset, float dropout_prob, float min_range,
+                                   float max_range, float far_oor, float near_oor, int limits,
+                                   int normalize) {
+  for (size_t k = 0; k < count; ++k) {
+    float v[3];
+    for (int c = 0; c < 3; ++c) {
+      float p = pixels[3 * k + c];
+      if (z_normal) {
+        float sd = std_a * (p * p) + std_b * p + std_c;
+        p = (p - mean_offset) + sd * z_normal[3 * k + c];
+        if (u_dropout && u_dropout[3 * k + c] < dropout_prob) p = near_oor;
+      }
+      v[c] = p;
+    }
+    if (limits) {
+      float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm > max_range) v[0] = v[1] = v[2] = far_oor;
+      nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (nrm < min_range) v[0] = v[1] = v[2] = near_oor;
+      if (normalize)
+        for (int c = 0; c < 3; ++c) v[c] = v[c] / max_range;
+    }
+    for (int c = 0; c < 3; ++c) pixels[3 * k + c] = v[c];
   }
 }

@@ -85,3 +85,91 @@ def test_postprocess_semantics(orc):
     assert np.allclose(out, [-1.0, 0.02, 0.5, 1.0, 1.0, 1.0])
     out = orc.sensor_postprocess(px.copy(), 0.2, 10.0, -1.0, -1.0, False)
     assert np.allclose(out, [-1.0, 0.2, 5.0, 10.0, -1.0, -1.0])  # far value -1 is then < min_range -> near value
+
+
+def _x_forward_camera(orc, W, H, hfov):
+    kinv, cx, cy = orc.camera_kinv(W, H, hfov)
+    frame = orc.quat_from_euler(np.deg2rad(np.array([[-90.0, 0.0, -90.0]], np.float32)))
+    return kinv, cx, cy, np.zeros((1, 1, 3), np.float32), frame.reshape(1, 1, 4)
+
+
+def test_normal_and_face_id_sensors(orc):
+    """warp_camera_kernels.py:70-121 / warp_lidar_kernels.py:90-126: geometric normal of the hit
+    face (cross(b-a, c-a) normalised: +x for this plate), zero vector and face -1 on a miss."""
+    tris, seg = _wall_scene()
+    W, H = 16, 12
+    kinv, cx, cy, pos, quat = _x_forward_camera(orc, W, H, 60.0)
+    _, s = orc.raycast_camera(W, H, kinv, 10.0, cx, cy, "pointcloud", pos, quat, tris, seg)  # same ray generation (:100-103)
+    hit = s[0, 0] != -2
+    nw, face = orc.raycast_camera(W, H, kinv, 10.0, cx, cy, "normal_world", pos, quat, tris, seg)
+    assert np.array_equal(nw[0, 0][hit], np.tile(np.float32([1, 0, 0]), (hit.sum(), 1)))
+    assert np.all(nw[0, 0][~hit] == 0.0) and np.all(face[0, 0][~hit] == -1)
+    assert np.array_equal(face[0, 0][hit], np.where(s[0, 0][hit] == 7, 0, 1))  # face index, not semantic id
+    # camera frame: (n . rd_p, n . (rd_p x e_z), n . (rd_p x e_y)) with rd_p = +x -> (1, 0, 0)
+    nc, _ = orc.raycast_camera(W, H, kinv, 10.0, cx, cy, "normal", pos, quat, tris, seg)
+    assert np.allclose(nc[0, 0][hit], [1, 0, 0], atol=1e-6) and np.all(nc[0, 0][~hit] == 0.0)
+    # LiDAR yawed by +90 deg looks along +y: the plate is seen by the rays pointing to sensor -y ... use a yaw of -30 deg
+    yaw = np.deg2rad(-30.0)
+    q = np.array([[[0, 0, np.sin(yaw / 2), np.cos(yaw / 2)]]], np.float32)
+    rv = orc.lidar_ray_table(5, 9, -40, 40, -10, 10)
+    r, s2 = orc.raycast_lidar(rv, 10.0, "range", pos, q, tris, seg)
+    hit2 = s2[0, 0] != -2
+    assert hit2.any() and (~hit2).any()
+    nw2, f2 = orc.raycast_lidar(rv, 10.0, "normal_world", pos, q, tris, seg)
+    assert np.array_equal(nw2[0, 0][hit2], np.tile(np.float32([1, 0, 0]), (hit2.sum(), 1))) and np.all(f2[0, 0][~hit2] == -1)
+    ns2, _ = orc.raycast_lidar(rv, 10.0, "normal", pos, q, tris, seg)  # world +x in the sensor frame = R(-yaw) e_x
+    assert np.allclose(ns2[0, 0][hit2], [np.cos(yaw), -np.sin(yaw), 0.0], atol=1e-6) and np.all(ns2[0, 0][~hit2] == 0.0)
+
+
+def test_stereo_occlusion_against_analytic_visibility(orc):
+    """warp_stereo_camera_kernels.py: wall at x = 3, a small occluder plate at x = 1.5; the stereo
+    partner sits `baseline` to the left of the camera (world +y).  Wall points the partner cannot
+    see are -1 / -2; missed rays whose far-plane point the partner cannot see are -1 too."""
+    a, b, c, d = [3, -1, -1], [3, 1, -1], [3, 1, 1], [3, -1, 1]
+    e, f_, g, h = [1.5, 0.3, -0.2], [1.5, 0.6, -0.2], [1.5, 0.6, 0.2], [1.5, 0.3, 0.2]
+    tris = np.array([[a + b + c, a + c + d, e + f_ + g, e + g + h]], np.float32)
+    seg = np.array([[7, 7, 5, 5]], np.int32)
+    W, H, hfov, far, base = 96, 72, 70.0, 10.0, 0.5
+    kinv, cx, cy, pos, quat = _x_forward_camera(orc, W, H, hfov)
+    depth, s = orc.raycast_stereo_camera(W, H, kinv, far, base, cx, cy, "depth", pos, quat, tris, seg)
+    mono, smono = orc.raycast_camera(W, H, kinv, far, cx, cy, "depth", pos, quat, tris, seg)
+    fpx = (W / 2) / np.tan(np.deg2rad(hfov / 2))
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    dy, dz = -(xs - W / 2) / fpx, -(ys - H / 2) / fpx  # ray = (1, dy, dz) t
+    m = 0.04  # skip pixels within 4 cm of an edge
+
+    def in_rect(y, z, y0, y1, z0, z1, margin):
+        return (y > y0 + margin) & (y < y1 - margin) & (z > z0 + margin) & (z < z1 - margin)
+
+    def classify(margin):
+        on_occ = in_rect(1.5 * dy, 1.5 * dz, 0.3, 0.6, -0.2, 0.2, margin)
+        on_wall = in_rect(3 * dy, 3 * dz, -1, 1, -1, 1, margin)
+        # wall point -> partner (0, base, 0): crosses x = 1.5 half way
+        wall_blocked = in_rect((3 * dy + base) / 2, 3 * dz / 2, 0.3, 0.6, -0.2, 0.2, margin)
+        # far-plane point (far, far dy, far dz) -> partner: crosses the wall plane at 30 %, the occluder plane at 15 %
+        far_blocked = in_rect(base + (far * dy - base) * 0.3, far * dz * 0.3, -1, 1, -1, 1, margin) | in_rect(
+            base + (far * dy - base) * 0.15, far * dz * 0.15, 0.3, 0.6, -0.2, 0.2, margin)
+        return on_occ, on_wall, wall_blocked, far_blocked
+
+    occ_in, wall_in, wblk_in, fblk_in = classify(m)
+    occ_out, wall_out, wblk_out, fblk_out = classify(-m)
+    D, S = depth[0, 0], s[0, 0]
+    sure_occ = occ_in
+    sure_wall_visible = wall_in & ~occ_out & ~wblk_out
+    sure_wall_hidden = wall_in & ~occ_out & wblk_in
+    sure_miss_visible = ~wall_out & ~occ_out & ~fblk_out
+    sure_miss_hidden = ~wall_out & ~occ_out & fblk_in
+    for mask in (sure_occ, sure_wall_visible, sure_wall_hidden, sure_miss_visible, sure_miss_hidden):
+        assert mask.sum() > 10
+    assert np.allclose(D[sure_occ], 1.5, rtol=1e-5) and np.all(S[sure_occ] == 5)
+    assert np.allclose(D[sure_wall_visible], 3.0, rtol=1e-5) and np.all(S[sure_wall_visible] == 7)
+    assert np.all(D[sure_wall_hidden] == -1.0) and np.all(S[sure_wall_hidden] == -2)
+    assert np.all(D[sure_miss_visible] == 1000.0) and np.all(D[sure_miss_hidden] == -1.0)
+    # wherever the stereo pixel is valid it equals the monocular pixel bit for bit
+    valid = D != -1.0
+    assert np.array_equal(D[valid], mono[0, 0][valid]) and np.array_equal(S[valid], smono[0, 0][valid])
+    # point-cloud variant: same validity pattern (range instead of depth), BVH == brute force
+    pc, spc = orc.raycast_stereo_camera(W, H, kinv, far, base, cx, cy, "pointcloud_world", pos, quat, tris, seg)
+    pcb, spcb = orc.raycast_stereo_camera(W, H, kinv, far, base, cx, cy, "pointcloud_world", pos, quat, tris, seg, use_bvh=True)
+    assert np.array_equal(pc, pcb) and np.array_equal(spc, spcb)
+    assert np.allclose(pc[0, 0][sure_wall_visible][:, 0], 3.0, rtol=1e-5) and np.all(spc[0, 0][sure_wall_hidden] == -2)
