@@ -70,3 +70,26 @@ top_wall = _wall("top_wall", [20.0, 20.0, 0.2], [0.5, 0.5, 1.0], TOP_WALL_SEMANT
 bottom_wall = _wall("bottom_wall", [20.0, 20.0, 0.2], [0.5, 0.5, 0.0], BOTTOM_WALL_SEMANTIC_ID)
 front_wall = _wall("front_wall", [0.2, 20.0, 20.0], [1.0, 0.5, 0.5], FRONT_WALL_SEMANTIC_ID)
 back_wall = _wall("back_wall", [0.2, 20.0, 20.0], [0.0, 0.5, 0.5], BACK_WALL_SEMANTIC_ID)
+
+
+# ---- env_with_lidar_nav_obstacles (config/asset_config/lidar_nav_env_config.py): the same URDF boxes, more of
+# them, spread over the whole (larger) env, and NOTHING is kept in the env unconditionally -- walls included:
+# the curriculum level decides how many of the shuffled assets stay (the rest is parked at -1000 m).
+class lidar_nav_panel_asset_params(panel_asset_params):  # lidar_nav_env_config.py:65-120
+    num_assets = 15
+    keep_in_env = False
+    min_state_ratio, max_state_ratio = _ratio([0.35, 0.0, 0.0], [1.0, 1.0, 1.0], (0, 0, -_PI / 3), (0, 0, _PI / 3))
+
+
+class lidar_nav_object_asset_params(object_asset_params):  # lidar_nav_env_config.py:273-312
+    num_assets = 70
+    keep_in_env = False
+    min_state_ratio, max_state_ratio = _ratio([0.30, 0.0, 0.0], [1.0, 1.0, 1.0], (-_PI,) * 3, (_PI,) * 3)
+
+
+def _free(wall):
+    return type("lidar_nav_" + wall.__name__, (wall,), dict(keep_in_env=False))  # lidar_nav_env_config.py:355-592
+
+
+lidar_nav_walls = {name: _free(w) for name, w in (("left_wall", left_wall), ("right_wall", right_wall), ("back_wall", back_wall),
+                                                  ("front_wall", front_wall), ("bottom_wall", bottom_wall), ("top_wall", top_wall))}

@@ -24,6 +24,19 @@ class lee_controller_config_octarotor:  # lee_controller_config_octarotor.py
     randomize_params = True
 
 
+class magpie_controller_config:  # magpie_controller_config.py:4-43
+    num_actions = 4
+    max_inclination_angle_rad = np.pi / 3.0
+    max_yaw_rate = np.pi / 3.0
+    K_pos_tensor_max, K_pos_tensor_min = [2.0, 2.0, 1.0], [2.0, 2.0, 1.0]
+    K_vel_tensor_max, K_vel_tensor_min = [3.3, 3.3, 2.6], [2.7, 2.7, 2.3]
+    K_rot_tensor_max = [12.9453125, 12.9453125, 0.32499998807907104]
+    K_rot_tensor_min = [8.9453125, 8.9453125, 0.32499998807907104]
+    K_angvel_tensor_max = [0.8910937666893005, 0.8910937666893005, 0.048818358927965164]
+    K_angvel_tensor_min = [0.65910937666893005, 0.65910937666893005, 0.028818358927965164]
+    randomize_params = True
+
+
 class fully_actuated_controller_config:  # fully_actuated_controller_rov.py
     num_actions = 7
     max_inclination_angle_rad = np.pi / 3.0

@@ -71,3 +71,16 @@ class EnvWithRandomBoxesCfg(EnvWithObstaclesCfg):
     class env_config:
         include_asset_type = dict({"boxes": True}, **{k: True for k in _WALLS})
         asset_type_to_dict_map = dict({"boxes": A.random_box_asset_params}, **_WALLS)
+
+
+class EnvWithLidarNavObstaclesCfg(EnvWithObstaclesCfg):
+    """env_with_lidar_nav_obstacles.py:20-82: 15 panels + 70 objects + 6 walls in a 10-15 m cube."""
+
+    class env(EnvWithObstaclesCfg.env):
+        lower_bound_min, lower_bound_max = [-7.50, -7.50, -5.0], [-5.0, -5.0, -3.0]
+        upper_bound_min, upper_bound_max = [5.0, 5.0, 3.0], [7.5, 7.5, 5.0]
+
+    class env_config:
+        include_asset_type = dict({"panels": True, "objects": True}, **{k: True for k in _WALLS})
+        asset_type_to_dict_map = dict({"panels": A.lidar_nav_panel_asset_params, "objects": A.lidar_nav_object_asset_params},
+                                      **A.lidar_nav_walls)

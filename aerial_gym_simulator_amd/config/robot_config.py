@@ -9,6 +9,7 @@ from .sensor_config import (
     BaseNormalFaceIDCameraConfig,
     DepthCamera64x48Config,
     Lidar32x512Config,
+    RSLidar_Airy_Config,
     StereoCameraConfig,
 )
 
@@ -203,3 +204,71 @@ class BaseOctarotorWithLidar32x512Cfg(BaseOctarotorCfg):
     class sensor_config(BaseOctarotorCfg.sensor_config):
         enable_lidar = True
         lidar_config = Lidar32x512Config
+
+
+class MagpieCfg:  # magpie_config.py:15-176, resources/robots/magpie/model.urdf
+    class init_config:
+        min_init_state = [0.1, 0.15, 0.15, 0, 0, -_PI, 1.0, -0.2, -0.2, -0.2, -0.2, -0.2, -0.2]
+        max_init_state = [0.2, 0.85, 0.85, 0, 0, _PI, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2]
+
+    class sensor_config:
+        enable_camera = False
+        camera_config = BaseDepthCameraConfig
+        enable_lidar = True
+        lidar_config = RSLidar_Airy_Config
+        enable_imu = False
+        imu_config = None
+
+    class disturbance:
+        enable_disturbance = True
+        prob_apply_disturbance = 0.05
+        max_force_and_torque_disturbance = [4.75, 4.75, 4.75, 0.03, 0.03, 0.03]
+
+    class damping:
+        linvel_linear_damping_coefficient = [0.0, 0.0, 0.0]
+        linvel_quadratic_damping_coefficient = [0.0, 0.0, 0.0]
+        angular_linear_damping_coefficient = [0.0, 0.0, 0.0]
+        angular_quadratic_damping_coefficient = [0.0, 0.0, 0.0]
+
+    class robot_asset(_CommonAsset):
+        file = "model.urdf"
+        name = "base_quadrotor"
+        collapse_fixed_joints = True  # the prop joints carry dont_collapse="true": 5 bodies remain
+        angular_damping = 0.01
+        linear_damping = 0.01
+        min_state_ratio, max_state_ratio = _state_ratio([0.1, 0.1, 0.1], [0.9, 0.9, 0.9], _PI)
+
+    class robot_model:  # model.urdf: base 1.2 kg + 4 props of 10 g at (+-0.1, +-0.1, 0)
+        base_mass = 1.2
+        base_inertia = [[0.013, 0, 0], [0, 0.014, 0], [0, 0, 0.013]]
+        # the URDF collision shape is a 0.7 x 0.7 x 0.5 box; the collision model here is a sphere (DESIGN.md
+        # "Collision"): radius = half the box width
+        collision_sphere_radius = 0.35
+        motor_mass = 0.01
+        motor_inertia = 0.000001
+        motor_xyz = [[0.1, 0.1, 0.0], [0.1, -0.1, 0.0], [-0.1, -0.1, 0.0], [-0.1, 0.1, 0.0]]
+        motor_rpy = [[0.0, 0.0, 0.0]] * 4
+
+    class control_allocator_config:
+        num_motors = 4
+        force_application_level = "base_link"  # not "motor_link": the combined wrench A u acts on the root link
+        application_mask = [1 + 4 + i for i in range(4)]
+        motor_directions = [1, -1, 1, -1]
+        allocation_matrix = [
+            [0.0, 0.0, 0.0, 0.0],
+            [0.0, 0.0, 0.0, 0.0],
+            [1.0, 1.0, 1.0, 1.0],
+            [-0.13, -0.13, 0.13, 0.13],
+            [-0.13, 0.13, 0.13, -0.13],
+            [-0.02, 0.02, -0.02, 0.02],
+        ]
+
+        class motor_model_config:
+            use_rps = True
+            motor_thrust_constant_min, motor_thrust_constant_max = 0.00000926312, 0.00001826312
+            motor_time_constant_increasing_min, motor_time_constant_increasing_max = 0.01, 0.02
+            motor_time_constant_decreasing_min, motor_time_constant_decreasing_max = 0.005, 0.015
+            max_thrust, min_thrust = 12.0, 0.1
+            max_thrust_rate = 1000000.0
+            thrust_to_torque_ratio = 0.02
+            use_discrete_approximation = True

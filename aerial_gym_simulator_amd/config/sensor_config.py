@@ -90,6 +90,27 @@ class Lidar32x512Config(BaseLidarConfig):
         enable_sensor_noise = False
 
 
+class RSLidar_Airy_Config(BaseLidarConfig):  # rslidar_airy_config.py:4-35 (dome LiDAR of the LiDAR-navigation task)
+    height, width = 48, 120
+    horizontal_fov_deg_min, horizontal_fov_deg_max = -180, 180
+    vertical_fov_deg_min, vertical_fov_deg_max = 0, 90
+    max_range, min_range = 10.0, 0.2
+    return_pointcloud = True
+    segmentation_camera = False
+    normalize_range = False
+    pointcloud_in_world_frame = True
+    far_out_of_range_value, near_out_of_range_value = _oor(max_range, normalize_range)
+    randomize_placement = True
+    min_translation = max_translation = [-0.05, 0.0, 0.0]
+    min_euler_rotation_deg = max_euler_rotation_deg = [0.0, -90.0, 0.0]  # front-mounted dome, looking up -> forward
+
+    class sensor_noise:
+        enable_sensor_noise = False
+        std_a, std_b, std_c = 0.00038089, -0.00343351, 0.01553284
+        mean_offset = -0.025
+        pixel_dropout_prob = 0.0
+
+
 class BaseNormalFaceIDLidarConfig(BaseLidarConfig):
     """sensor_type the reference's WarpSensor accepts (warp_sensor.py:63-70) without shipping a config."""
 

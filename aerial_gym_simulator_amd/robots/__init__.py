@@ -8,6 +8,7 @@ from ..config.robot_config import (
     BaseQuadWithFaceIDNormalCameraCfg,
     BaseQuadWithLidarCfg,
     BaseQuadWithStereoCameraCfg,
+    MagpieCfg,
 )
 from ..registry.robot_registry import robot_registry
 from .base_multirotor import BaseMultirotor
@@ -20,3 +21,4 @@ robot_registry.register("base_quadrotor_with_lidar", BaseMultirotor, BaseQuadWit
 robot_registry.register("base_octarotor_with_lidar_32x512", BaseMultirotor, BaseOctarotorWithLidar32x512Cfg)
 robot_registry.register("base_quadrotor_with_faceid_normal_camera", BaseMultirotor, BaseQuadWithFaceIDNormalCameraCfg)
 robot_registry.register("base_quadrotor_with_stereo_camera", BaseMultirotor, BaseQuadWithStereoCameraCfg)
+robot_registry.register("magpie", BaseMultirotor, MagpieCfg)

@@ -35,6 +35,8 @@ def composite_body(model):
     mass = float(model.base_mass) + m_motor * len(xyz)
     com = (m_motor * xyz.sum(axis=0)) / mass
     inertia = np.asarray(model.base_inertia, dtype=np.float64).copy()
+    # the motor links' own (diagonal) inertia, when the URDF gives one: rotated frames do not matter for k * I
+    inertia += len(xyz) * float(getattr(model, "motor_inertia", 0.0)) * np.eye(3)
     # base link sits at the origin; shift it and every motor to the common COM
     for m, r in [(float(model.base_mass), np.zeros(3))] + [(m_motor, p) for p in xyz]:
         d = r - com
@@ -84,7 +86,7 @@ def robot_params_dict(robot_cfg, controller_cfg, controller_kind, sim_cfg):
         num_motors=M,
         num_actions=num_actions,
         controller=controller_kind,
-        root_link_mode=int(ca.force_application_level == "root_link"),
+        root_link_mode=int(ca.force_application_level != "motor_link"),  # control_allocation.py:53-65: anything else = root wrench
         dt=float(sim_cfg.sim.dt),
         gravity=[float(g) for g in sim_cfg.sim.gravity],
         mass=float(np.float32(mass)),

@@ -379,6 +379,39 @@ def sensor_postprocess_points(pixels, min_range, max_range, far_oor, near_oor, l
     return pixels
 
 
+# ----------------------------------------------------------------------------- f2: LiDAR navigation task
+def reward_lidar_navigation(pos_err, vveh, wbody, yaw_error, crashes, action, prev_action, ttc, curriculum_progress, rp):
+    n = pos_err.shape[0]
+    reward = np.zeros(n, np.float32)
+    cr = np.ascontiguousarray(crashes, dtype=np.uint8)
+    lib().orc_reward_lidar_navigation(n, _p(_f(pos_err)), _p(_f(vveh)), _p(_f(wbody)), _p(_f(yaw_error)), _p(cr), _p(_f(action)),
+                                      _p(_f(prev_action)), _p(_f(ttc)), C.c_float(curriculum_progress), _p(_f(rp)), _p(reward))
+    return reward
+
+
+def lidar_image_obs(pointcloud, robot_pos, robot_linvel, ph=3, pw=6, low_row0=10, noise_mask=None, noise_val=None, max_mask=None,
+                    low_mask=None, low_val=None):
+    """pointcloud [N,H,W,3] -> (time_to_collision [N], inverse min-pooled range [N, (H/ph)*(W/pw)]).
+    low_mask / low_val: [N, H/ph, W/pw] (only rows >= low_row0 are read)."""
+    n, H, W = pointcloud.shape[0], pointcloud.shape[1], pointcloud.shape[2]
+    ttc = np.zeros(n, np.float32)
+    ds = np.zeros((n, (H // ph) * (W // pw)), np.float32)
+    opt = [(_f(a) if a is not None else None) for a in (noise_mask, noise_val, max_mask, low_mask, low_val)]
+    lib().orc_lidar_image_obs(n, H, W, ph, pw, low_row0, _p(_f(pointcloud)), _p(_f(robot_pos)), _p(_f(robot_linvel)),
+                              *[_p(a) for a in opt], _p(ttc), _p(ds))
+    return ttc, ds
+
+
+def obs_lidar_navigation(state, euler, qveh, vbody, wbody, actions, target, target_yaw, u_vec, u_euler, downsampled):
+    n, cells = state.shape[0], downsampled.shape[1]
+    obs = np.zeros((n, 17 + cells), np.float32)
+    a = _f(actions)
+    lib().orc_obs_lidar_navigation(n, _p(_f(state)), _p(_f(euler)), _p(_f(qveh)), _p(_f(vbody)), _p(_f(wbody)), _p(a), a.shape[1],
+                                   _p(_f(target)), _p(_f(target_yaw)), _p(_f(u_vec)), _p(_f(u_euler)), _p(_f(downsampled)), cells,
+                                   _p(obs))
+    return obs
+
+
 # ----------------------------------------------------------------------------- device-RNG restatement
 RNG_BOUNDS, RNG_STATE, RNG_GAINS, RNG_MOTOR, RNG_ASSET_SEL, RNG_ASSETS = 0, 1, 2, 3, 4, 16
 

@@ -20,6 +20,7 @@
 #include "oracle_types.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define ORC_PI_F 3.14159274101257324f /* float(torch.pi) */
@@ -802,5 +803,126 @@ void orc_obs_navigation(int n, const float *state, const float *euler, const flo
           if (17 + cell < obs_dim) o[17 + cell] = m;
         }
     }
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* f2: LiDAR navigation task, task/lidar_navigation_task/              */
+/*     lidar_navigation_task.py                                        */
+/* ------------------------------------------------------------------ */
+
+/* compute_reward (:554-719).  rp: 22 parameters in the order of
+ * lidar_navigation_task_config.py:30-53; all arrays row-major [N,*].   */
+void orc_reward_lidar_navigation(int n, const float *pos_err, const float *vveh, const float *wbody,
+                                 const float *yaw_error, const uint8_t *crashes, const float *action,
+                                 const float *prev_action, const float *ttc, float curriculum_progress,
+                                 const float *rp, float *reward) {
+  const float mult = (float)(1.0 + 2.0 * (double)curriculum_progress);
+  const float cpf = curriculum_progress;
+  for (int i = 0; i < n; ++i) {
+    const float *pe = pos_err + 3 * i, *v = vveh + 3 * i, *a = action + 4 * i, *pa = prev_action + 4 * i;
+    float dist = sqrtf(pe[0] * pe[0] + pe[1] * pe[1] + pe[2] * pe[2]);
+    float pos_reward = exp_reward(rp[0], rp[1], dist);
+    float very_close = exp_reward(rp[2], rp[3], dist);
+    float vel_norm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float vd[3], ug[3];
+    for (int k = 0; k < 3; ++k) { vd[k] = v[k] / (vel_norm + 1e-6f); ug[k] = pe[k] / (dist + 1e-6f); }
+    float reasonable_vel = exp_reward(2.0f, 2.0f, vel_norm - 2.0f);
+    float vdc = vd[0] * ug[0] + vd[1] * ug[1] + vd[2] * ug[2];
+    float near = dist / 3.0f;
+    if (near > 1.0f) near = 1.0f;
+    float vdc_reward = ((vdc > 0.0f) ? rp[4] * vdc * reasonable_vel : -0.2f) * near;
+    float over = vel_norm - 3.0f;
+    if (over < 0.0f) over = 0.0f;
+    float vel_mag_pen = exp_penalty(2.0f, 2.0f, over);
+    float close_to_goal = 1.0f - exp_reward(1.0f, 2.0f, dist);
+    float vx = v[0] < 0.0f ? 0.0f : v[0];
+    float neg_x_pen = exp_penalty(2.0f, 8.0f, vx) * close_to_goal;
+    float vel_pen = vel_mag_pen + neg_x_pen;
+    float low_vel = exp_reward(1.5f, 10.0f, vel_norm) + exp_reward(1.5f, 0.5f, vel_norm);
+    float ye = yaw_error[i];
+    float correct_yaw = exp_reward(2.0f, 0.2f, ye) + exp_reward(4.0f, 15.0f, ye);
+    float alignment = exp_reward(1.0f, 2.0f, ye);
+    float low_angvel = exp_reward(1.5f, 5.0f, wbody[3 * i + 2]) * alignment;
+    float stable = (dist < 1.0f) ? (low_vel + correct_yaw + low_angvel) : 0.0f;
+    float dist_reward = (20.0f - dist) / 20.0f;
+    float diff_pen = exp_penalty(rp[5], rp[6], a[0] - pa[0]) + exp_penalty(rp[7], rp[8], a[1] - pa[1]) +
+                     exp_penalty(rp[9], rp[10], a[2] - pa[2]) + exp_penalty(rp[11], rp[12], a[3] - pa[3]);
+    float abs_pen = cpf * exp_penalty(rp[13], rp[14], a[0]) + cpf * exp_penalty(rp[17], rp[18], a[2]) +
+                    cpf * exp_penalty(rp[19], rp[20], a[3]) + cpf * exp_penalty(rp[15], rp[16], a[1]);
+    float total_pen = diff_pen + abs_pen;
+    float t2 = ttc[i] * ttc[i];
+    float ttc_pen = exp_reward(-3.0f, 2.0f, t2);
+    float r = mult * (pos_reward + very_close * alignment + vdc_reward + dist_reward + stable + vel_pen + total_pen + ttc_pen);
+    if (crashes[i]) r = rp[21];
+    reward[i] = r;
+  }
+}
+
+/* process_image_observation (:313-363) + add_noise_to_downsampled_lidar_data (:281-310).
+ * pointcloud [N][H][W][3] world frame; ranges clipped to 10 outside [0.2, 10]; time to collision
+ * from the velocity component along each ray; ph x pw min-pooling; optional noise tensors
+ * ([N][H/ph][W/pw] each; low_* only used for rows >= low_row0, like ds[:, 10:]); inverse range. */
+void orc_lidar_image_obs(int n, int H, int W, int ph, int pw, int low_row0, const float *pointcloud,
+                         const float *robot_pos, const float *robot_linvel, const float *noise_mask,
+                         const float *noise_val, const float *max_mask, const float *low_mask,
+                         const float *low_val, float *ttc_out, float *ds_out) {
+  const int oh = H / ph, ow = W / pw;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    float *rng = (float *)malloc(sizeof(float) * (size_t)H * W);
+    const float *p = robot_pos + 3 * i, *lv = robot_linvel + 3 * i;
+    float tmin = INFINITY;
+    for (int j = 0; j < H * W; ++j) {
+      const float *pc = pointcloud + ((size_t)i * H * W + j) * 3;
+      float d[3] = {pc[0] - p[0], pc[1] - p[1], pc[2] - p[2]};
+      float r = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      float u[3] = {d[0] / (r + 1e-6f), d[1] / (r + 1e-6f), d[2] / (r + 1e-6f)};
+      float rc = r;
+      if (rc > 10.0f) rc = 10.0f;
+      if (rc < 0.2f) rc = 10.0f;
+      rng[j] = rc;
+      float vc = lv[0] * u[0] + lv[1] * u[1] + lv[2] * u[2];
+      float t = (vc > 0.0f) ? rc / (vc + 1e-6f) : 10.0f;
+      if (t < tmin) tmin = t;
+    }
+    ttc_out[i] = tmin < 0.0f ? 0.0f : (tmin > 10.0f ? 10.0f : tmin);
+    for (int cy = 0; cy < oh; ++cy)
+      for (int cx = 0; cx < ow; ++cx) {
+        float m = INFINITY;
+        for (int y = cy * ph; y < (cy + 1) * ph; ++y)
+          for (int x = cx * pw; x < (cx + 1) * pw; ++x)
+            if (rng[y * W + x] < m) m = rng[y * W + x];
+        size_t c = (size_t)i * oh * ow + (size_t)cy * ow + cx;
+        if (noise_mask && noise_mask[c] == 1.0f) m += noise_val[c];
+        if (max_mask && max_mask[c] == 1.0f) m = 10.0f;
+        if (low_mask && cy >= low_row0 && low_mask[c] == 1.0f) m = low_val[c];
+        ds_out[c] = 1.0f / m;
+      }
+    free(rng);
+  }
+}
+
+/* process_obs_for_task (:440-470): obs [N][17 + cells] */
+void orc_obs_lidar_navigation(int n, const float *state, const float *euler, const float *qveh, const float *vbody,
+                              const float *wbody, const float *actions, int num_actions, const float *target,
+                              const float *target_yaw, const float *u_vec, const float *u_euler,
+                              const float *downsampled, int cells, float *obs) {
+  for (int i = 0; i < n; ++i) {
+    const float *p = state + 13 * i;
+    float d[3] = {target[3 * i] - p[0], target[3 * i + 1] - p[1], target[3 * i + 2] - p[2]};
+    float v[3];
+    quat_rotate_inverse(qveh + 4 * i, d, v);
+    float dist = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float *o = obs + (size_t)i * (17 + cells);
+    for (int k = 0; k < 3; ++k) o[k] = (v[k] + 0.2f * (u_vec[3 * i + k] - 0.5f)) / dist;  /* 0.1 * 2 * (rand - 0.5) */
+    o[3] = dist;
+    float e0 = ssa(euler[3 * i]), e1 = ssa(euler[3 * i + 1]), e2 = ssa(euler[3 * i + 2]);
+    o[4] = e0 + 0.1f * (u_euler[3 * i] - 0.5f);
+    o[5] = e1 + 0.1f * (u_euler[3 * i + 1] - 0.5f);
+    o[6] = ssa(target_yaw[i] - e2);
+    for (int k = 0; k < 3; ++k) { o[7 + k] = vbody[3 * i + k]; o[10 + k] = wbody[3 * i + k]; }
+    for (int k = 0; k < 4; ++k) o[13 + k] = actions[num_actions * i + k];
+    for (int k = 0; k < cells; ++k) o[17 + k] = downsampled[(size_t)i * cells + k];
   }
 }
