@@ -207,6 +207,15 @@ _SIGNATURES = {
          C.c_float, C.c_int, C.c_int, _P],
     ),
     "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "agx_lidar_image_obs": (
+        C.c_int,
+        [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P],
+    ),
+    "agx_reward_lidar_navigation": (
+        C.c_int,
+        [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, _P, C.POINTER(C.c_float), C.c_float, _P, _P, C.c_int, C.c_int, _P, _P],
+    ),
+    "agx_obs_lidar_navigation": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())

@@ -91,3 +91,72 @@ class navigation_task_config:
         out[:, 2] = speed * torch.sin(max_inclination * a[:, 1]) * max_speed / 2.0
         out[:, 3] = a[:, 2] * max_yawrate
         return out
+
+
+class lidar_navigation_task_config:  # lidar_navigation_task_config.py:5-108
+    seed = -1
+    sim_name = "base_sim"
+    env_name = "env_with_lidar_nav_obstacles"
+    robot_name = "magpie"
+    controller_name = "magpie_acceleration_control"
+    args = {}
+    num_envs = 512
+    use_warp = True
+    headless = True
+    device = "cuda:0"
+    observation_space_dim = 13 + 4 + 16 * 20  # root state + actions + 3 x 6 min-pooled 48 x 120 LiDAR image
+    privileged_observation_space_dim = 0
+    action_space_dim = 4
+    episode_len_steps = 110
+    return_state_before_reset = False
+    target_min_ratio = [0.90, 0.15, 0.15]
+    target_max_ratio = [0.92, 0.80, 0.80]
+    lidar_pool = (3, 6)        # max_pool2d kernel of process_image_observation (:346-347)
+    lidar_low_noise_row0 = 10  # ds_lidar_data[:, 10:] (:302-308)
+
+    reward_parameters = {
+        "pos_reward_magnitude": 3.0,
+        "pos_reward_exponent": 1.0,
+        "very_close_to_goal_reward_magnitude": 5.0,
+        "very_close_to_goal_reward_exponent": 8.0,
+        "vel_direction_component_reward_magnitude": 1.0,
+        "x_action_diff_penalty_magnitude": 0.3,
+        "x_action_diff_penalty_exponent": 5.0,
+        "y_action_diff_penalty_magnitude": 0.3,
+        "y_action_diff_penalty_exponent": 5.0,
+        "z_action_diff_penalty_magnitude": 0.3,
+        "z_action_diff_penalty_exponent": 5.0,
+        "yawrate_action_diff_penalty_magnitude": 0.3,
+        "yawrate_action_diff_penalty_exponent": 5.0,
+        "x_absolute_action_penalty_magnitude": 0.1,
+        "x_absolute_action_penalty_exponent": 0.3,
+        "y_absolute_action_penalty_magnitude": 0.1,
+        "y_absolute_action_penalty_exponent": 0.3,
+        "z_absolute_action_penalty_magnitude": 0.15,
+        "z_absolute_action_penalty_exponent": 1.0,
+        "yawrate_absolute_action_penalty_magnitude": 0.15,
+        "yawrate_absolute_action_penalty_exponent": 2.0,
+        "collision_penalty": -10.0,
+    }
+    REWARD_PARAMETER_ORDER = tuple(reward_parameters.keys())
+
+    class vae_config:
+        use_vae = False
+
+    class curriculum:
+        min_level = 25
+        max_level = 70
+        check_after_log_instances = 2048
+        increase_step = 2
+        decrease_step = 1
+        success_rate_for_increase = 0.7
+        success_rate_for_decrease = 0.6
+
+    @staticmethod
+    def action_transformation_function(action):
+        """lidar_navigation_task_config.py:98-108: +-2 m/s^2 acceleration command, +-pi/3 rad/s yaw rate."""
+        a = torch.clamp(action, -1.0, 1.0)
+        out = torch.zeros((a.shape[0], 4), device=a.device)
+        out[:, 0:3] = 2 * a[:, 0:3]
+        out[:, 3] = a[:, 3] * (torch.pi / 3)
+        return out

@@ -67,7 +67,8 @@ class NavigationTask(BaseTask):
         self.task_obs = {"observations": torch.zeros((N, cfg.observation_space_dim), device=dev)}
         self.num_task_steps = 0
         self.infos = {}
-        self._rp = (C.c_float * 18)(*[float(cfg.reward_parameters[k]) for k in cfg.REWARD_PARAMETER_ORDER])
+        order = cfg.REWARD_PARAMETER_ORDER
+        self._rp = (C.c_float * len(order))(*[float(cfg.reward_parameters[k]) for k in order])
         self._u_vec = torch.zeros(N, 3, device=dev)
         self._u_euler = torch.zeros(N, 3, device=dev)
         self.curriculum_check_every = int(cfg.args.get("curriculum_check_every", 1)) if isinstance(cfg.args, dict) else 1

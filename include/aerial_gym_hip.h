@@ -216,6 +216,38 @@ int agx_obs_navigation(const AgxEnvBuffers *buf, int num_envs, const float *targ
                        int num_sensors, int height, int width, int grid_h, int grid_w,
                        int obs_dim, float *obs, void *stream);
 
+/* ---- LiDAR navigation task (task/lidar_navigation_task/lidar_navigation_task.py) -----------
+ * process_image_observation (:313-363) + add_noise_to_downsampled_lidar_data (:281-310):
+ * pointcloud [N][H][W][3] in the world frame (sensor 0) -> range = |p - robot_position| clipped to
+ * 10 outside [0.2, 10]; time_to_collision [N] = clamp(min over rays of range / (v . dir), 0, 10);
+ * pool_h x pool_w min-pooling; noise; downsampled [N][(H/pool_h) * (W/pool_w)] = 1 / range.
+ * Noise: device_noise = 0 and the five tensors ([N][cells]; 0/1 masks as floats, low_* only read
+ * for pooled rows >= low_row0; all may be NULL = no noise) reproduce the reference's torch draws;
+ * device_noise = 1 draws from the device generator (stream of env, buf->step_counter).          */
+int agx_lidar_image_obs(const AgxEnvBuffers *buf, int num_envs, int height, int width, int pool_h,
+                        int pool_w, int low_row0, const float *pointcloud, const float *noise_mask,
+                        const float *noise_val, const float *max_mask, const float *low_mask,
+                        const float *low_val, int device_noise, float *time_to_collision,
+                        float *downsampled, void *stream);
+
+/* compute_rewards_and_crashes + compute_reward (:472-719) + truncation / reset set (:399-403, like
+ * agx_reward_navigation).  action / prev_action: the task's transformed actions [N][4] row-major;
+ * rp: HOST pointer to the 22 reward parameters in the order of lidar_navigation_task_config.py:30-53;
+ * target [3][N], target_yaw [N], pos_err / prev_pos_err [3][N].                                  */
+int agx_reward_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
+                                const float *target_yaw, const float *action,
+                                const float *prev_action, const float *time_to_collision,
+                                const float *rp, float curriculum_progress, float *pos_err,
+                                float *prev_pos_err, int episode_len, int reset_on_collision,
+                                float *reward, void *stream);
+
+/* process_obs_for_task (:440-470): obs [N][17 + cells] = unit vector to target (+-0.1 noise) |
+ * distance | roll, pitch (+-0.05 noise) | yaw error | body lin/ang velocity | robot_actions(4) |
+ * downsampled.  u_vec / u_euler [N][3] U01 draws, or both NULL = device generator.              */
+int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
+                             const float *target_yaw, const float *u_vec, const float *u_euler,
+                             const float *downsampled, int cells, float *obs, void *stream);
+
 /* ---- reset ----------------------------------------------------------------------
  * Masked reset, in the order of EnvManager.reset_idx (env_manager.py:273-301):
  *   env bounds (IsaacGymEnv.reset_idx, IGE_env_manager.py:513-519), robot state
