@@ -115,6 +115,7 @@ class SceneManager:
         self.tri_seg = self.asset_semantic_id.to(torch.int32).repeat_interleave(12, dim=1).contiguous()
         self.boxes_soa = torch.zeros(K * 11, N, device=dev)
         self.bvh_nodes = torch.zeros(N, max(12 * K - 1, 1), 16, device=dev)
+        self.bvh_work = torch.zeros(N + 2, dtype=torch.int32, device=dev)  # dirty-env work list of agx_bvh_build
         g["scene_tri_world"] = self.tri_world
         g["scene_tri_seg"] = self.tri_seg
         g["scene_bvh_nodes"] = self.bvh_nodes

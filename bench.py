@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
-    ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar"])
+    ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar", "lidar_nav"])
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step")
@@ -58,6 +58,12 @@ def make_task(workload, num_envs, device, strict_rng, rank=0):
         cfg.device = device
         cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
         return task_registry.make_task("position_setpoint_task", seed=1 + rank, num_envs=num_envs, headless=True)
+    if workload == "lidar_nav":  # the reference's LiDAR-navigation recipe (magpie, 48 x 120 dome LiDAR, 337-D obs)
+        from aerial_gym_simulator_amd.config.task_config import lidar_navigation_task_config as lcfg
+
+        lcfg.device = device
+        lcfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
+        return task_registry.make_task("lidar_navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
     cfg = navigation_task_config
     cfg.device = device
     cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}  # rank: own scenes, RNG stream and semantic-id range
@@ -282,7 +288,8 @@ def main():
         "config": {
             "workload": {"dynamics": "base_quadrotor position_setpoint_task, lee_position_control, empty_env, 1 sub-step/step (BASELINE configs[1])",
                          "depth": "base_quadrotor navigation_task, lee_velocity_control, 100 random boxes + 6 walls, 10 sub-steps/step, 64x48 depth+seg camera (BASELINE configs[2])",
-                         "lidar": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes, 32x512 LiDAR range+seg (BASELINE configs[3])"}[args.workload],
+                         "lidar": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes, 32x512 LiDAR range+seg (BASELINE configs[3])",
+                         "lidar_nav": "magpie lidar_navigation_task, magpie_acceleration_control, env_with_lidar_nav_obstacles (91 assets), 48x120 world-frame point-cloud LiDAR, 10 sub-steps/step (SURVEY 8 f2)"}[args.workload],
             "num_envs_per_gpu": N,
             "num_envs_total": n_gpus * N,
             "sharding": (f"envs x{n_gpus}, 1 RCCL all_gather/step of [N, obs_dim+3] rows, "
