@@ -73,6 +73,7 @@ __device__ unsigned long long g_ray_stats[8];
 
 struct Ray {
   V3 o, d, rcp;
+  V3 orcp;    // o * rcp: the slab test is one fma per plane
   int kz;     // dominant axis
   bool swap;  // d[kz] < 0 : kx/ky swapped
   float Sx, Sy, Sz;
@@ -87,6 +88,7 @@ AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
   r.o = o;
   r.d = d;
   r.rcp = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  r.orcp = V3{o.x * r.rcp.x, o.y * r.rcp.y, o.z * r.rcp.z};
   float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
   int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
   int kx = kz == 2 ? 0 : kz + 1;
@@ -156,13 +158,18 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want)
   }
 }
 
-// conservative slab test (boxes are already grown by kBoxEps at build time)
+// Conservative slab test (boxes are already grown by kBoxEps = 1e-3 at build time).  t = b * rcp - o * rcp
+// as one fma per plane: its rounding error (<= 1 ulp of |b * rcp|, i.e. 6e-8 |b| in space units) is far
+// inside the 1e-3 growth for any |b| < 10 km, so culling stays conservative and the hit search stays
+// bit-identical to the brute-force loop.  A direction component that is exactly 0 makes both products
+// infinite and the fma NaN; fminf / fmaxf drop NaN operands, i.e. that axis' slab is not used for culling
+// (still conservative; at least one axis is finite because |d| = 1).
 AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tnear) {
-  float t0 = (lx - r.o.x) * r.rcp.x, t1 = (hx - r.o.x) * r.rcp.x;
+  float t0 = fmaf(lx, r.rcp.x, -r.orcp.x), t1 = fmaf(hx, r.rcp.x, -r.orcp.x);
   float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
-  t0 = (ly - r.o.y) * r.rcp.y; t1 = (hy - r.o.y) * r.rcp.y;
+  t0 = fmaf(ly, r.rcp.y, -r.orcp.y); t1 = fmaf(hy, r.rcp.y, -r.orcp.y);
   tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
-  t0 = (lz - r.o.z) * r.rcp.z; t1 = (hz - r.o.z) * r.rcp.z;
+  t0 = fmaf(lz, r.rcp.z, -r.orcp.z); t1 = fmaf(hz, r.rcp.z, -r.orcp.z);
   tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
   tmax *= 1.0000004f;
   tnear = tmin;

@@ -57,6 +57,11 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
 }
 
 // ------------------------------------------------------------------------------------ LBVH
+constexpr float kBvhLargeFraction = 0.75f;
+
+// obstacle parked outside the env by the curriculum (asset_manager.py:71 puts it at -1000 m)
+AGX_DEV bool tri_parked(const float *t) { return t[0] < -900.0f && t[1] < -900.0f && t[2] < -900.0f; }
+
 AGX_DEV uint32_t expand_bits10(uint32_t v) {
   v = (v * 0x00010001u) & 0xFF0000FFu;
   v = (v * 0x00000101u) & 0x0F00F00Fu;
@@ -74,7 +79,7 @@ AGX_DEV int delta_keys(const unsigned long long *keys, int nt, int i, int j) {
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] 0                     [12..14] hi_right [15] 0
 // child >= 0: internal node index, child < 0: leaf holding triangle ~child.
-AGX_DEV void bvh_build_env(int env, int nt, int npad, const float *__restrict__ tri_world, float *__restrict__ nodes) {
+AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   float *box = reinterpret_cast<float *>(keys + npad);                              // [(2nt-1)][6] internal then leaves
@@ -85,10 +90,38 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, const float *__restrict__ 
   const int tid = threadIdx.x;
   const float *tris = tri_world + (size_t)env * nt * 9;
 
-  // --- centroid bounds
+  // --- Morton grid = bounds of the sort centres of everything that is in the env.  Obstacles beyond the
+  // curriculum level are parked at -1000 m (asset_manager.py:71): letting them into the bounds would stretch
+  // the 10-bit grid over a kilometre.  With ppo > 0 the scene is a soup of K = nt / ppo objects of ppo
+  // consecutive triangles each (boxes: 12): the sort centre is the OBJECT's, so the triangles of an object
+  // stay together (their keys differ only in the index word) and the radix tree becomes a two-level
+  // hierarchy, objects on top.  Measured on the config-3 scene: 105 -> see profiles/r01_raycast_variants.txt.
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int f = tid; f < nt; f += kBvhThreads) {
+  float *ocen = reinterpret_cast<float *>(counter);  // [K][4] centre + largest extent (< 0: parked); counter is not live yet
+  const int K = ppo > 0 ? nt / ppo : 0;
+  for (int o = tid; o < K; o += kBvhThreads) {
+    const float *t = tris + (size_t)o * ppo * 9;
+    float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int v = 0; v < 3 * ppo; ++v)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        alo[c] = fminf(alo[c], t[3 * v + c]);
+        ahi[c] = fmaxf(ahi[c], t[3 * v + c]);
+      }
+    const bool parked = tri_parked(t);
+    float big = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float cen = 0.5f * (alo[c] + ahi[c]);
+      ocen[4 * o + c] = cen;
+      big = fmaxf(big, ahi[c] - alo[c]);
+      if (!parked) { lo[c] = fminf(lo[c], cen); hi[c] = fmaxf(hi[c], cen); }
+    }
+    ocen[4 * o + 3] = parked ? -1.0f : big;
+  }
+  for (int f = tid; f < nt && ppo <= 0; f += kBvhThreads) {
     const float *t = tris + (size_t)f * 9;
+    if (tri_parked(t)) continue;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float cen = (t[c] + t[3 + c] + t[6 + c]) * (1.0f / 3.0f);
@@ -117,20 +150,40 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, const float *__restrict__ 
   for (int c = 0; c < 3; ++c) {
     blo[c] = red[c * kBvhThreads];
     float ext = red[(3 + c) * kBvhThreads] - blo[c];
-    inv[c] = ext > 0.0f ? 1023.0f / ext : 0.0f;
+    inv[c] = (ext > 0.0f && ext < INFINITY) ? 1023.0f / ext : 0.0f;  // ext = -inf - inf when every primitive is parked
   }
-  // --- Morton keys (30-bit code | triangle index)
+  // --- keys: [large flag | 30-bit Morton code of the sort centre] . [triangle index]
+  float max_ext = fmaxf(fmaxf(red[3 * kBvhThreads] - blo[0], red[4 * kBvhThreads] - blo[1]), red[5 * kBvhThreads] - blo[2]);
   for (int f = tid; f < npad; f += kBvhThreads) {
     unsigned long long key = ~0ull;
     if (f < nt) {
       const float *t = tris + (size_t)f * 9;
       uint32_t code = 0;
+      float big = 0.0f;
+      bool parked;
+      if (ppo > 0) {
+        const float *oc = ocen + 4 * (f / ppo);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float cen = (t[c] + t[3 + c] + t[6 + c]) * (1.0f / 3.0f);
-        float qv = fminf(fmaxf((cen - blo[c]) * inv[c], 0.0f), 1023.0f);
-        code |= expand_bits10((uint32_t)qv) << (2 - c);
+        for (int c = 0; c < 3; ++c) {
+          float qv = fminf(fmaxf((oc[c] - blo[c]) * inv[c], 0.0f), 1023.0f);
+          code |= expand_bits10((uint32_t)qv) << (2 - c);
+        }
+        big = oc[3];
+        parked = big < 0.0f;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float cen = (t[c] + t[3 + c] + t[6 + c]) * (1.0f / 3.0f);
+          float qv = fminf(fmaxf((cen - blo[c]) * inv[c], 0.0f), 1023.0f);
+          code |= expand_bits10((uint32_t)qv) << (2 - c);
+          big = fmaxf(big, fmaxf(fmaxf(t[c], t[3 + c]), t[6 + c]) - fminf(fminf(t[c], t[3 + c]), t[6 + c]));
+        }
+        parked = tri_parked(t);
       }
+      // primitives larger than most of the obstacle field (the room's wall slabs) get their own subtree under
+      // the root: their huge boxes no longer inflate every level of the obstacle tree
+      if (big > kBvhLargeFraction * max_ext) code |= 1u << 30;
+      if (parked) code = 0xFFFFFFFEu;  // one subtree at the end of the order, culled at its root
       key = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)f;
     }
     keys[f] = key;
@@ -241,11 +294,11 @@ __global__ void __launch_bounds__(1024) k_compact_mask(int n, const uint8_t *__r
   }
 }
 
-__global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int npad, const float *__restrict__ tri_world,
+__global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int npad, int ppo, const float *__restrict__ tri_world,
                                                             int32_t *__restrict__ work, float *__restrict__ nodes) {
   if (!work) {  // every env
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
-      bvh_build_env(env, nt, npad, tri_world, nodes);
+      bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
       __syncthreads();  // LDS is reused by the next env
     }
     return;
@@ -258,7 +311,7 @@ __global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int np
     const int idx = next;
     __syncthreads();  // everybody has read `next` before thread 0 overwrites it; also fences LDS reuse
     if (idx >= count) break;
-    bvh_build_env(work[2 + idx], nt, npad, tri_world, nodes);
+    bvh_build_env(work[2 + idx], nt, npad, ppo, tri_world, nodes);
   }
 }
 
@@ -292,12 +345,14 @@ extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, co
 
 extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
 
-extern "C" int agx_bvh_build(int n, int nt, const float *tri_world, const uint8_t *mask, float *nodes, int32_t *work,
-                             void *stream) {
+extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *tri_world, const uint8_t *mask, float *nodes,
+                             int32_t *work, void *stream) {
   AGX_REQUIRE(n > 0, "bad num_envs");
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
   AGX_REQUIRE(tri_world && nodes, "null buffer");
   AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
+  AGX_REQUIRE(prims_per_object == 0 || (prims_per_object >= 4 && nt % prims_per_object == 0),
+              "prims_per_object must be 0 or >= 4 and divide num_tris");
   int npad = 1;
   while (npad < nt) npad <<= 1;
   size_t lds = bvh_lds_bytes(nt, npad);
@@ -312,7 +367,7 @@ extern "C" int agx_bvh_build(int n, int nt, const float *tri_world, const uint8_
   AGX_REQUIRE(lds <= 160 * 1024 - 256, "LBVH build needs %zu bytes of LDS (> 160 KiB)", lds);
   if (mask) hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
   const int grid = n < 512 ? n : 512;  // one resident workgroup per CU (LDS bound) x 2 to cover the tail
-  hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, tri_world,
-                     mask ? work : nullptr, nodes);
+  hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object,
+                     tri_world, mask ? work : nullptr, nodes);
   return check_launch("agx_bvh_build");
 }

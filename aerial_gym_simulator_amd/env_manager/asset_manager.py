@@ -73,5 +73,5 @@ class AssetManager:
         # (these three return immediately for envs whose mask is 0)
         _lib.check(lib.agx_scene_transform(N, sc.num_tris, K, p(sc.tri_local), p(sc.tri_asset), p(st), mk, p(sc.tri_world), stream),
                    "agx_scene_transform")
-        _lib.check(lib.agx_bvh_build(N, sc.num_tris, p(sc.tri_world), mk, p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
+        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), mk, p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
         _lib.check(lib.agx_boxes_from_assets(N, K, p(st), p(sc.half_extents), mk, p(sc.boxes_soa), stream), "agx_boxes_from_assets")

@@ -47,7 +47,9 @@ def parse():
     return ap.parse_args()
 
 
-def make_task(workload, num_envs, device, strict_rng, rank=0):
+def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all"):
+    """obstacles: "all" = every obstacle of the scene is in the env (BASELINE configs 3/4: 100 boxes + 6 walls);
+    "curriculum" = the task's own curriculum start (navigation_task_config.py: level 15 of 106)."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -65,6 +67,9 @@ def make_task(workload, num_envs, device, strict_rng, rank=0):
         lcfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
         return task_registry.make_task("lidar_navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
     cfg = navigation_task_config
+    if not hasattr(cfg, "_reference_curriculum"):
+        cfg._reference_curriculum = (cfg.curriculum.min_level, cfg.curriculum.max_level)
+    cfg.curriculum.min_level, cfg.curriculum.max_level = (106, 107) if obstacles == "all" else cfg._reference_curriculum
     cfg.device = device
     cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}  # rank: own scenes, RNG stream and semantic-id range
     if workload == "lidar":

@@ -326,11 +326,14 @@ int agx_scene_transform(int num_envs, int num_tris, int num_assets, const float 
  * A workgroup builds a binary LBVH over the T triangles of an env in LDS and stores
  * T-1 nodes of 16 floats each: [lo_l(3) child_l | hi_l(3) child_r | lo_r(3) pad | hi_r(3) pad],
  * child < 0 encodes a leaf: triangle index = ~child.
+ * prims_per_object > 0: the soup is made of objects of that many consecutive triangles (boxes:
+ * 12); the Morton order is then taken over object centres, which keeps an object's triangles
+ * together (two-level hierarchy).  0 = order by triangle centroid.
  * mask != NULL rebuilds only the flagged envs and needs `work` (int32[num_envs + 2], scratch):
  * the dirty env ids are compacted into it and a CU-sized persistent grid pulls from the list.   */
 size_t agx_bvh_nodes_bytes(int num_envs, int num_tris);
-int agx_bvh_build(int num_envs, int num_tris, const float *tri_world, const uint8_t *mask,
-                  float *nodes, int32_t *work, void *stream);
+int agx_bvh_build(int num_envs, int num_tris, int prims_per_object, const float *tri_world,
+                  const uint8_t *mask, float *nodes, int32_t *work, void *stream);
 
 /* Obstacle OBBs for the collision test, from the same asset poses:
  * boxes [K][11][N] <- asset_state [N][K][13], half_extents [N][K][3].                  */
