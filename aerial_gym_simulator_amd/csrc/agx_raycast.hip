@@ -72,8 +72,8 @@ __device__ unsigned long long g_ray_stats[8];
 #endif
 
 struct Ray {
-  V3 o, d, rcp;
-  V3 orcp;    // o * rcp: the slab test is one fma per plane
+  V3 o, d;
+  V3 rcp, orcp;  // 1 / d clamped to +-1e30, and o * rcp (slab test only; the triangle test uses d)
   int kz;     // dominant axis
   bool swap;  // d[kz] < 0 : kx/ky swapped
   float Sx, Sy, Sz;
@@ -87,7 +87,9 @@ AGX_DEV float pick(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
   r.o = o;
   r.d = d;
-  r.rcp = V3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+  const float kRcpMax = 1.0e30f;
+  r.rcp = V3{fminf(fmaxf(1.0f / d.x, -kRcpMax), kRcpMax), fminf(fmaxf(1.0f / d.y, -kRcpMax), kRcpMax),
+             fminf(fmaxf(1.0f / d.z, -kRcpMax), kRcpMax)};
   r.orcp = V3{o.x * r.rcp.x, o.y * r.rcp.y, o.z * r.rcp.z};
   float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
   int kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
@@ -158,12 +160,14 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want)
   }
 }
 
-// Conservative slab test (boxes are already grown by kBoxEps = 1e-3 at build time).  t = b * rcp - o * rcp
-// as one fma per plane: its rounding error (<= 1 ulp of |b * rcp|, i.e. 6e-8 |b| in space units) is far
-// inside the 1e-3 growth for any |b| < 10 km, so culling stays conservative and the hit search stays
-// bit-identical to the brute-force loop.  A direction component that is exactly 0 makes both products
-// infinite and the fma NaN; fminf / fmaxf drop NaN operands, i.e. that axis' slab is not used for culling
-// (still conservative; at least one axis is finite because |d| = 1).
+// Conservative slab test, one fma per plane: t = b * rcp - o * rcp, with rcp CLAMPED to +-1e30 in ray_setup.
+// Why this never culls a box that holds a hit (boxes are grown by kBoxEps = 1e-3 at build time; |coords| < 10 km):
+//   * |d_c| > 1e-30: the products are finite (|b| |rcp| < 1e34); the only new error vs (b - o) * rcp is the
+//     rounding of o * rcp, <= 6e-8 |o| in space units, far inside the 1e-3 growth.
+//   * |d_c| <= 1e-30 (incl. exactly 0, where 1/d = +-inf would give inf - inf = NaN or a wrong-signed inf --
+//     measured: occlusion rays with d_z == 0 lost their occluder, test_stereo_occlusion_ray_with_zero_direction_component):
+//     a hit at t <= max_t moves < 1e-26 along c, so the origin lies inside the un-grown slab up to that, i.e.
+//     >= 1e-3 inside the grown one; b * 1e30 - o * 1e30 then has the right sign and magnitude >= 1e27 > any max_t.
 AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tnear) {
   float t0 = fmaf(lx, r.rcp.x, -r.orcp.x), t1 = fmaf(hx, r.rcp.x, -r.orcp.x);
   float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);

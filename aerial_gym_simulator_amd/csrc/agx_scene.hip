@@ -97,7 +97,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   // stay together (their keys differ only in the index word) and the radix tree becomes a two-level
   // hierarchy, objects on top.  Measured on the config-3 scene: 105 -> see profiles/r01_raycast_variants.txt.
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  float *ocen = reinterpret_cast<float *>(counter);  // [K][4] centre + largest extent (< 0: parked); counter is not live yet
+  float *ocen = reinterpret_cast<float *>(counter);  // [K][8] centre, largest extent (< 0: parked), AABB lo, -; counter is not live yet
   const int K = ppo > 0 ? nt / ppo : 0;
   for (int o = tid; o < K; o += kBvhThreads) {
     const float *t = tris + (size_t)o * ppo * 9;
@@ -113,11 +113,12 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float cen = 0.5f * (alo[c] + ahi[c]);
-      ocen[4 * o + c] = cen;
+      ocen[8 * o + c] = cen;
+      ocen[8 * o + 4 + c] = alo[c];
       big = fmaxf(big, ahi[c] - alo[c]);
       if (!parked) { lo[c] = fminf(lo[c], cen); hi[c] = fmaxf(hi[c], cen); }
     }
-    ocen[4 * o + 3] = parked ? -1.0f : big;
+    ocen[8 * o + 3] = parked ? -1.0f : big;
   }
   for (int f = tid; f < nt && ppo <= 0; f += kBvhThreads) {
     const float *t = tris + (size_t)f * 9;
@@ -162,7 +163,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       float big = 0.0f;
       bool parked;
       if (ppo > 0) {
-        const float *oc = ocen + 4 * (f / ppo);
+        const float *oc = ocen + 8 * (f / ppo);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float qv = fminf(fmaxf((oc[c] - blo[c]) * inv[c], 0.0f), 1023.0f);
@@ -351,8 +352,8 @@ extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *t
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
   AGX_REQUIRE(tri_world && nodes, "null buffer");
   AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
-  AGX_REQUIRE(prims_per_object == 0 || (prims_per_object >= 4 && nt % prims_per_object == 0),
-              "prims_per_object must be 0 or >= 4 and divide num_tris");
+  AGX_REQUIRE(prims_per_object == 0 || (prims_per_object >= 9 && nt % prims_per_object == 0),
+              "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;
   while (npad < nt) npad <<= 1;
   size_t lds = bvh_lds_bytes(nt, npad);

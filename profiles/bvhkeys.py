@@ -3,11 +3,11 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIBS = {k: os.path.join(ROOT, "aerial_gym_simulator_amd", "lib", f"libagx_var_bvhkey{k}.so") for k in (0, 12)}  # k = prims per object
+LIBS = {k: os.path.join(ROOT, "aerial_gym_simulator_amd", "lib", f"libagx_var_bvhkey{k}.so") for k in (0, 1)}  # k = AGX_BVH_SUBKEY
 if sys.argv[1] == "build":
     from aerial_gym_simulator_amd import _build
     for k, path in LIBS.items():
-        print(_build.build_library(extra_flags=["-DAGX_RAY_STATS"], lib_path=path))
+        print(_build.build_library(extra_flags=["-DAGX_RAY_STATS", f"-DAGX_BVH_SUBKEY={k}"], lib_path=path))
 elif sys.argv[1] == "run":
     import subprocess
     for k in LIBS:
@@ -19,7 +19,7 @@ else:
     import torch, bench
     n = 1024
     from aerial_gym_simulator_amd.env_manager.env_manager import EnvManager
-    EnvManager.bvh_prims_per_object = k
+    EnvManager.bvh_prims_per_object = 12
     t = bench.make_task(wl.split("@")[0], n, "cuda:0", False, obstacles="curriculum" if "@" in wl else "all"); t.reset()
     print("obstacles in env:", t.obs_dict["num_obstacles_in_env"], end="  ")
     lib = ctypes.CDLL(LIBS[k])
