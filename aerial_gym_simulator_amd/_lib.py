@@ -94,6 +94,24 @@ class AgxEnvBuffers(C.Structure):
         ("num_boxes", C.c_int32),
         ("step_rows", C.c_void_p * 2),
         ("step_reward", C.c_void_p),
+        ("body_force", C.c_void_p),
+    ]
+
+
+class AgxImuArgs(C.Structure):
+    _fields_ = [
+        ("bias_std", C.c_float * 6),
+        ("noise_std", C.c_float * 6),
+        ("max_value", C.c_float * 6),
+        ("max_bias_init", C.c_float * 6),
+        ("min_rot", C.c_float * 3),
+        ("max_rot", C.c_float * 3),
+        ("g_world", C.c_float * 3),
+        ("sqrt_dt", C.c_float),
+        ("mass", C.c_float),
+        ("world_frame", C.c_int32),
+        ("enable_noise", C.c_int32),
+        ("enable_bias", C.c_int32),
     ]
 
 
@@ -207,6 +225,8 @@ _SIGNATURES = {
          C.c_float, C.c_int, C.c_int, _P],
     ),
     "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "agx_imu_update": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxImuArgs), _P, _P, _P, _P, _P, _P]),
+    "agx_imu_reset": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxImuArgs), _P, _P, _P, _P, _P]),
     "agx_lidar_image_obs": (
         C.c_int,
         [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P],

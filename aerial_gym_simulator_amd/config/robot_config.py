@@ -5,6 +5,7 @@ import numpy as np
 
 from .sensor_config import (
     BaseDepthCameraConfig,
+    BaseImuConfig,
     BaseLidarConfig,
     BaseNormalFaceIDCameraConfig,
     DepthCamera64x48Config,
@@ -113,6 +114,20 @@ class BaseQuadWithCamera64x48Cfg(BaseQuadCfg):
     class sensor_config(BaseQuadCfg.sensor_config):
         enable_camera = True
         camera_config = DepthCamera64x48Config
+
+
+class BaseQuadWithImuCfg(BaseQuadCfg):  # base_quad_config.py:196-199
+    class sensor_config(BaseQuadCfg.sensor_config):
+        enable_imu = True
+        imu_config = BaseImuConfig
+
+
+class BaseQuadWithCameraImuCfg(BaseQuadCfg):  # base_quad_config.py:207-213
+    class sensor_config(BaseQuadCfg.sensor_config):
+        enable_camera = True
+        camera_config = BaseDepthCameraConfig
+        enable_imu = True
+        imu_config = BaseImuConfig
 
 
 class BaseQuadWithLidarCfg(BaseQuadCfg):

@@ -120,3 +120,17 @@ class BaseNormalFaceIDLidarConfig(BaseLidarConfig):
 
     class sensor_noise(BaseLidarConfig.sensor_noise):
         enable_sensor_noise = False
+
+
+class BaseImuConfig(BaseSensorConfig):  # imu_config/base_imu_config.py:4-62 (a VN100-like IMU)
+    sensor_type = "imu"
+    world_frame = False
+    enable_noise = True
+    enable_bias = True
+    bias_std = [9.782812831313576e-07] * 3 + [2.6541629581345176e-05] * 3
+    imu_noise_std = [0.001688956233495657] * 3 + [0.0010679343003532472] * 3
+    max_measurement_value = [100.0, 100.0, 100.0, 10.0, 10.0, 10.0]
+    max_bias_init_value = [1.0e-03] * 6
+    gravity_compensation = False
+    randomize_placement = False
+    min_euler_rotation_deg, max_euler_rotation_deg = [-2.0, -2.0, -2.0], [2.0, 2.0, 2.0]

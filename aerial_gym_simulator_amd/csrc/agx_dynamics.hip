@@ -486,6 +486,9 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
           bw[c] += ((hi - lo) * ud[1 + c] + lo) * occ;
         }
       }
+      if (B.body_force && sub == k - 1) {  // what the IMU's force sensor sees (agx_imu_update)
+        B.body_force[0 * n + i] = bw[0]; B.body_force[1 * n + i] = bw[1]; B.body_force[2 * n + i] = bw[2];
+      }
       integrate(P, s, V3{bw[0], bw[1], bw[2]}, V3{bw[3], bw[4], bw[5]});
       if (B.boxes) {
         traj[(sub * 3 + 0) * bd + tid] = s.p.x;

@@ -27,6 +27,8 @@ enum {
   RNG_BOUNDS = 0, RNG_STATE = 1, RNG_GAINS = 2, RNG_MOTOR = 3, RNG_ASSET_SEL = 4,
   RNG_LIDAR_NOISE = 5,  // counter word 1 = env step; block = pooled cell        (agx_lidar_image_obs)
   RNG_OBS_NOISE = 6,    // counter word 1 = env step; 6 draws                    (agx_obs_lidar_navigation)
+  RNG_IMU_RESET = 7,    // counter word 1 = episode; 9 draws                     (agx_imu_reset)
+  RNG_IMU = 8,          // counter word 1 = env step; block = 3 * sub-step + j   (agx_imu_update)
   RNG_ASSETS = 16,      // + asset index
   RNG_DISTURB = 1 << 20 // + sub-step; counter word 1 = env step
 };

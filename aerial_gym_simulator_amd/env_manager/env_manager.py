@@ -184,6 +184,8 @@ class EnvManager(BaseManager):
         B.step_counter = 0
         B.boxes = p(self.scene.boxes_soa) if self.scene.num_assets > 0 else None
         B.num_boxes = self.scene.num_assets
+        imu = self.robot_manager.imu_sensor
+        B.body_force = p(imu.body_force) if imu is not None else None
         self._buffers = B
         self._params = robot.params
         robot._env_binding = self
@@ -384,6 +386,7 @@ class EnvManager(BaseManager):
         )
         self._reward_fresh = self.task_args is not None
         self._obs_fresh = False
+        self.robot_manager.post_physics_step(num_substeps)
 
     def step(self, actions, env_actions=None):
         if env_actions is not None:

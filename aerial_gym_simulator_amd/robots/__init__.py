@@ -5,6 +5,8 @@ from ..config.robot_config import (
     BaseQuadCfg,
     BaseQuadWithCamera64x48Cfg,
     BaseQuadWithCameraCfg,
+    BaseQuadWithCameraImuCfg,
+    BaseQuadWithImuCfg,
     BaseQuadWithFaceIDNormalCameraCfg,
     BaseQuadWithLidarCfg,
     BaseQuadWithStereoCameraCfg,
@@ -22,3 +24,5 @@ robot_registry.register("base_octarotor_with_lidar_32x512", BaseMultirotor, Base
 robot_registry.register("base_quadrotor_with_faceid_normal_camera", BaseMultirotor, BaseQuadWithFaceIDNormalCameraCfg)
 robot_registry.register("base_quadrotor_with_stereo_camera", BaseMultirotor, BaseQuadWithStereoCameraCfg)
 robot_registry.register("magpie", BaseMultirotor, MagpieCfg)
+robot_registry.register("base_quadrotor_with_imu", BaseMultirotor, BaseQuadWithImuCfg)
+robot_registry.register("base_quadrotor_with_camera_imu", BaseMultirotor, BaseQuadWithCameraImuCfg)

@@ -22,6 +22,7 @@ class RobotManagerHIP:
         if (sc.enable_camera or sc.enable_lidar) and not self.use_warp:
             raise ValueError("ray-cast sensors need use_warp=True (the rasteriser camera of Isaac Gym is out of scope)")
         self.warp_sensor = None
+        self.imu_sensor = None
         self.has_IGE_sensors = False
 
     def prepare_for_sim(self, global_tensor_dict, scene):
@@ -53,14 +54,28 @@ class RobotManagerHIP:
             )
             self.warp_sensor = HipSensor(cfg, N, scene, dev)
             self.warp_sensor.init_tensors(g)
+        if getattr(sc, "enable_imu", False):  # robot_manager.py:256-268
+            from ..sensors.imu_sensor import IMUSensor
+
+            self.imu_sensor = IMUSensor(sc.imu_config, N, dev)
+            self.imu_sensor.init_tensors(g)
 
     def draw_sensor_reset_randoms(self, env_ids):
         if self.warp_sensor is not None:
             self.warp_sensor.draw_reset_randoms(env_ids)
+        if self.imu_sensor is not None:
+            self.imu_sensor.draw_reset_randoms(env_ids)
 
     def reset_sensors_masked(self):
         if self.warp_sensor is not None:
             self.warp_sensor.reset_masked()
+        if self.imu_sensor is not None:
+            self.imu_sensor.reset_masked()
+
+    def post_physics_step(self, k_substeps):
+        """the reference updates the IMU after every physics sub-step (robot_manager.py:491-495)"""
+        if self.imu_sensor is not None:
+            self.imu_sensor.update(k_substeps)
 
     def reset(self):
         self.robot.reset()

@@ -68,7 +68,8 @@ class PositionSetpointTask(BaseTask):
         env.post_obs = (_lib.dptr(self.target_soa), _lib.dptr(self.task_obs["observations"]))
         self._plan = None
         e = env.cfg.env
-        simple = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and not env.strict_rng
+        simple = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and env.robot_manager.imu_sensor is None
+                  and not env.strict_rng
                   and not env.robot_manager.robot.cfg.disturbance.enable_disturbance
                   and e.num_physics_steps_per_env_step_std == 0 and not self.task_config.return_state_before_reset)
         if simple:

@@ -138,6 +138,8 @@ typedef struct AgxEnvBuffers {
      the gather of step t may overlap step t+1.                                                 */
   float *step_rows[2];
   const float *step_reward; /* [N] the task's reward buffer (required when step_rows is set)     */
+  float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
+                            the body frame = allocator output + drag + disturbance; read by agx_imu_update */
 } AgxEnvBuffers;
 
 const char *agx_last_error(void);
@@ -247,6 +249,30 @@ int agx_reward_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const fl
 int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
                              const float *target_yaw, const float *u_vec, const float *u_euler,
                              const float *downsampled, int cells, float *obs, void *stream);
+
+/* ---- IMU (aerial_gym/sensors/imu_sensor.py:74-153) ------------------------------------------
+ * The reference reads Isaac Gym's force sensor on the base link (total force incl. gravity, body
+ * frame) every physics sub-step; here the same quantity is m * (body_force / m + R^T g).
+ * agx_imu_update is called once per env step after agx_env_step with the same k: the bias random
+ * walk takes k steps (z_bias [k][N][6] normal draws), noise (z_noise [N][6]) and the measurement are
+ * those of the last sub-step.  z_noise == z_bias == NULL: device generator (Box-Muller on the
+ * stream of (env, buf->step_counter)).  sensor_quat [N][4], bias [N][6] (in/out), imu_meas [N][6]
+ * = [accel(3), gyro(3)] clamped to +-max_value.                                                 */
+typedef struct AgxImuArgs {
+  float bias_std[6], noise_std[6], max_value[6], max_bias_init[6];
+  float min_rot[3], max_rot[3]; /* sensor mount perturbation, radians                              */
+  float g_world[3];             /* gravity * (1 - gravity_compensation)                            */
+  float sqrt_dt, mass;
+  int32_t world_frame, enable_noise, enable_bias;
+} AgxImuArgs;
+int agx_imu_update(const AgxEnvBuffers *buf, int num_envs, int k_substeps, const AgxImuArgs *args,
+                   const float *sensor_quat, const float *z_noise, const float *z_bias, float *bias,
+                   float *imu_meas, void *stream);
+/* IMUSensor.reset_idx for the envs of buf->reset_mask (when reset_flag[flag_parity] != 0):
+ * bias = max_bias_init * (2 (u - 0.5)), sensor_quat = quat_from_euler(U(min_rot, max_rot)).
+ * u_bias [N][6], u_rot [N][3] uniform draws, or both NULL = device generator (env, episode).     */
+int agx_imu_reset(const AgxEnvBuffers *buf, int num_envs, const AgxImuArgs *args, const float *u_bias,
+                  const float *u_rot, float *bias, float *sensor_quat, void *stream);
 
 /* ---- reset ----------------------------------------------------------------------
  * Masked reset, in the order of EnvManager.reset_idx (env_manager.py:273-301):

@@ -412,6 +412,26 @@ def obs_lidar_navigation(state, euler, qveh, vbody, wbody, actions, target, targ
     return obs
 
 
+# ----------------------------------------------------------------------------- f4: IMU
+def imu_update(mass, g_world, sqrt_dt, world_frame, enable_noise, enable_bias, bias_std, noise_std, max_value, force, quat, wbody,
+               sensor_quat, z_noise, z_bias, bias):
+    """one physics sub-step of IMUSensor.update; `bias` [N,6] is updated in place; returns imu_meas [N,6]"""
+    n = force.shape[0]
+    meas = np.zeros((n, 6), np.float32)
+    assert bias.dtype == np.float32 and bias.flags["C_CONTIGUOUS"]
+    lib().orc_imu_update(n, C.c_float(mass), _p(_f(g_world)), C.c_float(sqrt_dt), int(world_frame), int(enable_noise), int(enable_bias),
+                         _p(_f(bias_std)), _p(_f(noise_std)), _p(_f(max_value)), _p(_f(force)), _p(_f(quat)), _p(_f(wbody)),
+                         _p(_f(sensor_quat)), _p(_f(z_noise)), _p(_f(z_bias)), _p(bias), _p(meas))
+    return meas
+
+
+def imu_reset(mask, u_bias, u_rot, max_bias_init, min_rot, max_rot, bias, sensor_quat):
+    n = bias.shape[0]
+    mk = np.ascontiguousarray(mask, dtype=np.uint8)
+    lib().orc_imu_reset(n, _p(mk), _p(_f(u_bias)), _p(_f(u_rot)), _p(_f(max_bias_init)), _p(_f(min_rot)), _p(_f(max_rot)), _p(bias),
+                        _p(sensor_quat))
+
+
 # ----------------------------------------------------------------------------- device-RNG restatement
 RNG_BOUNDS, RNG_STATE, RNG_GAINS, RNG_MOTOR, RNG_ASSET_SEL, RNG_ASSETS = 0, 1, 2, 3, 4, 16
 

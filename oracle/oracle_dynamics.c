@@ -926,3 +926,50 @@ void orc_obs_lidar_navigation(int n, const float *state, const float *euler, con
     for (int k = 0; k < cells; ++k) o[17 + k] = downsampled[(size_t)i * cells + k];
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* f4: IMU, aerial_gym/sensors/imu_sensor.py:74-131.  force [N,3] is    */
+/* what the force sensor reports on the base link (body frame, total    */
+/* force incl. gravity); one call = one physics sub-step.               */
+/* ------------------------------------------------------------------ */
+void orc_imu_update(int n, float mass, const float *g_world, float sqrt_dt, int world_frame, int enable_noise,
+                    int enable_bias, const float *bias_std, const float *noise_std, const float *max_value,
+                    const float *force, const float *quat, const float *wbody, const float *sensor_quat,
+                    const float *z_noise, const float *z_bias, float *bias, float *meas) {
+  for (int i = 0; i < n; ++i) {
+    float at[3] = {force[3 * i] / mass, force[3 * i + 1] / mass, force[3 * i + 2] / mass};
+    float q2[4], acc[3], ang[3], tmp[3];
+    quat_mul(quat + 4 * i, sensor_quat + 4 * i, q2);
+    if (world_frame) {
+      float d[3] = {at[0] - g_world[0], at[1] - g_world[1], at[2] - g_world[2]};
+      quat_rotate_inverse(q2, d, acc);
+      quat_rotate_inverse(q2, wbody + 3 * i, ang);
+    } else {
+      quat_rotate_inverse(sensor_quat + 4 * i, at, acc);
+      quat_rotate_inverse(q2, g_world, tmp);
+      for (int c = 0; c < 3; ++c) acc[c] = acc[c] - tmp[c];
+      quat_rotate_inverse(sensor_quat + 4 * i, wbody + 3 * i, ang);
+    }
+    for (int c = 0; c < 6; ++c) {
+      float noise = z_noise[6 * i + c] * noise_std[c] / sqrt_dt;
+      bias[6 * i + c] += z_bias[6 * i + c] * bias_std[c] * sqrt_dt;
+      float v = (c < 3 ? acc[c] : ang[c - 3]) + (float)enable_bias * bias[6 * i + c] + (float)enable_noise * noise;
+      float mx = max_value[c];
+      v = v < mx ? v : mx;   /* tensor_clamp: max(min(x, hi), lo) */
+      v = v > -mx ? v : -mx;
+      meas[6 * i + c] = v;
+    }
+  }
+}
+
+/* IMUSensor.reset_idx (:144-153): bias = max_init * (2 (u - 0.5)); sensor quat from U(min, max) euler angles */
+void orc_imu_reset(int n, const uint8_t *mask, const float *u_bias, const float *u_rot, const float *max_bias_init,
+                   const float *min_rot, const float *max_rot, float *bias, float *sensor_quat) {
+  for (int i = 0; i < n; ++i) {
+    if (!mask[i]) continue;
+    for (int c = 0; c < 6; ++c) bias[6 * i + c] = max_bias_init[c] * (2.0f * (u_bias[6 * i + c] - 0.5f));
+    float e[3];
+    for (int c = 0; c < 3; ++c) e[c] = (max_rot[c] - min_rot[c]) * u_rot[3 * i + c] + min_rot[c];
+    quat_from_euler_xyz(e[0], e[1], e[2], sensor_quat + 4 * i);
+  }
+}

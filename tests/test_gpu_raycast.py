@@ -390,9 +390,13 @@ def test_postprocess_points_bit_exact(orc, limits):
 def test_sensor_front_end_stereo_and_normal_robots(orc, robot):
     """The reference's robot names for the f1 sensors build through SimBuilder and their images equal
     the oracle's on the env's own scene and sensor pose (incl. range limits / normalisation)."""
+    import random
+
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
 
+    random.seed(11)       # asset shuffle (asset_loader.py:181 uses python `random`)
+    torch.manual_seed(11)  # sensor mount jitter, robot spawn
     n = 3
     env = SimBuilder().build_env("base_sim", "env_with_random_boxes", robot, "lee_velocity_control", DEV, num_envs=n,
                                  args={"rng_seed": 5})

@@ -207,3 +207,22 @@ def test_lidar_navigation_obs_matches_reference(orc):
     assert np.minimum(d, 2 * np.pi - d).max() < 3e-6  # yaw error wraps at +-pi
     keep = np.r_[0:6, 7:337]
     assert rel_err(obs[:, keep], g["obs"][:, keep]) < 2e-6
+
+
+@pytest.mark.parametrize("frame", ["body", "world"])
+def test_imu_matches_reference(orc, frame):
+    """sensors/imu_sensor.py: reset_idx + a chain of update() calls (bias random walk, noise, clamps)."""
+    g = load_golden("imu_sensor")
+    n = g["body_force"].shape[1]
+    bias, sq = np.zeros((n, 6), np.float32), np.zeros((n, 4), np.float32)
+    orc.imu_reset(np.ones(n, np.uint8), g[frame + "_u_bias"], g[frame + "_u_rot"], g["max_bias_init"], np.deg2rad(g["min_rot_deg"]),
+                  np.deg2rad(g["max_rot_deg"]), bias, sq)
+    assert rel_err(bias, g[frame + "_bias0"]) < 1e-6 and rel_err(sq, g[frame + "_sensor_quat"]) < 1e-6
+    sqrt_dt = np.float32(np.sqrt(0.01))
+    for k in range(g[frame + "_force"].shape[0]):
+        meas = orc.imu_update(float(g["mass"]), [0.0, 0.0, -9.81], sqrt_dt, frame == "world", 1, 1, g["bias_std"], g["noise_std"],
+                              g["max_value"], g[frame + "_force"][k], g[frame + "_quat"][k], g[frame + "_wbody"][k],
+                              g[frame + "_sensor_quat"], g[frame + "_z_noise"][k], g[frame + "_z_bias"][k], bias)
+        assert rel_err(meas, g[frame + "_meas"][k]) < 2e-6, k
+    assert rel_err(bias, g[frame + "_bias_end"]) < 1e-6
+    assert np.abs(g[frame + "_meas"][-1][:8, 0:3]).max() == 100.0  # the clamp was exercised
