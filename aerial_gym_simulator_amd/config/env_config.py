@@ -84,3 +84,18 @@ class EnvWithLidarNavObstaclesCfg(EnvWithObstaclesCfg):
         include_asset_type = dict({"panels": True, "objects": True}, **{k: True for k in _WALLS})
         asset_type_to_dict_map = dict({"panels": A.lidar_nav_panel_asset_params, "objects": A.lidar_nav_object_asset_params},
                                       **A.lidar_nav_walls)
+
+
+class DynamicEnvironmentCfg(EnvWithObstaclesCfg):
+    """dynamic_environment.py: 35 free objects, no walls, obstacle twists as env actions (6 per obstacle)."""
+
+    class env(EnvWithObstaclesCfg.env):
+        num_env_actions = 6
+        create_ground_plane = True  # (no effect here: there is no ground contact model)
+        write_to_sim_at_every_timestep = True
+        lower_bound_min, lower_bound_max = [-2.0, -4.0, 0.0], [-1.0, -2.5, 0.0]
+        upper_bound_min, upper_bound_max = [9.0, 2.5, 4.0], [10.0, 4.0, 5.0]
+
+    class env_config:
+        include_asset_type = {"objects": True}
+        asset_type_to_dict_map = {"objects": A.object_asset_params}

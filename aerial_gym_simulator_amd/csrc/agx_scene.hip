@@ -59,6 +59,45 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
 // ------------------------------------------------------------------------------------ LBVH
 constexpr float kBvhLargeFraction = 0.75f;
 
+// Kinematic obstacles (EnvManager.step(actions, env_actions), obstacle_manager.py:40-44): the env action of an
+// obstacle is its twist (world-frame linear and angular velocity), written into the root state every sub-step;
+// the pose follows with the integrator's rule (p += v dt, exponential map for q) for k sub-steps.
+__global__ void __launch_bounds__(256) k_assets_integrate(int count, float *__restrict__ asset_state, const float *__restrict__ twist,
+                                                           float dt, int k) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= count) return;
+  float *st = asset_state + (size_t)a * 13;
+  const float *tw = twist + (size_t)a * 6;
+  V3 p = V3{st[0], st[1], st[2]};
+  Q4 q = Q4{st[3], st[4], st[5], st[6]};
+  const V3 v = V3{tw[0], tw[1], tw[2]}, w = V3{tw[3], tw[4], tw[5]};
+  const float wm2 = dot(w, w);
+  float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, cs = 1.0f;
+  if (wm2 != 0.0f) {
+    float wm = sqrtf(wm2);
+    float sn;
+    sincos_bounded(fminf(dt * wm * 0.5f, 60.0f), sn, cs);
+    float sc = sn / wm;
+    x1 = w.x * sc; y1 = w.y * sc; z1 = w.z * sc;
+  }
+  for (int s = 0; s < k; ++s) {
+    p = V3{p.x + v.x * dt, p.y + v.y * dt, p.z + v.z * dt};
+    if (wm2 != 0.0f) {
+      float rx = x1 * q.w + y1 * q.z - z1 * q.y;
+      float ry = y1 * q.w + z1 * q.x - x1 * q.z;
+      float rz = z1 * q.w + x1 * q.y - y1 * q.x;
+      float rw = -(x1 * q.x) - y1 * q.y - z1 * q.z;
+      rx += q.x * cs; ry += q.y * cs; rz += q.z * cs; rw += q.w * cs;
+      float nn = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
+      q = Q4{rx / nn, ry / nn, rz / nn, rw / nn};
+    }
+  }
+  st[0] = p.x; st[1] = p.y; st[2] = p.z;
+  st[3] = q.x; st[4] = q.y; st[5] = q.z; st[6] = q.w;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) st[7 + c] = tw[c];  // obstacle_linvel / obstacle_angvel
+}
+
 // obstacle parked outside the env by the curriculum (asset_manager.py:71 puts it at -1000 m)
 AGX_DEV bool tri_parked(const float *t) { return t[0] < -900.0f && t[1] < -900.0f && t[2] < -900.0f; }
 
@@ -345,6 +384,15 @@ extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, co
 }
 
 extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
+
+extern "C" int agx_assets_integrate(int n, int num_assets, float *asset_state, const float *twist, float dt, int k, void *stream) {
+  AGX_REQUIRE(n > 0 && num_assets > 0 && k >= 0 && k <= AGX_MAX_SUBSTEPS && dt > 0.0f, "bad arguments");
+  AGX_REQUIRE(asset_state && twist, "null buffer");
+  const int count = n * num_assets;
+  hipLaunchKernelGGL(k_assets_integrate, dim3(blocks_for(count, 256)), dim3(256), 0, (hipStream_t)stream, count, asset_state, twist,
+                     dt, k);
+  return check_launch("agx_assets_integrate");
+}
 
 extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *tri_world, const uint8_t *mask, float *nodes,
                              int32_t *work, void *stream) {

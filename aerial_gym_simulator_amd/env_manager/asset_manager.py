@@ -51,6 +51,27 @@ class AssetManager:
         if bool((samples > 0).any()):
             rs.rand_into(self._u2, tag="assets_half_draw")
 
+    def apply_env_actions(self, env, twists, k_substeps):
+        """Kinematic obstacles: integrate the poses by k sub-steps of the commanded twists and move the
+        geometry (triangles, BVH, collision boxes) of every env."""
+        sc = self.scene
+        N, K = sc.num_envs, sc.num_assets
+        if K == 0:
+            return
+        tw = twists
+        if tw.dtype != torch.float32 or not tw.is_contiguous():
+            tw = tw.to(dtype=torch.float32).contiguous()
+        if tw.shape != (N, K, 6):
+            raise ValueError(f"env_actions must have shape ({N}, {K}, 6), got {tuple(tw.shape)}")
+        lib, stream, p = env._lib, env._stream(), _lib.dptr
+        st = self.env_asset_state_tensor
+        _lib.check(lib.agx_assets_integrate(N, K, p(st), p(tw), float(self.g["dt"]), int(k_substeps), stream), "agx_assets_integrate")
+        _lib.check(lib.agx_scene_transform(N, sc.num_tris, K, p(sc.tri_local), p(sc.tri_asset), p(st), None, p(sc.tri_world), stream),
+                   "agx_scene_transform")
+        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), None,
+                                     p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
+        _lib.check(lib.agx_boxes_from_assets(N, K, p(st), p(sc.half_extents), None, p(sc.boxes_soa), stream), "agx_boxes_from_assets")
+
     def reset_masked(self, env):
         if self.scene.num_assets == 0:
             return

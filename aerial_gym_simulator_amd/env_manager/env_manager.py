@@ -389,13 +389,23 @@ class EnvManager(BaseManager):
         self.robot_manager.post_physics_step(num_substeps)
 
     def step(self, actions, env_actions=None):
-        if env_actions is not None:
-            raise NotImplementedError("kinematic obstacle actions (env_actions) are not supported yet (SURVEY f4)")
+        """env_actions: [N, num_assets, 6] obstacle twists (world-frame linear + angular velocity), the
+        reference's dynamic-environment interface (env_manager.py:399-416, obstacle_manager.py:40-44)."""
         self._require_device()
+        g = self.global_tensor_dict
+        k = self.num_physics_steps()
+        if env_actions is not None:
+            if g["env_actions"] is None:  # the first tensor handed in becomes THE buffer, like the reference (:406-411)
+                g["env_actions"], g["prev_env_actions"] = env_actions, env_actions
+                self.env_actions, self.prev_env_actions = g["env_actions"], g["prev_env_actions"]
+            self.prev_env_actions[:] = self.env_actions
+            self.env_actions[:] = env_actions
+            # the obstacles move first, then the robots fly k sub-steps against their new poses
+            self.asset_manager.apply_env_actions(self, self.env_actions, k)
         # new env step: switch to the reset flag the previous step's reset kernel cleared
         self._parity ^= 1
         self._buffers.flag_parity = self._parity
-        self.simulate(actions, env_actions, self.num_physics_steps())
+        self.simulate(actions, env_actions, k)
         self.step_counter += 1
 
     def compute_observations(self):

@@ -348,6 +348,14 @@ int agx_scene_transform(int num_envs, int num_tris, int num_assets, const float 
                         const int32_t *tri_asset, const float *asset_state, const uint8_t *mask,
                         float *tri_world, void *stream);
 
+/* Kinematic obstacles: EnvManager.step(actions, env_actions) with env_actions = obstacle twists
+ * (obstacle_manager.py:40-44, examples/dynamic_env_example.py:33-45).  twist [N][K][6] = world-frame
+ * linear and angular velocity; asset_state [N][K][13] gets the twist in its velocity slots and its
+ * pose advanced by k sub-steps of dt (same rule as the robot integrator).  Follow with
+ * agx_scene_transform / agx_bvh_build / agx_boxes_from_assets (mask NULL) to move the geometry.  */
+int agx_assets_integrate(int num_envs, int num_assets, float *asset_state, const float *twist,
+                         float dt, int k_substeps, void *stream);
+
 /* wp.Mesh(...) BVH build / mesh.refit() (warp_env_manager.py:162-166, 52-53).
  * A workgroup builds a binary LBVH over the T triangles of an env in LDS and stores
  * T-1 nodes of 16 floats each: [lo_l(3) child_l | hi_l(3) child_r | lo_r(3) pad | hi_r(3) pad],

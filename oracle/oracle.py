@@ -412,6 +412,14 @@ def obs_lidar_navigation(state, euler, qveh, vbody, wbody, actions, target, targ
     return obs
 
 
+# ----------------------------------------------------------------------------- f4: kinematic obstacles
+def assets_integrate(asset_state, twist, dt, k):
+    """asset_state [N,K,13] updated in place from twist [N,K,6]"""
+    assert asset_state.dtype == np.float32 and asset_state.flags["C_CONTIGUOUS"]
+    lib().orc_assets_integrate(asset_state.shape[0] * asset_state.shape[1], _p(asset_state), _p(_f(twist)), C.c_float(dt), int(k))
+    return asset_state
+
+
 # ----------------------------------------------------------------------------- f4: IMU
 def imu_update(mass, g_world, sqrt_dt, world_frame, enable_noise, enable_bias, bias_std, noise_std, max_value, force, quat, wbody,
                sensor_quat, z_noise, z_bias, bias):

@@ -973,3 +973,37 @@ void orc_imu_reset(int n, const uint8_t *mask, const float *u_bias, const float 
     quat_from_euler_xyz(e[0], e[1], e[2], sensor_quat + 4 * i);
   }
 }
+
+/* f4: kinematic obstacles -- twist [N*K,6] (world frame) written into the state, pose advanced by k
+ * sub-steps with the integrator's rule (orc_integrate's pose update, constant velocities)           */
+void orc_assets_integrate(int count, float *asset_state, const float *twist, float dt, int k) {
+  for (int a = 0; a < count; ++a) {
+    float *st = asset_state + (size_t)a * 13;
+    const float *tw = twist + (size_t)a * 6;
+    float wm2 = tw[3] * tw[3] + tw[4] * tw[4] + tw[5] * tw[5];
+    float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f, cs = 1.0f;
+    if (wm2 != 0.0f) {
+      float wm = sqrtf(wm2);
+      float half = dt * wm * 0.5f;
+      if (half > 60.0f) half = 60.0f;
+      float sn = sinf(half);
+      cs = cosf(half);
+      float sc = sn / wm;
+      x1 = tw[3] * sc; y1 = tw[4] * sc; z1 = tw[5] * sc;
+    }
+    for (int s = 0; s < k; ++s) {
+      for (int c = 0; c < 3; ++c) st[c] = st[c] + tw[c] * dt;
+      if (wm2 != 0.0f) {
+        float *q = st + 3;
+        float rx = x1 * q[3] + y1 * q[2] - z1 * q[1];
+        float ry = y1 * q[3] + z1 * q[0] - x1 * q[2];
+        float rz = z1 * q[3] + x1 * q[1] - y1 * q[0];
+        float rw = -(x1 * q[0]) - y1 * q[1] - z1 * q[2];
+        rx += q[0] * cs; ry += q[1] * cs; rz += q[2] * cs; rw += q[3] * cs;
+        float nn = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
+        q[0] = rx / nn; q[1] = ry / nn; q[2] = rz / nn; q[3] = rw / nn;
+      }
+    }
+    for (int c = 0; c < 6; ++c) st[7 + c] = tw[c];
+  }
+}
