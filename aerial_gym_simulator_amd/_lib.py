@@ -226,6 +226,11 @@ _SIGNATURES = {
          C.c_float, C.c_int, C.c_int, _P],
     ),
     "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "agx_nav_bookkeeping": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_float, _P, _P, _P, _P]),
+    "agx_nav_target_reset": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P,
+                                       C.c_int, _P]),
+    "agx_sensor_mount_reset": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P, _P, _P]),
     "agx_imu_update": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxImuArgs), _P, _P, _P, _P, _P, _P]),
     "agx_imu_reset": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxImuArgs), _P, _P, _P, _P, _P]),
     "agx_lidar_image_obs": (

@@ -677,14 +677,20 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
     Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
     V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
     V3 v = quat_rotate_inverse(qveh, tgt - p);
+    float u6[6];
+    if (u_vec) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { u6[c] = u_vec[(size_t)i * 3 + c]; u6[3 + c] = u_euler[(size_t)i * 3 + c]; }
+    } else {
+      rng_fill<6>(B.rng_seed, i, B.step_counter, RNG_OBS_NOISE, u6);
+    }
     // 0.1 * 2 * rand_like(vec - 0.5): the -0.5 sits inside rand_like in the reference (:374)
-    V3 pv = V3{v.x + 0.1f * 2.0f * u_vec[(size_t)i * 3], v.y + 0.1f * 2.0f * u_vec[(size_t)i * 3 + 1],
-               v.z + 0.1f * 2.0f * u_vec[(size_t)i * 3 + 2]};
+    V3 pv = V3{v.x + 0.1f * 2.0f * u6[0], v.y + 0.1f * 2.0f * u6[1], v.z + 0.1f * 2.0f * u6[2]};
     float dist = norm(v);
     o[0] = pv.x / dist; o[1] = pv.y / dist; o[2] = pv.z / dist; o[3] = dist;
     float e0 = ssa(B.derived[0 * n + i]), e1 = ssa(B.derived[1 * n + i]);
-    o[4] = e0 + 0.1f * (u_euler[(size_t)i * 3] - 0.5f);
-    o[5] = e1 + 0.1f * (u_euler[(size_t)i * 3 + 1] - 0.5f);
+    o[4] = e0 + 0.1f * (u6[3] - 0.5f);
+    o[5] = e1 + 0.1f * (u6[4] - 0.5f);
     o[6] = 0.0f;
     o[7] = B.derived[10 * n + i]; o[8] = B.derived[11 * n + i]; o[9] = B.derived[12 * n + i];
     o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
@@ -991,7 +997,8 @@ extern "C" int agx_obs_navigation(const AgxEnvBuffers *B, int n, const float *ta
                                   const float *u_euler, const float *pixels, int ns, int H, int W, int gh, int gw,
                                   int obs_dim, float *obs, void *stream) {
   if (int e = check_common(nullptr, B, n)) return e;
-  AGX_REQUIRE(target && u_vec && u_euler && obs && B->state && B->derived && B->actions, "null buffer");
+  AGX_REQUIRE(target && obs && B->state && B->derived && B->actions, "null buffer");
+  AGX_REQUIRE((u_vec == nullptr) == (u_euler == nullptr), "u_vec and u_euler: both tensors or both NULL (device generator)");
   AGX_REQUIRE(obs_dim >= 17, "obs_dim must be >= 17");
   AGX_REQUIRE(!pixels || (ns > 0 && H > 0 && W > 0 && gh > 0 && gw > 0), "bad image sizes");
   hipLaunchKernelGGL(k_obs_navigation, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec,

@@ -28,8 +28,10 @@ enum {
   RNG_LIDAR_NOISE = 5,  // counter word 1 = env step; block = pooled cell        (agx_lidar_image_obs)
   RNG_OBS_NOISE = 6,    // counter word 1 = env step; 6 draws                    (agx_obs_lidar_navigation)
   RNG_IMU_RESET = 7,    // counter word 1 = episode; 9 draws                     (agx_imu_reset)
+  RNG_TARGET = 9,       // counter word 1 = episode; 4 draws (target ratio xyz, target yaw) (agx_nav_target_reset)
   RNG_IMU = 8,          // counter word 1 = env step; block = 3 * sub-step + j   (agx_imu_update)
-  RNG_ASSETS = 16,      // + asset index
+  RNG_ASSETS = 16,      // + asset index (< 2^16 assets)
+  RNG_SENSOR_MOUNT = 1 << 16,  // + sensor index; counter word 1 = episode; 6 draws  (agx_sensor_mount_reset)
   RNG_DISTURB = 1 << 20 // + sub-step; counter word 1 = env step
 };
 

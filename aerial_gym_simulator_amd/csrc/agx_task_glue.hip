@@ -1,0 +1,134 @@
+// Small per-env kernels that replace the torch glue of the navigation-type tasks in the sync-free mode:
+// success / timeout bookkeeping with device-side curriculum counters, target (+ target yaw) resampling and
+// sensor mount re-randomisation of the envs that reset.  Each replaces 5-15 tiny torch launches per env step;
+// at the 512-2048 envs an RL run typically uses, those launches -- not the simulation -- bound the step time.
+#include "agx_common.h"
+#include "agx_device_math.h"
+#include "agx_rng.h"
+
+namespace agx {
+
+struct Ratio3 {
+  float lo[3], hi[3];
+};
+
+// navigation_task.py:311-326 / lidar_navigation_task.py:405-418: successes = truncated & within `radius` of the
+// target & not crashed; timeouts = truncated & not success & not crashed.  counters += (successes, crashes, timeouts).
+__global__ void __launch_bounds__(256) k_nav_bookkeeping(AgxEnvBuffers B, int n, const float *__restrict__ target, float radius,
+                                                          uint8_t *__restrict__ successes, uint8_t *__restrict__ timeouts,
+                                                          int32_t *__restrict__ counters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool succ = false, tout = false, crash = false;
+  if (i < n) {
+    V3 d = V3{target[0 * n + i] - B.state[0 * n + i], target[1 * n + i] - B.state[1 * n + i], target[2 * n + i] - B.state[2 * n + i]};
+    const bool near = norm(d) < radius;
+    crash = B.crashes[i] != 0;
+    const bool trunc = B.truncations[i] != 0;
+    succ = trunc && near && !crash;
+    tout = trunc && !succ && !crash;
+    successes[i] = succ ? 1 : 0;
+    timeouts[i] = tout ? 1 : 0;
+  }
+  const unsigned long long ms = __ballot(succ), mc = __ballot(crash), mt = __ballot(tout);
+  if ((threadIdx.x & 63) == 0) {
+    if (ms) atomicAdd(counters + 0, __popcll(ms));
+    if (mc) atomicAdd(counters + 1, __popcll(mc));
+    if (mt) atomicAdd(counters + 2, __popcll(mt));
+  }
+}
+
+// reset_idx of the navigation tasks (navigation_task.py:166-175, lidar_navigation_task.py:164-181) for the envs of
+// reset_mask: target = bounds_min + (bounds_max - bounds_min) * U(min_ratio, max_ratio); optional target_yaw =
+// U(-pi, pi); optional robot_prev_actions = 0.
+__global__ void __launch_bounds__(256) k_nav_target_reset(AgxEnvBuffers B, int n, int num_actions, Ratio3 R, const float *__restrict__ u,
+                                                           float *__restrict__ target, float *__restrict__ target_yaw,
+                                                           int zero_prev_actions) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || B.reset_flag[B.flag_parity] == 0 || B.reset_mask[i] == 0) return;
+  float uu[4];
+  if (u) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) uu[c] = u[(size_t)i * 4 + c];
+  } else {
+    rng_fill<4>(B.rng_seed, i, B.episode_count ? B.episode_count[i] : 0, RNG_TARGET, uu);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float ratio = (R.hi[c] - R.lo[c]) * uu[c] + R.lo[c];
+    float lo = B.bounds_min[c * n + i], hi = B.bounds_max[c * n + i];
+    target[c * n + i] = lo + (hi - lo) * ratio;
+  }
+  if (target_yaw) target_yaw[i] = (kPi - (-kPi)) * uu[3] + (-kPi);
+  if (zero_prev_actions)
+    for (int c = 0; c < num_actions; ++c) B.prev_actions[c * n + i] = 0.0f;
+}
+
+// WarpSensor.reset_idx (warp_sensor.py:153-172) for the envs of reset_mask
+__global__ void __launch_bounds__(256) k_sensor_mount_reset(AgxEnvBuffers B, int n, int ns, Ratio3 Tr, Ratio3 Ro,
+                                                             const float *__restrict__ u_pos, const float *__restrict__ u_rot,
+                                                             float *__restrict__ local_pos, float *__restrict__ local_quat) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * ns) return;
+  const int i = idx / ns, s = idx % ns;
+  if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[i] == 0) return;
+  float uu[6];
+  if (u_pos) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { uu[c] = u_pos[(size_t)idx * 3 + c]; uu[3 + c] = u_rot[(size_t)idx * 3 + c]; }
+  } else {
+    rng_fill<6>(B.rng_seed, i, B.episode_count ? B.episode_count[i] : 0, RNG_SENSOR_MOUNT + s, uu);
+  }
+  float e[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    local_pos[(size_t)idx * 3 + c] = (Tr.hi[c] - Tr.lo[c]) * uu[c] + Tr.lo[c];
+    e[c] = (Ro.hi[c] - Ro.lo[c]) * uu[3 + c] + Ro.lo[c];
+  }
+  Q4 q = quat_from_euler(e[0], e[1], e[2]);
+  float *o = local_quat + (size_t)idx * 4;
+  o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+}
+
+}  // namespace agx
+
+using namespace agx;
+
+static Ratio3 ratio3(const float *lo, const float *hi) {
+  Ratio3 r;
+  for (int c = 0; c < 3; ++c) { r.lo[c] = lo[c]; r.hi[c] = hi[c]; }
+  return r;
+}
+
+extern "C" int agx_nav_bookkeeping(const AgxEnvBuffers *B, int n, const float *target, float radius, uint8_t *successes,
+                                   uint8_t *timeouts, int32_t *counters, void *stream) {
+  AGX_REQUIRE(B && n > 0 && B->state && B->crashes && B->truncations, "bad arguments");
+  AGX_REQUIRE(target && successes && timeouts && counters, "null buffer");
+  hipLaunchKernelGGL(k_nav_bookkeeping, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, target, radius, successes,
+                     timeouts, counters);
+  return check_launch("agx_nav_bookkeeping");
+}
+
+extern "C" int agx_nav_target_reset(const AgxEnvBuffers *B, int n, int num_actions, const float *min_ratio, const float *max_ratio,
+                                    const float *u, float *target, float *target_yaw, int zero_prev_actions, void *stream) {
+  AGX_REQUIRE(B && n > 0 && B->reset_mask && B->reset_flag && B->bounds_min && B->bounds_max, "bad arguments");
+  AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
+  AGX_REQUIRE(min_ratio && max_ratio && target, "null buffer");
+  AGX_REQUIRE(u || B->episode_count, "device RNG needs buf->episode_count");
+  AGX_REQUIRE(!zero_prev_actions || (B->prev_actions && num_actions >= 1 && num_actions <= AGX_MAX_ACTIONS), "bad prev_actions");
+  hipLaunchKernelGGL(k_nav_target_reset, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, num_actions,
+                     ratio3(min_ratio, max_ratio), u, target, target_yaw, zero_prev_actions);  // ratios: HOST pointers
+  return check_launch("agx_nav_target_reset");
+}
+
+extern "C" int agx_sensor_mount_reset(const AgxEnvBuffers *B, int n, int ns, const float *min_translation,
+                                      const float *max_translation, const float *min_rot, const float *max_rot, const float *u_pos,
+                                      const float *u_rot, float *local_pos, float *local_quat, void *stream) {
+  AGX_REQUIRE(B && n > 0 && ns > 0 && B->reset_mask && B->reset_flag, "bad arguments");
+  AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
+  AGX_REQUIRE(min_translation && max_translation && min_rot && max_rot && local_pos && local_quat, "null buffer");
+  AGX_REQUIRE((u_pos == nullptr) == (u_rot == nullptr), "u_pos and u_rot: both tensors or both NULL");
+  AGX_REQUIRE(u_pos || B->episode_count, "device RNG needs buf->episode_count");
+  hipLaunchKernelGGL(k_sensor_mount_reset, dim3(blocks_for(n * ns, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, ns,
+                     ratio3(min_translation, max_translation), ratio3(min_rot, max_rot), u_pos, u_rot, local_pos, local_quat);
+  return check_launch("agx_sensor_mount_reset");
+}

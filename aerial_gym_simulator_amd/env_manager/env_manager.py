@@ -405,6 +405,8 @@ class EnvManager(BaseManager):
         # new env step: switch to the reset flag the previous step's reset kernel cleared
         self._parity ^= 1
         self._buffers.flag_parity = self._parity
+        # counter word of the per-step device RNG streams (disturbance, observation / LiDAR noise, IMU)
+        self._buffers.step_counter = self.step_counter & 0x7FFFFFFF
         self.simulate(actions, env_actions, k)
         self.step_counter += 1
 

@@ -89,6 +89,10 @@ class HipSensor:
         self.sensor_position = torch.zeros(N, S, 3, device=dev)
         self.sensor_orientation = torch.zeros(N, S, 4, device=dev)
         self.sensor_orientation[..., 3] = 1.0
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+        self._min_t, self._max_t = f3(cfg.min_translation), f3(cfg.max_translation)
+        self._min_r = f3([math.radians(x) for x in cfg.min_euler_rotation_deg])
+        self._max_r = f3([math.radians(x) for x in cfg.max_euler_rotation_deg])
         self._u_pos = torch.zeros(N, S, 3, device=dev)
         self._u_rot = torch.zeros(N, S, 3, device=dev)
         self._noise_z = self._noise_u = None
@@ -110,17 +114,15 @@ class HipSensor:
         if not self.cfg.randomize_placement:
             return
         g = self.g
-        if not g.get("strict_rng", True):
-            rs = g["random_source"]
-            rs.rand_into(self._u_pos, tag="sensor_pos")
-            rs.rand_into(self._u_rot, tag="sensor_rot")
         env = g["env_manager"]
-        mask = (g["reset_mask"].bool() & (g["reset_flag"][env._parity] != 0)).view(-1, 1, 1)
-        pos = (self.max_translation - self.min_translation) * self._u_pos + self.min_translation
-        eul = (self.max_rotation - self.min_rotation) * self._u_rot + self.min_rotation
-        quat = quat_from_euler_xyz(eul[..., 0], eul[..., 1], eul[..., 2])
-        self.sensor_local_position[:] = torch.where(mask, pos, self.sensor_local_position)
-        self.sensor_local_orientation[:] = torch.where(mask, quat, self.sensor_local_orientation)
+        p = _lib.dptr
+        strict = bool(g.get("strict_rng", True))
+        _lib.check(
+            env._lib.agx_sensor_mount_reset(env._buffers, self.num_envs, self.num_sensors, self._min_t, self._max_t, self._min_r, self._max_r,
+                                            p(self._u_pos) if strict else None, p(self._u_rot) if strict else None,
+                                            p(self.sensor_local_position), p(self.sensor_local_orientation), env._stream()),
+            "agx_sensor_mount_reset",
+        )
 
     def update(self):
         """WarpSensor.update (warp_sensor.py:177-200): pose -> ray-cast -> noise / range limits / normalise."""

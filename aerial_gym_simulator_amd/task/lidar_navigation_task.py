@@ -45,6 +45,11 @@ class LiDARNavigationTask(NavigationTask):
         assert len(self._rp) == 22
         self._noise = None  # strict mode: the five noise tensors of add_noise_to_downsampled_lidar_data
 
+    _zero_prev_actions_on_reset = True  # lidar_navigation_task.py:172
+
+    def _target_yaw_ptr(self):
+        return _lib.dptr(self.target_yaw)
+
     # the reward needs the task-level action history and the time to collision: it is its own launch
     def _fuse_with_env(self):
         self.sim_env.task_args = None
@@ -89,18 +94,9 @@ class LiDARNavigationTask(NavigationTask):
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
-        near = torch.norm(self.target_position - self.obs_dict["robot_position"], dim=1) < 1.0
-        crashed = self.terminations
-        successes = self.truncations & near & ~crashed
-        timeouts = self.truncations & ~successes & ~crashed
-        self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = successes, timeouts, crashed
-        self.check_and_update_curriculum_level(successes, crashed, timeouts)
+        self._bookkeeping()
         reset_envs = env.post_reward_calculation_step()
-        if env.strict_rng:
-            if len(reset_envs) > 0:
-                self.reset_idx(reset_envs.indices)
-        else:
-            self.reset_idx(reset_envs.mask)
+        self._reset_targets(reset_envs)
         self.num_task_steps += 1
         self.process_image_observation()
         if not self.task_config.return_state_before_reset:

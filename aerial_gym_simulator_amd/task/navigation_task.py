@@ -71,7 +71,15 @@ class NavigationTask(BaseTask):
         self._rp = (C.c_float * len(order))(*[float(cfg.reward_parameters[k]) for k in order])
         self._u_vec = torch.zeros(N, 3, device=dev)
         self._u_euler = torch.zeros(N, 3, device=dev)
-        self.curriculum_check_every = int(cfg.args.get("curriculum_check_every", 1)) if isinstance(cfg.args, dict) else 1
+        # sync-free mode: bookkeeping on the device; the host only reads the three counters every
+        # `curriculum_check_every` steps (the reference syncs on them every step, navigation_task.py:237)
+        default_every = 1 if self.sim_env.strict_rng else 16
+        self.curriculum_check_every = int(cfg.args.get("curriculum_check_every", default_every)) if isinstance(cfg.args, dict) else default_every
+        self._successes = torch.zeros(N, dtype=torch.bool, device=dev)
+        self._timeouts = torch.zeros(N, dtype=torch.bool, device=dev)
+        self._counters = torch.zeros(3, dtype=torch.int32, device=dev)
+        self._min_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_min_ratio])
+        self._max_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_max_ratio])
         self._fuse_with_env()
 
     def _fuse_with_env(self):
@@ -123,20 +131,63 @@ class NavigationTask(BaseTask):
         self.timeouts_aggregate += torch.sum(timeouts)
         if self.num_task_steps % self.curriculum_check_every != 0:
             return
-        instances = self.success_aggregate + self.crashes_aggregate + self.timeouts_aggregate
+        self._curriculum_decision(int(self.success_aggregate), int(self.crashes_aggregate), int(self.timeouts_aggregate))  # host sync (:237)
+
+    def _curriculum_decision(self, n_success, n_crash, n_timeout):
+        """navigation_task.py:229-270 on host integers; returns True when the aggregates were consumed."""
+        instances = n_success + n_crash + n_timeout
         c = self.task_config.curriculum
-        if int(instances) >= c.check_after_log_instances:  # host sync, as in the reference (:237)
-            success_rate = float(self.success_aggregate / instances)
-            if success_rate > c.success_rate_for_increase:
-                self.curriculum_level += c.increase_step
-            elif success_rate < c.success_rate_for_decrease:
-                self.curriculum_level -= c.decrease_step
-            self.curriculum_level = min(max(self.curriculum_level, c.min_level), c.max_level)
-            self.obs_dict["curriculum_level"] = self.curriculum_level
-            self.obs_dict["num_obstacles_in_env"] = self.curriculum_level
-            self._update_progress()
-            logger.warning(f"Curriculum Level: {self.curriculum_level}, success rate {success_rate:.3f}")
-            self.success_aggregate = self.crashes_aggregate = self.timeouts_aggregate = 0
+        if instances < c.check_after_log_instances:
+            return False
+        success_rate = n_success / instances
+        if success_rate > c.success_rate_for_increase:
+            self.curriculum_level += c.increase_step
+        elif success_rate < c.success_rate_for_decrease:
+            self.curriculum_level -= c.decrease_step
+        self.curriculum_level = min(max(self.curriculum_level, c.min_level), c.max_level)
+        self.obs_dict["curriculum_level"] = self.curriculum_level
+        self.obs_dict["num_obstacles_in_env"] = self.curriculum_level
+        self._update_progress()
+        logger.warning(f"Curriculum Level: {self.curriculum_level}, success rate {success_rate:.3f}")
+        self.success_aggregate = self.crashes_aggregate = self.timeouts_aggregate = 0
+        return True
+
+    def _bookkeeping(self):
+        """successes / timeouts / crashes of this step and the curriculum (navigation_task.py:311-330)."""
+        env = self.sim_env
+        if env.strict_rng:  # reference-faithful: torch reductions and a host sync on the aggregates
+            near = torch.norm(self.target_position - self.obs_dict["robot_position"], dim=1) < 1.0
+            crashed = self.terminations
+            successes = self.truncations & near & ~crashed
+            timeouts = self.truncations & ~successes & ~crashed
+            self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = successes, timeouts, crashed
+            self.check_and_update_curriculum_level(successes, crashed, timeouts)
+            return
+        p = _lib.dptr
+        _lib.check(env._lib.agx_nav_bookkeeping(env._buffers, env.num_envs, p(self.target_soa), 1.0, p(self._successes),
+                                                p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
+        self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = self._successes, self._timeouts, self.terminations
+        if self.num_task_steps % self.curriculum_check_every == 0:
+            ns, nc, nt = self._counters.tolist()  # the only host sync of the task, every `curriculum_check_every` steps
+            if self._curriculum_decision(ns, nc, nt):
+                self._counters.zero_()
+
+    def _reset_targets(self, reset_envs):
+        """reset_idx for the envs that were just reset"""
+        env = self.sim_env
+        if env.strict_rng:
+            if len(reset_envs) > 0:
+                self.reset_idx(reset_envs.indices)
+            return
+        _lib.check(env._lib.agx_nav_target_reset(env._buffers, env.num_envs, env.num_robot_actions, self._min_ratio, self._max_ratio, None,
+                                                 _lib.dptr(self.target_soa), self._target_yaw_ptr(), int(self._zero_prev_actions_on_reset),
+                                                 env._stream()), "agx_nav_target_reset")
+        self.infos = {}
+
+    _zero_prev_actions_on_reset = False
+
+    def _target_yaw_ptr(self):
+        return None
 
     def step(self, actions):
         env = self.sim_env
@@ -148,19 +199,9 @@ class NavigationTask(BaseTask):
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
-        # successes / timeouts (navigation_task.py:311-326)
-        near = torch.norm(self.target_position - self.obs_dict["robot_position"], dim=1) < 1.0
-        crashed = self.terminations
-        successes = self.truncations & near & ~crashed
-        timeouts = self.truncations & ~successes & ~crashed
-        self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = successes, timeouts, crashed
-        self.check_and_update_curriculum_level(successes, crashed, timeouts)
+        self._bookkeeping()
         reset_envs = env.post_reward_calculation_step()
-        if env.strict_rng:
-            if len(reset_envs) > 0:
-                self.reset_idx(reset_envs.indices)
-        else:
-            self.reset_idx(reset_envs.mask)
+        self._reset_targets(reset_envs)
         self.num_task_steps += 1
         self.process_image_observation()
         self.post_image_reward_addition()
@@ -203,15 +244,16 @@ class NavigationTask(BaseTask):
     def process_obs_for_task(self):
         env = self.sim_env
         env._require_device()
-        rs = self.obs_dict["random_source"]
-        rs.rand_into(self._u_vec, tag="obs_vec")
-        rs.rand_into(self._u_euler, tag="obs_euler")
+        uv = ue = None  # sync-free: the kernel draws from the device generator
+        if env.strict_rng:
+            rs = self.obs_dict["random_source"]
+            uv, ue = _lib.dptr(rs.rand_into(self._u_vec, tag="obs_vec")), _lib.dptr(rs.rand_into(self._u_euler, tag="obs_euler"))
         px = self.obs_dict.get("depth_range_pixels")
         use_px = px is not None and px.dim() == 4 and self.task_config.observation_space_dim > 17
         S, H, W = (px.shape[1], px.shape[2], px.shape[3]) if use_px else (0, 0, 0)
         _lib.check(
-            env._lib.agx_obs_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), _lib.dptr(self._u_vec),
-                                        _lib.dptr(self._u_euler), _lib.dptr(px) if use_px else None, S, H, W, 8, 8,
+            env._lib.agx_obs_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), uv, ue,
+                                        _lib.dptr(px) if use_px else None, S, H, W, 8, 8,
                                         int(self.task_config.observation_space_dim),
                                         _lib.dptr(self.task_obs["observations"]), env._stream()),
             "agx_obs_navigation",

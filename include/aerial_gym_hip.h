@@ -209,7 +209,8 @@ int agx_reward_navigation(const AgxEnvBuffers *buf, int num_envs, const float *t
 
 /* process_obs_for_task of the navigation task (navigation_task.py:369-393): obs [N][obs_dim]
  * row-major = unit vector to target (+0.2 U01 noise) | distance | roll, pitch (+-0.05 noise) | 0 |
- * body lin/ang velocity | robot_actions(4) | latents.  u_vec, u_euler: [N][3] U01 draws.
+ * body lin/ang velocity | robot_actions(4) | latents.  u_vec, u_euler: [N][3] U01 draws, or both
+ * NULL = device generator (stream of (env, buf->step_counter)).
  * The reference fills the latents with a VAE encoding of the depth image (a conv net outside
  * the simulation hot path); here latents = grid_h x grid_w min-pooled depth image
  * (pixels [N][S][H][W], sensor 0), or left untouched when pixels == NULL.                  */
@@ -249,6 +250,26 @@ int agx_reward_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const fl
 int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
                              const float *target_yaw, const float *u_vec, const float *u_euler,
                              const float *downsampled, int cells, float *obs, void *stream);
+
+/* ---- task glue of the navigation-type tasks (sync-free mode: no torch launches per step) ----
+ * successes / timeouts (navigation_task.py:311-326, lidar_navigation_task.py:405-418): u8 [N] each;
+ * counters int32[3] += (sum successes, sum crashes, sum timeouts) for the curriculum.            */
+int agx_nav_bookkeeping(const AgxEnvBuffers *buf, int num_envs, const float *target, float radius,
+                        uint8_t *successes, uint8_t *timeouts, int32_t *counters, void *stream);
+/* reset_idx of the tasks (navigation_task.py:166-175, lidar_navigation_task.py:164-181) for the envs
+ * of buf->reset_mask: target [3][N] = bounds_min + (bounds_max - bounds_min) * U(min_ratio, max_ratio),
+ * target_yaw [N] (or NULL) = U(-pi, pi), robot_prev_actions = 0 if asked.  min/max_ratio: HOST float[3];
+ * u [N][4] uniform draws or NULL = device generator (env, episode).                              */
+int agx_nav_target_reset(const AgxEnvBuffers *buf, int num_envs, int num_actions, const float *min_ratio,
+                         const float *max_ratio, const float *u, float *target, float *target_yaw,
+                         int zero_prev_actions, void *stream);
+/* WarpSensor.reset_idx (warp_sensor.py:153-172) for the envs of buf->reset_mask: local_pos [N][S][3] =
+ * U(min_translation, max_translation), local_quat [N][S][4] = quat_from_euler(U(min_rot, max_rot))
+ * (HOST float[3] each, radians); u_pos / u_rot [N][S][3] or both NULL = device generator.         */
+int agx_sensor_mount_reset(const AgxEnvBuffers *buf, int num_envs, int num_sensors,
+                           const float *min_translation, const float *max_translation,
+                           const float *min_rot, const float *max_rot, const float *u_pos,
+                           const float *u_rot, float *local_pos, float *local_quat, void *stream);
 
 /* ---- IMU (aerial_gym/sensors/imu_sensor.py:74-153) ------------------------------------------
  * The reference reads Isaac Gym's force sensor on the base link (total force incl. gravity, body

@@ -442,6 +442,7 @@ def imu_reset(mask, u_bias, u_rot, max_bias_init, min_rot, max_rot, bias, sensor
 
 # ----------------------------------------------------------------------------- device-RNG restatement
 RNG_BOUNDS, RNG_STATE, RNG_GAINS, RNG_MOTOR, RNG_ASSET_SEL, RNG_ASSETS = 0, 1, 2, 3, 4, 16
+RNG_LIDAR_NOISE, RNG_OBS_NOISE, RNG_IMU_RESET, RNG_IMU, RNG_TARGET, RNG_SENSOR_MOUNT = 5, 6, 7, 8, 9, 1 << 16
 
 
 def rng_fill(seed, episodes, stream, count):

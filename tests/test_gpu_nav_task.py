@@ -152,6 +152,22 @@ def test_navigation_task_step_by_step_vs_oracle(orc):
             tris_ref = orc.scene_transform(tri_local, tri_asset, post["asset"])
             assert np.array_equal(post["tri_world"], tris_ref), t
             lpos, lquat = npy(sensor.sensor_local_position), npy(sensor.sensor_local_orientation)
+            if reset_ref.any():
+                # task targets and sensor mounts of the reset envs: device streams of (env, new episode)
+                f32 = np.float32
+                u4 = orc.rng_fill(seed, post["ep"], orc.RNG_TARGET, 4)
+                lo_t, hi_t = np.array(cfg.target_min_ratio, f32), np.array(cfg.target_max_ratio, f32)
+                tgt_ref = post["bmin"] + (post["bmax"] - post["bmin"]) * ((hi_t - lo_t) * u4[:, 0:3] + lo_t)
+                assert np.array_equal(post["target"][reset_ref], tgt_ref[reset_ref].astype(f32)), t
+                assert np.array_equal(post["target"][~reset_ref], pre["target"][~reset_ref]), t
+                um = orc.rng_fill(seed, post["ep"], orc.RNG_SENSOR_MOUNT, 6)
+                sc_ = sensor.cfg
+                lo_p, hi_p = np.array(sc_.min_translation, f32), np.array(sc_.max_translation, f32)
+                lo_e = np.array([np.radians(v) for v in sc_.min_euler_rotation_deg], f32)
+                hi_e = np.array([np.radians(v) for v in sc_.max_euler_rotation_deg], f32)
+                assert np.array_equal(lpos[reset_ref, 0], ((hi_p - lo_p) * um[:, 0:3] + lo_p)[reset_ref]), t
+                q_ref = orc.quat_from_euler(((hi_e - lo_e) * um[:, 3:6] + lo_e).astype(f32))
+                assert np.abs(lquat[reset_ref, 0] - q_ref[reset_ref]).max() < 3e-7, t
             spos, squat = orc.sensor_pose(post["state"], lpos, lquat, frame)
             assert np.array_equal(npy(sensor.sensor_position), spos) and np.array_equal(npy(sensor.sensor_orientation), squat), t
             px_ref, seg_ref = orc.raycast_camera(64, 48, kinv, 10.0, cx, cy, "depth", spos, squat, tris_ref, tri_seg)
@@ -159,8 +175,9 @@ def test_navigation_task_step_by_step_vs_oracle(orc):
             assert np.array_equal(npy(g["segmentation_pixels"]), seg_ref), t                # segmentation ids: bit-exact
             assert np.array_equal(npy(g["depth_range_pixels"]), px_ref), t                  # normalised depth: bit-exact
             # ---------------- observation (fresh derived tensors of reset steps come from update_states)
+            u6 = orc.rng_fill(seed, np.full(n, env.step_counter - 1), 6, 6)  # RNG_OBS_NOISE of (env, this env step)
             obs_ref = orc.obs_navigation(post["state"], post["euler"], post["qveh"], post["vbody"], post["wbody"], post["actions"],
-                                         post["target"], rs.last("obs_vec"), rs.last("obs_euler"), px_ref, cfg.observation_space_dim)
+                                         post["target"], u6[:, 0:3], u6[:, 3:6], px_ref, cfg.observation_space_dim)
             assert rel_err(npy(obs["observations"]), obs_ref) < 1e-5, t
             if reset_ref.any():  # the reference refreshes EVERY env's derived tensors when any env resets
                 eu, qv, vv, vb, wb = orc.update_states(post["state"])
