@@ -23,7 +23,16 @@ def _ratio(lo_xyz, hi_xyz, lo_rpy=(0.0, 0.0, 0.0), hi_rpy=(0.0, 0.0, 0.0)):
 
 class asset_state_params:
     num_assets = 1
-    box_sizes = [[1.0, 1.0, 1.0]]  # one entry is picked per instance (uniformly, python `random`)
+    # Geometry source, in this order:
+    #  1. asset_folder (+ file): URDF files as in the reference's config (env_object_config.py:20-21): `file` for
+    #     every instance, or file = None -> random.choices over the folder's *.urdf (asset_loader.py:44-56).  Used
+    #     when the folder exists on this machine (e.g. <aerial_gym>/resources/models/environment_assets/objects).
+    #  2. box_sizes: the same boxes restated as data (checked against the reference's URDFs by
+    #     tests/test_assets.py when the reference tree is present); one entry is picked per instance.
+    asset_folder = None
+    file = None
+    use_collision_mesh_instead_of_visual = False
+    box_sizes = [[1.0, 1.0, 1.0]]
     random_box_size_range = None   # or ([lo xyz], [hi xyz]): sizes drawn per instance
     keep_in_env = False
     semantic_id = -1               # < 0: assigned incrementally per instance (from 100)

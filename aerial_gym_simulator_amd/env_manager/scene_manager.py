@@ -11,6 +11,7 @@ Device data owned here
     bvh_nodes     [N, T-1, 16] LBVH built on device by agx_bvh_build
     boxes_soa     [K*11, N]   OBBs (+ bounding radius) for the collision test
 """
+import os
 import random
 
 import numpy as np
@@ -61,12 +62,13 @@ class SceneManager:
         slot_random = np.array([t.random_box_size_range is not None for t in slots])
         slot_rlo = np.array([t.random_box_size_range[0] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
         slot_rhi = np.array([t.random_box_size_range[1] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
-        max_choices = max(len(t.box_sizes) if t.box_sizes else 1 for t in slots)
-        slot_nchoice = np.array([len(t.box_sizes) if t.box_sizes else 1 for t in slots])
+        # geometry per asset type: URDF folder when configured and present, else the restated box-size table
+        choices = [self._box_choices(t) for t in slots]
+        max_choices = max(len(c) for c in choices)
+        slot_nchoice = np.array([len(c) for c in choices])
         slot_choices = np.zeros((len(slots), max_choices, 3), np.float32)
-        for j, t in enumerate(slots):
-            if t.box_sizes:
-                slot_choices[j, : len(t.box_sizes)] = t.box_sizes
+        for j, c in enumerate(choices):
+            slot_choices[j, : len(c)] = c
         free_idx = list(range(nk, nk + nf))
         for i in range(N):
             rng = np.random.default_rng(scene_seed_base + shard_rank * N + i)  # seeded by GLOBAL env index
@@ -83,6 +85,24 @@ class SceneManager:
         counter = 100 + semantic_offset + np.arange(N * K).reshape(N, K)
         sem = np.where(sem < 0, counter, sem)
         self._np = dict(size=size, lo=lo, hi=hi, sem=sem)
+
+    _urdf_cache = {}
+
+    @classmethod
+    def _box_choices(cls, acfg):
+        """Box sizes an instance of this asset type may take (one is drawn per instance and env)."""
+        folder = getattr(acfg, "asset_folder", None)
+        if folder and os.path.isdir(folder):
+            from ..assets import list_urdf_files, parse_box_urdf
+
+            files = [acfg.file] if getattr(acfg, "file", None) else list_urdf_files(folder)
+            if not files:
+                raise ValueError(f"no URDF files in {folder}")
+            key = (folder, tuple(files), bool(getattr(acfg, "use_collision_mesh_instead_of_visual", False)))
+            if key not in cls._urdf_cache:  # asset_loader.py:66-70 keeps a buffer of loaded files, too
+                cls._urdf_cache[key] = [parse_box_urdf(os.path.join(folder, f), key[2]).size for f in files]
+            return cls._urdf_cache[key]
+        return list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
 
     def prepare_for_simulation(self, global_tensor_dict):
         g, N, dev, K = global_tensor_dict, self.num_envs, self.device, self.num_assets
