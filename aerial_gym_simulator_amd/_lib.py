@@ -272,7 +272,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.agx_abi_version() != 3:
+    if lib.agx_abi_version() != 4:
         raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
     _lib = lib
     return lib

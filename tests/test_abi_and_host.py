@@ -24,7 +24,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/aerial_gym_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     L = _lib.load()
-    assert L.agx_abi_version() == 3
+    assert L.agx_abi_version() == 4
     # links only against the HIP runtime / libc: no torch, no python in the C ABI library
     needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
     libs = re.findall(r"Shared library: \[(.*?)\]", needed)
