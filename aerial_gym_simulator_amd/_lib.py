@@ -197,6 +197,7 @@ _SIGNATURES = {
                                    C.c_int, _P, _P]),
     "agx_scene_transform": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_bvh_nodes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "agx_prims_from_assets": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "agx_assets_integrate": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),

@@ -6,9 +6,18 @@ described here by its box sizes + the placement ranges of
 aerial_gym/config/asset_config/env_object_config.py.  URDF/mesh ingestion is out of scope
 (SURVEY.md section 8 f3).
 """
+import os
+
 import numpy as np
 
 _PI = float(np.pi)
+# Root of the reference's (or your own) `resources` tree for asset types that are read from URDF files.  The
+# box-only sets are restated below as data and need no files; `trees` / `thin` do.
+RESOURCES = os.environ.get("AERIAL_GYM_RESOURCES", "/nonexistent/aerial_gym/resources")
+
+
+def _assets(sub):
+    return os.path.join(RESOURCES, "models", "environment_assets", sub)
 
 PANEL_SEMANTIC_ID = 20
 FRONT_WALL_SEMANTIC_ID, BACK_WALL_SEMANTIC_ID = 9, 10
@@ -102,3 +111,24 @@ def _free(wall):
 
 lidar_nav_walls = {name: _free(w) for name, w in (("left_wall", left_wall), ("right_wall", right_wall), ("back_wall", back_wall),
                                                   ("front_wall", front_wall), ("bottom_wall", bottom_wall), ("top_wall", top_wall))}
+
+
+# ---- sets that only exist as URDF files (multi-link cylinder trees, thin rods): AERIAL_GYM_RESOURCES must point
+# at a `resources` directory that has models/environment_assets/{trees,thin}
+class tree_asset_params(asset_state_params):  # env_object_config.py:225-270
+    num_assets = 1
+    asset_folder = _assets("trees")
+    box_sizes = None
+    keep_in_env = True
+    per_link_semantic = True
+    semantic_id = -1
+    min_state_ratio, max_state_ratio = _ratio([0.1, 0.1, 0.0], [0.9, 0.9, 0.0], (0, -_PI / 6, -_PI), (0, _PI / 6, _PI))
+    color = [70, 200, 100]
+
+
+class thin_asset_params(asset_state_params):  # env_object_config.py:181-222
+    num_assets = 0
+    asset_folder = _assets("thin")
+    box_sizes = None
+    min_state_ratio, max_state_ratio = _ratio([0.3, 0.05, 0.05], [0.85, 0.95, 0.95], (-_PI,) * 3, (_PI,) * 3)
+    color = [170, 66, 66]

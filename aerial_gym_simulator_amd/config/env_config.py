@@ -99,3 +99,16 @@ class DynamicEnvironmentCfg(EnvWithObstaclesCfg):
     class env_config:
         include_asset_type = {"objects": True}
         asset_type_to_dict_map = {"objects": A.object_asset_params}
+
+
+class ForestEnvCfg(EnvWithObstaclesCfg):
+    """forest_env.py: a multi-link cylinder tree + 35 objects over a floor slab, 10 x 10 x 4 m."""
+
+    class env(EnvWithObstaclesCfg.env):
+        collision_force_threshold = 0.005
+        lower_bound_min = lower_bound_max = [-5.0, -5.0, -1.0]
+        upper_bound_min = upper_bound_max = [5.0, 5.0, 3.0]
+
+    class env_config:
+        include_asset_type = {"trees": True, "objects": True, "bottom_wall": True}
+        asset_type_to_dict_map = {"trees": A.tree_asset_params, "objects": A.object_asset_params, "bottom_wall": A.bottom_wall}

@@ -59,6 +59,30 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
 // ------------------------------------------------------------------------------------ LBVH
 constexpr float kBvhLargeFraction = 0.75f;
 
+// Multi-primitive assets (URDFs with several links: the reference's `trees`): every primitive is its own rigid
+// piece whose pose follows the asset's,  prim = asset (x) local.  prim_state [N][P][13] then plays the role of
+// asset_state for agx_scene_transform / agx_boxes_from_assets.
+__global__ void __launch_bounds__(256) k_prims_from_assets(int n, int np_, int na, const int32_t *__restrict__ prim_asset,
+                                                            const float *__restrict__ asset_state,
+                                                            const float *__restrict__ local_pos,
+                                                            const float *__restrict__ local_quat,
+                                                            const uint8_t *__restrict__ mask, float *__restrict__ prim_state) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * np_) return;
+  const int env = idx / np_, p = idx % np_;
+  if (mask && !mask[env]) return;
+  const float *as = asset_state + ((size_t)env * na + prim_asset[idx]) * 13;  // per env: the free assets are shuffled
+  const float *lp = local_pos + (size_t)idx * 3, *lq = local_quat + (size_t)idx * 4;
+  const Q4 qa = Q4{as[3], as[4], as[5], as[6]};
+  const V3 c = tf_apply(qa, V3{as[0], as[1], as[2]}, V3{lp[0], lp[1], lp[2]});
+  const Q4 q = quat_mul(qa, Q4{lq[0], lq[1], lq[2], lq[3]});
+  float *o = prim_state + (size_t)idx * 13;
+  o[0] = c.x; o[1] = c.y; o[2] = c.z;
+  o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+#pragma unroll
+  for (int k = 7; k < 13; ++k) o[k] = as[k];
+}
+
 // Kinematic obstacles (EnvManager.step(actions, env_actions), obstacle_manager.py:40-44): the env action of an
 // obstacle is its twist (world-frame linear and angular velocity), written into the root state every sub-step;
 // the pose follows with the integrator's rule (p += v dt, exponential map for q) for k sub-steps.
@@ -384,6 +408,16 @@ extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, co
 }
 
 extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
+
+extern "C" int agx_prims_from_assets(int n, int num_prims, int num_assets, const int32_t *prim_asset, const float *asset_state,
+                                     const float *local_pos, const float *local_quat, const uint8_t *mask, float *prim_state,
+                                     void *stream) {
+  AGX_REQUIRE(n > 0 && num_prims > 0 && num_assets > 0, "bad sizes");
+  AGX_REQUIRE(prim_asset && asset_state && local_pos && local_quat && prim_state, "null buffer");
+  hipLaunchKernelGGL(k_prims_from_assets, dim3(blocks_for(n * num_prims, 256)), dim3(256), 0, (hipStream_t)stream, n, num_prims,
+                     num_assets, prim_asset, asset_state, local_pos, local_quat, mask, prim_state);
+  return check_launch("agx_prims_from_assets");
+}
 
 extern "C" int agx_assets_integrate(int n, int num_assets, float *asset_state, const float *twist, float dt, int k, void *stream) {
   AGX_REQUIRE(n > 0 && num_assets > 0 && k >= 0 && k <= AGX_MAX_SUBSTEPS && dt > 0.0f, "bad arguments");

@@ -66,11 +66,7 @@ class AssetManager:
         lib, stream, p = env._lib, env._stream(), _lib.dptr
         st = self.env_asset_state_tensor
         _lib.check(lib.agx_assets_integrate(N, K, p(st), p(tw), float(self.g["dt"]), int(k_substeps), stream), "agx_assets_integrate")
-        _lib.check(lib.agx_scene_transform(N, sc.num_tris, K, p(sc.tri_local), p(sc.tri_asset), p(st), None, p(sc.tri_world), stream),
-                   "agx_scene_transform")
-        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), None,
-                                     p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
-        _lib.check(lib.agx_boxes_from_assets(N, K, p(st), p(sc.half_extents), None, p(sc.boxes_soa), stream), "agx_boxes_from_assets")
+        self._refresh_geometry(env, None)
 
     def reset_masked(self, env):
         if self.scene.num_assets == 0:
@@ -90,9 +86,21 @@ class AssetManager:
                                  p(self.asset_max_state_ratio), int(num_obstacles), int(self.num_keep_in_env), p(st), stream),
             "agx_reset_assets",
         )
-        mk = p(g["reset_mask"])
-        # (these three return immediately for envs whose mask is 0)
-        _lib.check(lib.agx_scene_transform(N, sc.num_tris, K, p(sc.tri_local), p(sc.tri_asset), p(st), mk, p(sc.tri_world), stream),
+        self._refresh_geometry(env, p(g["reset_mask"]))
+
+    def _refresh_geometry(self, env, mk):
+        """World-frame triangles, BVH and collision boxes of the envs flagged in `mk` (None = all); the kernels
+        return immediately for clean envs.  Multi-primitive scenes first derive the primitive poses."""
+        sc = self.scene
+        N, K = sc.num_envs, sc.num_assets
+        lib, stream, p = env._lib, env._stream(), _lib.dptr
+        st, KP = self.env_asset_state_tensor, sc.num_prims
+        if sc.has_prims:
+            _lib.check(lib.agx_prims_from_assets(N, KP, K, p(sc.prim_asset), p(st), p(sc.prim_local_pos), p(sc.prim_local_quat), mk,
+                                                 p(sc.prim_state), stream), "agx_prims_from_assets")
+            st = sc.prim_state
+        _lib.check(lib.agx_scene_transform(N, sc.num_tris, KP, p(sc.tri_local), p(sc.tri_asset), p(st), mk, p(sc.tri_world), stream),
                    "agx_scene_transform")
-        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), mk, p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
-        _lib.check(lib.agx_boxes_from_assets(N, K, p(st), p(sc.half_extents), mk, p(sc.boxes_soa), stream), "agx_boxes_from_assets")
+        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), mk,
+                                     p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
+        _lib.check(lib.agx_boxes_from_assets(N, KP, p(st), p(sc.half_extents), mk, p(sc.boxes_soa), stream), "agx_boxes_from_assets")

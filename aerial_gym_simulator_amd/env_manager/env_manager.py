@@ -183,7 +183,7 @@ class EnvManager(BaseManager):
         B.rng_seed = self.rng_seed
         B.step_counter = 0
         B.boxes = p(self.scene.boxes_soa) if self.scene.num_assets > 0 else None
-        B.num_boxes = self.scene.num_assets
+        B.num_boxes = self.scene.num_prims  # collision boxes: one per primitive (= per asset for box scenes)
         imu = self.robot_manager.imu_sensor
         B.body_force = p(imu.body_force) if imu is not None else None
         self._buffers = B

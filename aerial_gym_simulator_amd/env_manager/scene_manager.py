@@ -63,7 +63,12 @@ class SceneManager:
         slot_rlo = np.array([t.random_box_size_range[0] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
         slot_rhi = np.array([t.random_box_size_range[1] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
         # geometry per asset type: URDF folder when configured and present, else the restated box-size table
-        choices = [self._box_choices(t) for t in slots]
+        self.num_prims, self.has_prims = K, False
+        variants = [self._variants(t) for t in slots]
+        if any(len(v) != 1 or v[0].kind != "box" or not np.allclose(v[0].T, np.eye(4)) for vs in variants for v in vs):
+            self._init_general(slots, variants, nk, nf, N, scene_seed_base, shard_rank)
+            return
+        choices = [[v[0].dims for v in vs] for vs in variants]
         max_choices = max(len(c) for c in choices)
         slot_nchoice = np.array([len(c) for c in choices])
         slot_choices = np.zeros((len(slots), max_choices, 3), np.float32)
@@ -89,20 +94,93 @@ class SceneManager:
     _urdf_cache = {}
 
     @classmethod
-    def _box_choices(cls, acfg):
-        """Box sizes an instance of this asset type may take (one is drawn per instance and env)."""
+    def _variants(cls, acfg):
+        """The shapes an instance of this asset type may take: a list of variants, each a list of primitives
+        (assets.Prim).  One variant is drawn per instance and env (asset_loader.py:44-56)."""
+        from ..assets import Prim, list_urdf_files, load_urdf_primitives
+
         folder = getattr(acfg, "asset_folder", None)
         if folder and os.path.isdir(folder):
-            from ..assets import list_urdf_files, parse_box_urdf
-
             files = [acfg.file] if getattr(acfg, "file", None) else list_urdf_files(folder)
             if not files:
                 raise ValueError(f"no URDF files in {folder}")
             key = (folder, tuple(files), bool(getattr(acfg, "use_collision_mesh_instead_of_visual", False)))
             if key not in cls._urdf_cache:  # asset_loader.py:66-70 keeps a buffer of loaded files, too
-                cls._urdf_cache[key] = [parse_box_urdf(os.path.join(folder, f), key[2]).size for f in files]
+                cls._urdf_cache[key] = [load_urdf_primitives(os.path.join(folder, f), key[2]) for f in files]
             return cls._urdf_cache[key]
-        return list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
+        if folder and getattr(acfg, "box_sizes", None) is None and getattr(acfg, "random_box_size_range", None) is None:
+            raise FileNotFoundError(f"asset folder {folder} does not exist (point asset_folder at your aerial_gym "
+                                    "resources/models/environment_assets/<set> directory)")
+        sizes = list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
+        return [[Prim("box", tuple(float(v) for v in sz), np.eye(4), "base_link", 0)] for sz in sizes]
+
+    def _init_general(self, slots, variants, nk, nf, N, scene_seed_base, shard_rank):
+        """Scenes with multi-primitive assets (several links, cylinders): every primitive is its own rigid piece
+        (own triangles in its own frame, own collision box) tied to its asset by agx_prims_from_assets.  The
+        primitive layout is fixed by the canonical slot order; which asset INDEX owns a slot differs per env
+        (the reference shuffles the free assets of every env, asset_loader.py:179-183)."""
+        from ..assets import half_extents, num_triangles, quat_xyzw_from_matrix, tessellate
+
+        K = len(slots)
+        self.has_prims = True
+        P_s = [max(len(v) for v in vs) for vs in variants]                    # primitives per slot
+        tri_s = [[max(num_triangles((v[q] if q < len(v) else v[0]).kind) for v in vs) for q in range(P_s[s])]
+                 for s, vs in enumerate(variants)]                            # triangles per primitive slot
+        prim_base = np.concatenate([[0], np.cumsum(P_s)]).astype(int)
+        KP = self.num_prims = int(prim_base[-1])
+        tri_count = np.array([t for ts in tri_s for t in ts], int)
+        tri_base = np.concatenate([[0], np.cumsum(tri_count)]).astype(int)
+        T = self.num_tris = int(tri_base[-1])
+        ids_per_slot = np.array([max(len(v) for v in vs) if getattr(t, "per_link_semantic", False) and t.semantic_id < 0 else 1
+                                 for t, vs in zip(slots, variants)])
+        semantic_offset = self.semantic_offset = semantic_id_offset(shard_rank, N, int(ids_per_slot.sum()))
+        lo, hi = np.zeros((N, K, 13), np.float32), np.zeros((N, K, 13), np.float32)
+        prim_asset = np.zeros((N, KP), np.int32)
+        prim_half, prim_lpos = np.zeros((N, KP, 3), np.float32), np.zeros((N, KP, 3), np.float32)
+        prim_lquat = np.zeros((N, KP, 4), np.float32)
+        prim_sem = np.zeros((N, KP), np.int64)
+        tri_local = np.zeros((N, T, 9), np.float32)
+        asset_sem = np.zeros((N, K), np.int64)
+        counter = 100 + semantic_offset
+        free_idx = list(range(nk, nk + nf))
+        for i in range(N):
+            rng = np.random.default_rng(scene_seed_base + shard_rank * N + i)
+            order = free_idx[:]
+            random.shuffle(order)
+            perm = list(range(nk)) + order
+            u = rng.uniform(0.0, 1.0, (K, 3)).astype(np.float32)
+            pick = rng.integers(0, 1 << 30, K)
+            for j, s_ in enumerate(perm):  # asset index j of this env is canonical slot s_
+                t = slots[s_]
+                lo[i, j], hi[i, j] = t.min_state_ratio, t.max_state_ratio
+                vs = variants[s_]
+                v = vs[int(pick[j]) % len(vs)]
+                if getattr(t, "random_box_size_range", None) is not None:
+                    rl, rh = np.array(t.random_box_size_range[0], np.float32), np.array(t.random_box_size_range[1], np.float32)
+                    from ..assets import Prim
+                    v = [Prim("box", tuple(float(x) for x in (rl + (rh - rl) * u[j])), np.eye(4), "base_link", 0)]
+                base_id = t.semantic_id if t.semantic_id >= 0 else counter
+                asset_sem[i, j] = base_id
+                links = sorted({p.link_index for p in v})
+                for q in range(P_s[s_]):
+                    pr = v[q] if q < len(v) else v[0]  # padding = a duplicate of primitive 0 (same hits, same ids)
+                    pg = prim_base[s_] + q
+                    prim_asset[i, pg] = j
+                    prim_half[i, pg] = half_extents(pr)
+                    prim_lpos[i, pg] = pr.T[:3, 3]
+                    prim_lquat[i, pg] = quat_xyzw_from_matrix(pr.T[:3, :3])
+                    per_link = getattr(t, "per_link_semantic", False) and t.semantic_id < 0
+                    prim_sem[i, pg] = base_id + (links.index(pr.link_index) if per_link else 0)
+                    tr = tessellate(pr).reshape(-1, 9)
+                    tri_local[i, tri_base[pg]: tri_base[pg] + len(tr)] = tr
+                    if len(tr) < tri_count[pg]:  # a box in a slot that may also hold a cylinder: repeat its triangles
+                        reps = tri_count[pg] // len(tr)
+                        tri_local[i, tri_base[pg]: tri_base[pg + 1]] = np.tile(tr, (reps, 1))
+                if t.semantic_id < 0:
+                    counter += int(ids_per_slot[s_])
+        tri_prim = np.repeat(np.arange(KP, dtype=np.int32), tri_count)
+        self._np = dict(lo=lo, hi=hi, sem=asset_sem, size=np.zeros((N, K, 3), np.float32), prim_asset=prim_asset, prim_half=prim_half,
+                        prim_lpos=prim_lpos, prim_lquat=prim_lquat, prim_sem=prim_sem, tri_local=tri_local, tri_prim=tri_prim)
 
     def prepare_for_simulation(self, global_tensor_dict):
         g, N, dev, K = global_tensor_dict, self.num_envs, self.device, self.num_assets
@@ -113,6 +191,8 @@ class SceneManager:
             self.boxes_soa = None
             return
         d = self._np
+        if self.has_prims:
+            return self._prepare_general(g, d)
         self.half_extents = torch.from_numpy(d["size"] * 0.5).to(dev)
         g["asset_min_state_ratio"] = torch.from_numpy(d["lo"]).to(dev)
         g["asset_max_state_ratio"] = torch.from_numpy(d["hi"]).to(dev)
@@ -139,3 +219,28 @@ class SceneManager:
         g["scene_tri_world"] = self.tri_world
         g["scene_tri_seg"] = self.tri_seg
         g["scene_bvh_nodes"] = self.bvh_nodes
+
+    def _prepare_general(self, g, d):
+        N, dev, K, KP, T = self.num_envs, self.device, self.num_assets, self.num_prims, self.num_tris
+        t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dt)  # noqa: E731
+        g["asset_min_state_ratio"], g["asset_max_state_ratio"] = t(d["lo"]), t(d["hi"])
+        self.asset_semantic_id = t(d["sem"])
+        self.asset_state = torch.zeros(N, K, 13, device=dev)
+        self.asset_state[..., 6] = 1.0
+        g["env_asset_state_tensor"] = self.asset_state
+        g["obstacle_position"], g["obstacle_orientation"] = self.asset_state[..., 0:3], self.asset_state[..., 3:7]
+        g["obstacle_linvel"], g["obstacle_angvel"] = self.asset_state[..., 7:10], self.asset_state[..., 10:13]
+        # primitives: the pieces the scene kernels see in place of assets
+        self.prim_asset = t(d["prim_asset"])            # [N, P] owning asset index (per env: the free assets are shuffled)
+        self.prim_local_pos, self.prim_local_quat = t(d["prim_lpos"]), t(d["prim_lquat"])
+        self.half_extents = t(d["prim_half"])           # [N, P, 3]
+        self.prim_state = torch.zeros(N, KP, 13, device=dev)
+        self.prim_state[..., 6] = 1.0
+        self.tri_local = t(d["tri_local"])
+        self.tri_world = torch.zeros_like(self.tri_local)
+        self.tri_asset = t(d["tri_prim"])               # triangle -> primitive index
+        self.tri_seg = t(d["prim_sem"]).to(torch.int32)[:, self.tri_asset.long()].contiguous()
+        self.boxes_soa = torch.zeros(KP * 11, N, device=dev)
+        self.bvh_nodes = torch.zeros(N, max(T - 1, 1), 16, device=dev)
+        self.bvh_work = torch.zeros(N + 2, dtype=torch.int32, device=dev)
+        g["scene_tri_world"], g["scene_tri_seg"], g["scene_bvh_nodes"] = self.tri_world, self.tri_seg, self.bvh_nodes

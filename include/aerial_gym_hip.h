@@ -369,6 +369,14 @@ int agx_scene_transform(int num_envs, int num_tris, int num_assets, const float 
                         const int32_t *tri_asset, const float *asset_state, const uint8_t *mask,
                         float *tri_world, void *stream);
 
+/* Multi-primitive assets (URDFs with several links, e.g. the reference's `trees`): prim_state [N][P][13]
+ * pose = asset pose (x) local pose (local_pos [N][P][3], local_quat [N][P][4], prim_asset [N][P] = owning
+ * asset index in that env), velocities copied.  prim_state then stands in for asset_state (num_assets = P) in
+ * agx_scene_transform (tri_asset = primitive index) and agx_boxes_from_assets.                     */
+int agx_prims_from_assets(int num_envs, int num_prims, int num_assets, const int32_t *prim_asset,
+                          const float *asset_state, const float *local_pos, const float *local_quat,
+                          const uint8_t *mask, float *prim_state, void *stream);
+
 /* Kinematic obstacles: EnvManager.step(actions, env_actions) with env_actions = obstacle twists
  * (obstacle_manager.py:40-44, examples/dynamic_env_example.py:33-45).  twist [N][K][6] = world-frame
  * linear and angular velocity; asset_state [N][K][13] gets the twist in its velocity slots and its

@@ -260,6 +260,14 @@ def scene_transform(tri_local, tri_asset, asset_state):
     return out
 
 
+def prims_from_assets(prim_asset, asset_state, local_pos, local_quat):
+    n, na = asset_state.shape[0], asset_state.shape[1]
+    pa = np.ascontiguousarray(prim_asset, dtype=np.int32)  # [N, P]
+    out = np.zeros((n, pa.shape[1], 13), np.float32)
+    lib().orc_prims_from_assets(n, pa.shape[1], na, _p(pa), _p(_f(asset_state)), _p(_f(local_pos)), _p(_f(local_quat)), _p(out))
+    return out
+
+
 def sensor_pose(state, local_pos, local_quat, frame_quat):
     n, ns = local_pos.shape[0], local_pos.shape[1]
     pos = np.zeros((n, ns, 3), np.float32)

@@ -602,3 +602,17 @@ void orc_sensor_postprocess_points(size_t count, float *pixels, const float *z_n
     for (int c = 0; c < 3; ++c) pixels[3 * k + c] = v[c];
   }
 }
+
+/* f3: multi-primitive assets -- prim pose = asset pose (x) local pose (tf_apply / quat_mul of utils/math.py) */
+void orc_prims_from_assets(int n, int np_, int na, const int32_t *prim_asset, const float *asset_state,
+                           const float *local_pos, const float *local_quat, float *prim_state) {
+  for (int e = 0; e < n; ++e)
+    for (int p = 0; p < np_; ++p) {
+      const float *as = asset_state + ((size_t)e * na + prim_asset[(size_t)e * np_ + p]) * 13;
+      const float *lp = local_pos + ((size_t)e * np_ + p) * 3, *lq = local_quat + ((size_t)e * np_ + p) * 4;
+      float *o = prim_state + ((size_t)e * np_ + p) * 13;
+      tf_apply(as + 3, as, lp, o);
+      quat_mul(as + 3, lq, o + 3);
+      for (int k = 7; k < 13; ++k) o[k] = as[k];
+    }
+}

@@ -110,3 +110,89 @@ def test_restated_box_tables_match_the_reference_urdfs():
     # with the trees / thin sets (cylinders) the loader says what is missing instead of guessing
     with pytest.raises(NotImplementedError):
         parse_box_urdf(os.path.join(REF_ASSETS, "trees", "tree_0.urdf"))
+
+
+FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "assets")
+
+
+def test_urdf_primitives_forward_kinematics_and_tessellation():
+    from aerial_gym_simulator_amd.assets import half_extents, load_urdf_primitives, quat_xyzw_from_matrix, tessellate
+    from aerial_gym_simulator_amd.assets.urdf_primitives import rpy_matrix
+
+    ps = load_urdf_primitives(os.path.join(FIX, "trees", "tree_a.urdf"))
+    assert [p.kind for p in ps] == ["cylinder"] * 3 and [p.link for p in ps] == ["trunk", "branch_1", "branch_2"]
+
+    def T(xyz, rpy):
+        m = np.eye(4)
+        m[:3, :3], m[:3, 3] = rpy_matrix(*rpy), xyz
+        return m
+
+    j01, j12 = T([0.4, 0.2, 2.2], [0.9, 0.3, -0.5]), T([0.0, 0.3, 0.6], [-0.7, 0.2, 1.1])
+    assert np.allclose(ps[0].T, T([0.1, -0.05, 1.5], [0, 0.1, 0.3]))          # root link: only the visual origin
+    assert np.allclose(ps[1].T, j01)                                            # child: joint origin
+    assert np.allclose(ps[2].T, j01 @ j12 @ T([0, 0, 0.2], [0, 0, 0]))          # grandchild: chain x visual origin
+    for p in ps:
+        q = quat_xyzw_from_matrix(p.T[:3, :3])
+        x, y, z, w = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(R, p.T[:3, :3], atol=1e-12) and w >= 0
+        tris = tessellate(p).astype(np.float64)
+        assert tris.shape == (36, 3, 3)
+        vol = np.einsum("ij,ij->i", tris[:, 0], np.cross(tris[:, 1], tris[:, 2])).sum() / 6  # closed, outward normals
+        r, L = p.dims
+        assert abs(vol - 0.5 * 9 * r * r * np.sin(2 * np.pi / 9) * L) < 1e-6 * max(vol, 1)
+        assert np.abs(tris[..., 2]).max() <= L / 2 + 1e-6 and np.abs(np.linalg.norm(tris[..., :2], axis=-1)).max() <= r + 1e-6
+        assert half_extents(p) == (r, r, L / 2)
+    mixed = load_urdf_primitives(os.path.join(FIX, "trees", "tree_b.urdf"))
+    assert [p.kind for p in mixed] == ["box", "cylinder"] and tessellate(mixed[0]).shape == (12, 3, 3)
+
+
+def test_multi_primitive_scene_layout():
+    """canonical primitive layout, per-env owner indices, padding by duplication, per-link semantic ids"""
+    import random
+
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import asset_config as A
+    from aerial_gym_simulator_amd.config.env_config import ForestEnvCfg
+    from aerial_gym_simulator_amd.env_manager.scene_manager import SceneManager
+
+    class trees(A.tree_asset_params):
+        num_assets = 2
+        asset_folder = os.path.join(FIX, "trees")
+
+    class Cfg(ForestEnvCfg):
+        class env_config:
+            include_asset_type = {"trees": True, "objects": True, "bottom_wall": True}
+            asset_type_to_dict_map = {"trees": trees, "objects": A.object_asset_params, "bottom_wall": A.bottom_wall}
+
+    random.seed(0)
+    sc = SceneManager(Cfg, 6, "cpu", None)
+    assert sc.has_prims and sc.num_assets == 38 and sc.keep_in_env_num == 3
+    assert sc.num_prims == 1 + 2 * 3 + 35 and sc.num_tris == 12 + 2 * 3 * 36 + 35 * 12
+    d = sc._np
+    pa = d["prim_asset"]
+    assert all(sorted(set(pa[i])) == list(range(38)) for i in range(6))        # every asset owns at least one primitive
+    assert (pa[:, 0] == 0).all() and (pa[:, 1:4] == 1).all() and (pa[:, 4:7] == 2).all()  # keep_in_env assets are not shuffled
+    assert any(not np.array_equal(pa[0, 7:], pa[i, 7:]) for i in range(1, 6))  # the free objects are, per env
+    # a 2-link tree in a 3-primitive slot: the third primitive duplicates the first (same box, same triangles, same id)
+    two_link = [(i, s) for i in range(6) for s in (1, 4) if np.array_equal(d["prim_half"][i, s], np.float32([0.25, 0.2, 0.4]))]
+    assert two_link, "tree_b.urdf (box stump + pole) was never drawn"
+    i, s = two_link[0]
+    assert np.array_equal(d["prim_half"][i, s + 2], d["prim_half"][i, s]) and d["prim_sem"][i, s + 2] == d["prim_sem"][i, s]
+    t0 = d["tri_local"][i, 12 + (s - 1) * 36: 12 + s * 36]
+    assert np.array_equal(t0[:12], t0[12:24])  # a box in a 36-triangle slot: its 12 triangles repeated
+    sem = d["prim_sem"]
+    assert sem[0, 0] == 13 and sem[0, 1] == 100 and set(np.diff(sem[0, 1:4])) <= {0, 1}  # floor id, then per-link ids from 100
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="reference tree not present (GPU box)")
+def test_reference_trees_and_thin_sets_load():
+    from aerial_gym_simulator_amd.assets import list_urdf_files, load_urdf_primitives
+
+    for sub, n_prims in (("trees", 13), ("thin", 1)):
+        files = list_urdf_files(os.path.join(REF_ASSETS, sub))
+        for f in files[:25]:
+            ps = load_urdf_primitives(os.path.join(REF_ASSETS, sub, f))
+            assert len(ps) == n_prims and all(np.isfinite(p.T).all() for p in ps)
