@@ -45,6 +45,7 @@ class SceneManager:
         self.keep_in_env_num = len(keep_slots)
         K = self.num_assets = len(keep_slots) + len(free_slots)
         self.num_tris = 12 * K
+        self.num_prims, self.has_prims = K, False  # collision / scene pieces: one per asset unless a URDF has several links
         # sharding: start of this rank's slice of the global asset counter
         semantic_offset = self.semantic_offset = semantic_id_offset(shard_rank, N, K)
         if K == 0:
@@ -63,7 +64,6 @@ class SceneManager:
         slot_rlo = np.array([t.random_box_size_range[0] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
         slot_rhi = np.array([t.random_box_size_range[1] if t.random_box_size_range else [0, 0, 0] for t in slots], np.float32)
         # geometry per asset type: URDF folder when configured and present, else the restated box-size table
-        self.num_prims, self.has_prims = K, False
         variants = [self._variants(t) for t in slots]
         if any(len(v) != 1 or v[0].kind != "box" or not np.allclose(v[0].T, np.eye(4)) for vs in variants for v in vs):
             self._init_general(slots, variants, nk, nf, N, scene_seed_base, shard_rank)

@@ -245,6 +245,32 @@ def cpu_baseline_dynamics(num_envs, budget_s=12.0):
     }
 
 
+def cpu_baseline_raycast(task, budget_s=8.0, sample_envs=512):
+    """The CPU oracle's ray-cast (C port of the reference's camera kernel over a median-split BVH, OpenMP over
+    envs) on a sample of the GPU task's own scenes and sensor poses: frames of `sample_envs` envs for ~budget_s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as orc
+
+    env = task.sim_env
+    sc, sen = env.scene, env.robot_manager.warp_sensor
+    m = min(sample_envs, env.num_envs)
+    npy = lambda t: np.ascontiguousarray(t[:m].detach().cpu().numpy())  # noqa: E731
+    tris, seg, pos, quat = npy(sc.tri_world), npy(sc.tri_seg), npy(sen.sensor_position), npy(sen.sensor_orientation)
+    cfg = sen.cfg
+    kinv, cx, cy = orc.camera_kinv(cfg.width, cfg.height, cfg.horizontal_fov_deg)
+    orc.raycast_camera(cfg.width, cfg.height, kinv, cfg.max_range, cx, cy, "depth", pos, quat, tris, seg, use_bvh=True)  # warm-up
+    frames, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        orc.raycast_camera(cfg.width, cfg.height, kinv, cfg.max_range, cx, cy, "depth", pos, quat, tris, seg, use_bvh=True)
+        frames += 1
+    dt = time.perf_counter() - t0
+    rays = frames * m * cfg.num_sensors * cfg.width * cfg.height
+    return {"value": frames * m / dt, "unit": "env-frames/s", "rays_per_s": rays / dt, "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+            "kind": "port", "sample": f"{frames} frames of {m} envs ({dt:.1f} s): oracle C port of the depth+seg camera kernel, BVH build "
+                                      "included in every frame (OpenMP over envs), scenes and poses of the GPU run"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -374,6 +400,9 @@ def main():
                 "raycast_roofline": {"bound": "hbm", "achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N,
                                      "traffic": pmc_traffic("k_raycast_depth_%d" % N)}})
+            if not args.no_cpu_baseline:
+                out["plus_depth"]["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
+                out["plus_depth"]["gpu_frames_per_s_kernel"] = N / kt2
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -196,3 +196,13 @@ def test_reference_trees_and_thin_sets_load():
         for f in files[:25]:
             ps = load_urdf_primitives(os.path.join(REF_ASSETS, sub, f))
             assert len(ps) == n_prims and all(np.isfinite(p.T).all() for p in ps)
+
+
+def test_empty_scene_has_the_attributes_the_binding_reads():
+    """EnvManager._bind reads scene.num_prims / boxes for every env, also the obstacle-free ones"""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.env_config import EmptyEnvCfg
+    from aerial_gym_simulator_amd.env_manager.scene_manager import SceneManager
+
+    sc = SceneManager(EmptyEnvCfg, 4, "cpu", None)
+    assert (sc.num_assets, sc.num_prims, sc.num_tris, sc.has_prims) == (0, 0, 0, False)

@@ -477,3 +477,40 @@ def test_stereo_occlusion_ray_with_zero_direction_component(orc):
     for y, x in g["pixels"]:
         assert ref_seg[0, 0, y, x] == -2 and ref_px[0, 0, y, x] == -1.0  # occluded
     assert np.array_equal(got_seg, ref_seg) and np.array_equal(got_px, ref_px)
+
+
+def test_full_size_frame_properties(orc):
+    """BASELINE config-3 size (8192 envs x 64 x 48 rays, 1272 triangles per env): size-independent properties --
+    the frame is deterministic, equals the concatenation of its two 4096-env halves (envs never interact),
+    a masked rebuild of half the envs leaves images untouched, and a random subset of envs matches the oracle."""
+    n = 8192
+    base = random_box_scene(64, 100, seed=5)  # 64 distinct scenes tiled over the batch
+    rep = n // 64
+    sc = {k: (np.tile(v, (rep,) + (1,) * (v.ndim - 1)) if k in ("tri_local", "tri_seg", "asset_state", "half") else v) for k, v in base.items()}
+    S = Scene(sc)
+    S.build()
+    st = random_robot_states(n, 77, *base["bounds"])
+    lp = np.tile(np.float32([0.1, 0.0, 0.03]), (n, 1, 1))
+    lq = np.tile(np.float32([0, 0, 0, 1]), (n, 1, 1))
+    frame = orc.quat_from_euler(np.deg2rad(np.array([[-90.0, 0.0, -90.0]], np.float32)))[0]
+    pos, quat = orc.sensor_pose(st, lp, lq, frame)
+    kinv, cx, cy = orc.camera_kinv(64, 48, 87.0)
+    px, seg = S.camera(64, 48, kinv, 10.0, cx, cy, 1, pos, quat)
+    px2, seg2 = S.camera(64, 48, kinv, 10.0, cx, cy, 1, pos, quat)
+    assert np.array_equal(px, px2) and np.array_equal(seg, seg2)  # deterministic
+    half = n // 2
+    for lo in (0, half):
+        sub = {k: (v[lo:lo + half] if k in ("tri_local", "tri_seg", "asset_state", "half") else v) for k, v in sc.items()}
+        Sh = Scene(sub)
+        Sh.build()
+        hp, hs = Sh.camera(64, 48, kinv, 10.0, cx, cy, 1, pos[lo:lo + half], quat[lo:lo + half])
+        assert np.array_equal(hp, px[lo:lo + half]) and np.array_equal(hs, seg[lo:lo + half])
+    mask = (np.arange(n) % 2).astype(np.uint8)
+    S.build(mask)  # rebuild the odd envs from unchanged poses: same trees, same images
+    px3, seg3 = S.camera(64, 48, kinv, 10.0, cx, cy, 1, pos, quat)
+    assert np.array_equal(px3, px) and np.array_equal(seg3, seg)
+    pick = np.random.default_rng(3).choice(n, 24, replace=False)
+    tris = orc.scene_transform(sc["tri_local"][pick], sc["tri_asset"], sc["asset_state"][pick])
+    rp, rs = orc.raycast_camera(64, 48, kinv, 10.0, cx, cy, "depth", pos[pick], quat[pick], tris, sc["tri_seg"][pick], use_bvh=True)
+    assert np.array_equal(px[pick], rp) and np.array_equal(seg[pick], rs)
+    assert (seg >= 0).mean() > 0.9
