@@ -334,10 +334,19 @@ AGX_DEV bool collide_trajectory(const float *__restrict__ boxes, int nb, int n, 
                                 int tid, V3 lo, V3 hi, float r) {
   bool hit = false;
   const float r2 = r * r;
+  // the cull data (centre, bounding radius) of box b + 1 is fetched while box b is processed: with few envs the
+  // loop is a chain of dependent HBM round trips otherwise (101 us at 256 envs x 106 boxes)
+  const float *b0 = boxes + i;
+  float ncx = 0.0f, ncy = 0.0f, ncz = 0.0f, nrad = 0.0f;
+  if (nb > 0) { ncx = b0[0]; ncy = b0[(size_t)n]; ncz = b0[2 * (size_t)n]; nrad = b0[10 * (size_t)n]; }
   for (int b = 0; b < nb; ++b) {
     const float *bx = boxes + (size_t)b * 11 * n + i;
-    V3 c = V3{bx[0], bx[(size_t)n], bx[2 * (size_t)n]};
-    float reach = bx[10 * (size_t)n] + r + 1.0e-3f;
+    V3 c = V3{ncx, ncy, ncz};
+    float reach = nrad + r + 1.0e-3f;
+    if (b + 1 < nb) {
+      const float *bn = bx + (size_t)11 * n;
+      ncx = bn[0]; ncy = bn[(size_t)n]; ncz = bn[2 * (size_t)n]; nrad = bn[10 * (size_t)n];
+    }
     float dx = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.0f);
     float dy = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.0f);
     float dz = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.0f);

@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs L
   V3 partner = ro;
   if (VARIANT == RAY_STEREO) partner = ro + wp_quat_rotate(sq, V3{-CA.baseline, 0.0f, 0.0f});
   const int tiles_x = (width + 7) >> 3, tiles_y = (height + 7) >> 3;
-  for (int tile = wave; tile < tiles_x * tiles_y; tile += kRayThreads / 64) {
+  // gridDim.z workgroups share the tiles of one (env, sensor): small batches still fill the GPU
+  for (int tile = blockIdx.z * (kRayThreads / 64) + wave; tile < tiles_x * tiles_y; tile += gridDim.z * (kRayThreads / 64)) {
     const int x = (tile % tiles_x) * 8 + (lane & 7), y = (tile / tiles_x) * 8 + (lane >> 3);
     const bool active = x < width && y < height;
     V3 local = V3{0.0f, 0.0f, 1.0f};
@@ -485,7 +486,14 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(n, ns);
+  // 256 CUs x 32 waves = 8192 resident waves, and tails want ~2x that in the grid: split an image's 8x8 tiles over several workgroups when the
+  // batch alone cannot provide them (256 envs: 199 -> see profiles/r01_small_batch.txt us per frame)
+  const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
+  const int tiles = ((width + 7) / 8) * ((height + 7) / 8), waves_per_wg = kRayThreads / 64;
+  int split = (16384 + n * ns * waves_per_wg - 1) / (n * ns * waves_per_wg);
+  const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
+  split = split < 1 ? 1 : (split > max_split ? max_split : split);
+  dim3 grid(n, ns, AGX_RAY_USE_LDS ? 1 : split);
   if (AGX_RAY_USE_LDS && lds <= 160 * 1024) {
     hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors,
                        pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);

@@ -15,7 +15,7 @@
 namespace agx {
 
 constexpr float kBoxEps = 1.0e-3f;
-constexpr int kBvhThreads = 256;
+constexpr int kBvhThreads = 512;
 constexpr int kBvhMaxTris = 2048;
 
 __global__ void __launch_bounds__(256) k_scene_transform(int n, int nt, int na, const float *__restrict__ tri_local,

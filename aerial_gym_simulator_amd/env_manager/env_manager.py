@@ -82,6 +82,7 @@ class EnvManager(BaseManager):
         self.global_tensor_dict = {}
         self.keep_in_env = None
         self.step_counter = 0
+        self._stream_cache = None
         self._lib = None
         self.populate_env(env_cfg=self.cfg, sim_cfg=self.sim_config)
         self.prepare_sim()
@@ -242,7 +243,15 @@ class EnvManager(BaseManager):
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
-        return _lib.current_stream(self.device)
+        """torch's current stream on this device.  Looked up once per public call (step / reset / render ...):
+        torch.cuda.current_stream() costs microseconds and a navigation step makes ~15 launches."""
+        s = self._stream_cache
+        if s is None:
+            s = self._stream_cache = _lib.current_stream(self.device)
+        return s
+
+    def _new_call(self):
+        self._stream_cache = None
 
     def _require_device(self):
         if self._buffers is None:
@@ -308,6 +317,7 @@ class EnvManager(BaseManager):
 
     def reset_idx(self, env_ids=None):
         self._require_device()
+        self._new_call()
         g = self.global_tensor_dict
         if env_ids is None:
             env_ids = torch.arange(self.num_envs, device=self.device)
@@ -392,6 +402,7 @@ class EnvManager(BaseManager):
         """env_actions: [N, num_assets, 6] obstacle twists (world-frame linear + angular velocity), the
         reference's dynamic-environment interface (env_manager.py:399-416, obstacle_manager.py:40-44)."""
         self._require_device()
+        self._new_call()
         g = self.global_tensor_dict
         k = self.num_physics_steps()
         if env_actions is not None:

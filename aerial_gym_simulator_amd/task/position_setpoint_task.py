@@ -111,6 +111,7 @@ class PositionSetpointTask(BaseTask):
             self.prev_actions = self.actions  # previous step's tensor (no copy; the reward does not read it)
             self.actions = actions
             env = self.sim_env
+            env._new_call()
             self._plan.task.contents.episode_len = self.task_config.episode_len_steps
             rc = self._plan_fn(self._plan, actions.data_ptr(), env._stream())
             if rc != 0:
