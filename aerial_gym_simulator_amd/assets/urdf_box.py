@@ -2,10 +2,10 @@
 
 Every obstacle the reference ships for `env_with_obstacles` / `env_with_lidar_nav_obstacles` / `dynamic_env`
 (resources/models/environment_assets/{panels,objects,walls}/*.urdf) is a single link with one <box>.  This
-module reads such files (stdlib XML, no urdfpy / trimesh) so an asset type may point at a folder of URDFs --
-`asset_folder` + `file` exactly as in config/asset_config/env_object_config.py -- instead of the box-size table
-restated in config/asset_config.py.  Multi-link assets and other primitives (the `trees` / `thin` sets:
-cylinders) are not handled yet: parse_box_urdf raises NotImplementedError for them (remaining)."""
+module reads such files (stdlib XML, no urdfpy / trimesh) and is what tests/test_assets.py uses to check the
+box-size tables restated in config/asset_config.py against the reference's files.  The scene builder itself goes
+through assets/urdf_primitives.py, which also handles multi-link box / cylinder assets (`trees`, `thin`);
+parse_box_urdf stays strict: anything but one box in one link raises NotImplementedError."""
 import os
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass

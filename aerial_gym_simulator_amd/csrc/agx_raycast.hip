@@ -9,7 +9,7 @@
 //     XCD's L2 for the frame, so HBM sees each scene once per frame.  (An LDS-staged variant of
 //     the same traversal is kept behind AGX_RAY_USE_LDS; it is slower here, see below.)
 //   * a wavefront (64 lanes) owns an 8x8 pixel tile and walks the tree as ONE packet:
-//     every node fetch is a wave-uniform LDS broadcast, lanes vote with __ballot on which
+//     every node fetch is a wave-uniform (scalar) load, lanes vote with __ballot on which
 //     children to visit and in which order (majority near-first), and the packet's
 //     traversal stack lives in ONE VGPR spread over the 64 lanes (entry k in lane k,
 //     pushed with a lane-select v_cndmask, popped with v_readlane) -- no per-lane stacks, no scratch,
@@ -21,8 +21,8 @@
 //     the result is independent of traversal order and bit-identical to a brute-force
 //     loop over all triangles (DESIGN.md "closest-hit semantics").
 //
-// No MFMA: traversal is branchy gather work; the bound is LDS latency / VALU, with HBM
-// traffic = scene + image bytes (DESIGN.md "ray-cast roofline").
+// No MFMA: traversal is branchy gather work; the kernel is VALU-issue bound (4300 VALU per 64-ray packet,
+// profiles/r01_sq_counters_navigation.json), with HBM traffic ~ scene + image bytes.
 #include "agx_common.h"
 #include "agx_device_math.h"
 
