@@ -198,16 +198,25 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 16);
     float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
+    const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
     float tl, tr;
     bool hl = ray_box(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
     bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
     unsigned long long ml = __ballot(hl), mr = __ballot(hr);
     if (cl < 0) {
-      if (ml) { test_leaf<ANY>(r, tris, ~cl, hl); AGX_STAT(2, 1); AGX_STAT(3, __popcll(ml)); }
+      if (ml) {
+        test_leaf<ANY>(r, tris, ~cl, hl);
+        if (cl2 >= 0) test_leaf<ANY>(r, tris, cl2, hl);
+        AGX_STAT(2, cl2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(ml));
+      }
       ml = 0;
     }
     if (cr < 0) {
-      if (mr) { test_leaf<ANY>(r, tris, ~cr, hr); AGX_STAT(2, 1); AGX_STAT(3, __popcll(mr)); }
+      if (mr) {
+        test_leaf<ANY>(r, tris, ~cr, hr);
+        if (cr2 >= 0) test_leaf<ANY>(r, tris, cr2, hr);
+        AGX_STAT(2, cr2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(mr));
+      }
       mr = 0;
     }
     int next = -1;

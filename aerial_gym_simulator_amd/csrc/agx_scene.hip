@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
 
 // ------------------------------------------------------------------------------------ LBVH
 constexpr float kBvhLargeFraction = 0.75f;
+#ifdef AGX_BVH_EXPERIMENT  // profiles/bvh_sah_experiment.py: object sort codes supplied by the host
+__device__ const uint32_t *g_obj_codes = nullptr;
+#endif
 
 // Multi-primitive assets (URDFs with several links: the reference's `trees`): every primitive is its own rigid
 // piece whose pose follows the asset's,  prim = asset (x) local.  prim_state [N][P][13] then plays the role of
@@ -140,8 +143,8 @@ AGX_DEV int delta_keys(const unsigned long long *keys, int nt, int i, int j) {
 
 // Node record written to HBM (16 floats):
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
-//   [8..10] lo_right [11] 0                     [12..14] hi_right [15] 0
-// child >= 0: internal node index, child < 0: leaf holding triangle ~child.
+//   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
+// child >= 0: internal node index, child < 0: leaf holding triangle ~child and, if second >= 0, that triangle too.
 AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
@@ -234,6 +237,9 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
         }
         big = oc[3];
         parked = big < 0.0f;
+#ifdef AGX_BVH_EXPERIMENT
+        if (g_obj_codes) { code = g_obj_codes[(size_t)env * (nt / ppo) + f / ppo]; big = 0.0f; }
+#endif
       } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -248,6 +254,19 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       // the root: their huge boxes no longer inflate every level of the obstacle tree
       if (big > kBvhLargeFraction * max_ext) code |= 1u << 30;
       if (parked) code = 0xFFFFFFFEu;  // one subtree at the end of the order, culled at its root
+      // The three finest Morton bits (sub-centimetre cells) are replaced by the triangle's FACE CLASS (dominant axis
+      // and sign of its normal): inside an object (same code) the two triangles of a box face then share the whole
+      // upper word and become sibling leaves, which the emit stage folds into one two-triangle leaf -- half the
+      // in-object nodes.  A collision of classes only shapes the tree; hits never depend on it.  (The index stays
+      // alone in the low word: hipcc dropped an `& 0xFFFFFF` on the LDS read when the class lived there.)
+      if (ppo > 0 && !parked) {
+        V3 e1 = V3{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2 = V3{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+        V3 nrm = cross(e1, e2);
+        float ax = fabsf(nrm.x), ay = fabsf(nrm.y), az = fabsf(nrm.z);
+        int d = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        float comp = d == 0 ? nrm.x : (d == 1 ? nrm.y : nrm.z);
+        code = (code & ~7u) | (uint32_t)(2 * d + (comp < 0.0f ? 1 : 0));
+      }
       key = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)f;
     }
     keys[f] = key;
@@ -325,18 +344,32 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     }
   }
   __syncthreads();
-  // --- emit nodes with both child boxes inline
+  // --- emit nodes with both child boxes inline.  A child whose own two children are both leaves is folded into a
+  // two-triangle leaf (first triangle in the child slot, second in the pad slot); the folded node is never visited.
   float *out = nodes + (size_t)env * (nt - 1) * 16;
   for (int i = tid; i < n_int; i += kBvhThreads) {
-    int cl = child[2 * i], cr = child[2 * i + 1];
-    const float *a = box + (size_t)cl * 6, *b = box + (size_t)cr * 6;
-    int el = cl >= n_int ? ~(int)(uint32_t)(keys[cl - n_int] & 0xFFFFFFFFull) : cl;
-    int er = cr >= n_int ? ~(int)(uint32_t)(keys[cr - n_int] & 0xFFFFFFFFull) : cr;
+    int ref[2], second[2];
+    const float *bx[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      int c = child[2 * i + side];
+      bx[side] = box + (size_t)c * 6;
+      second[side] = -1;
+      if (c >= n_int) {
+        ref[side] = ~(int)(uint32_t)(keys[c - n_int] & 0xFFFFFFFFull);
+      } else if (child[2 * c] >= n_int && child[2 * c + 1] >= n_int) {
+        ref[side] = ~(int)(uint32_t)(keys[child[2 * c] - n_int] & 0xFFFFFFFFull);
+        second[side] = (int)(uint32_t)(keys[child[2 * c + 1] - n_int] & 0xFFFFFFFFull);
+      } else {
+        ref[side] = c;
+      }
+    }
+    const float *a = bx[0], *b = bx[1];
     float *o = out + (size_t)i * 16;
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(el);
-    o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(er);
-    o[8] = b[0]; o[9] = b[1]; o[10] = b[2]; o[11] = 0.0f;
-    o[12] = b[3]; o[13] = b[4]; o[14] = b[5]; o[15] = 0.0f;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(ref[0]);
+    o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(ref[1]);
+    o[8] = b[0]; o[9] = b[1]; o[10] = b[2]; o[11] = __int_as_float(second[0]);
+    o[12] = b[3]; o[13] = b[4]; o[14] = b[5]; o[15] = __int_as_float(second[1]);
   }
 }
 
@@ -408,6 +441,12 @@ extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, co
 }
 
 extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
+
+#ifdef AGX_BVH_EXPERIMENT
+extern "C" int agx_debug_set_obj_codes(const uint32_t *codes) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_obj_codes), &codes, sizeof(codes));
+}
+#endif
 
 extern "C" int agx_prims_from_assets(int n, int num_prims, int num_assets, const int32_t *prim_asset, const float *asset_state,
                                      const float *local_pos, const float *local_quat, const uint8_t *mask, float *prim_state,
