@@ -36,3 +36,22 @@ def orc():
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (1.0 + np.abs(b).max()))
+
+
+@pytest.fixture(autouse=True)
+def _seed_everything(request):
+    """Scene construction uses python `random` (asset shuffle, like the reference) and torch's global generator:
+    seed them per test so a failure can be reproduced."""
+    import random
+    import zlib
+
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    try:
+        import torch
+
+        torch.manual_seed(seed)
+    except ImportError:
+        pass
+    yield

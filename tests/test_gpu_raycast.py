@@ -514,3 +514,37 @@ def test_full_size_frame_properties(orc):
     rp, rs = orc.raycast_camera(64, 48, kinv, 10.0, cx, cy, "depth", pos[pick], quat[pick], tris, sc["tri_seg"][pick], use_bvh=True)
     assert np.array_equal(px[pick], rp) and np.array_equal(seg[pick], rs)
     assert (seg >= 0).mean() > 0.9
+
+
+def test_bvh_structure_covers_every_triangle_once(orc):
+    """Independent of any ray: the device-built tree reaches every triangle exactly once (one- and two-triangle
+    leaves), every child box contains its triangles, and folded nodes are unreachable."""
+    for n, k, walls in ((1, 1, False), (2, 7, False), (3, 100, True)):
+        sc = random_box_scene(n, k, seed=4, walls=walls)
+        S = Scene(sc)
+        S.build()
+        nodes = S.nodes.cpu().numpy()
+        NI = nodes.view(np.int32)
+        tris = S.tri_world.cpu().numpy().reshape(n, -1, 3, 3)
+        nt = S.nt
+        for e in range(n):
+            seen = np.zeros(nt, int)
+            stack, visited = [0], 0
+            while stack:
+                i = stack.pop()
+                visited += 1
+                assert 0 <= i < nt - 1
+                for cslot, sslot, lo, hi in ((3, 11, slice(0, 3), slice(4, 7)), (7, 15, slice(8, 11), slice(12, 15))):
+                    c, s2 = NI[e, i, cslot], NI[e, i, sslot]
+                    blo, bhi = nodes[e, i, lo], nodes[e, i, hi]
+                    if c < 0:
+                        members = [~c] + ([s2] if s2 >= 0 else [])
+                        for f in members:
+                            assert 0 <= f < nt
+                            seen[f] += 1
+                            assert (tris[e, f] >= blo - 1e-6).all() and (tris[e, f] <= bhi + 1e-6).all()  # grown by 1e-3
+                    else:
+                        assert s2 == -1
+                        stack.append(int(c))
+            assert seen.min() == 1 and seen.max() == 1
+            assert visited <= nt - 1 and (nt < 24 or visited < 0.7 * (nt - 1))  # box faces fold into two-triangle leaves
