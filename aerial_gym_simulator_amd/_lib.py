@@ -94,6 +94,7 @@ class AgxEnvBuffers(C.Structure):
         ("num_boxes", C.c_int32),
         ("step_rows", C.c_void_p * 2),
         ("step_reward", C.c_void_p),
+        ("step_signal", C.c_void_p),
         ("body_force", C.c_void_p),
     ]
 
@@ -199,6 +200,13 @@ _SIGNATURES = {
     "agx_bvh_nodes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "agx_prims_from_assets": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "agx_assets_integrate": (C.c_int, [C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P]),
+    "agx_exchange_unique_id": (C.c_int, [C.c_char_p, _P, C.c_int]),
+    "agx_exchange_create": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "agx_exchange_post": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_uint32, _P]),
+    "agx_exchange_probe": (C.c_int, [_P, _P]),
+    "agx_exchange_wait": (C.c_int, [_P, C.c_int, _P]),
+    "agx_exchange_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_uint32, C.c_int, _P]),
+    "agx_exchange_destroy": (C.c_int, [_P]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_sensor_pose": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
@@ -273,7 +281,7 @@ def load():
             raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.agx_abi_version() != 4:
+    if lib.agx_abi_version() != 5:
         raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
     _lib = lib
     return lib

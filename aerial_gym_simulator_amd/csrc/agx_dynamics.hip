@@ -25,6 +25,7 @@
 #endif
 #include "agx_device_math.h"
 #include "agx_rng.h"
+#include "agx_step_signal.h"
 
 namespace agx {
 
@@ -617,9 +618,9 @@ __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n,
 // position_setpoint_task.py:194-203, obs [N][13] row-major (what the policy network consumes)
 // reward | terminated | truncated behind the observation in the exchange row (header: step_rows)
 AGX_DEV void write_step_row_tail(const AgxEnvBuffers &B, int i, float *__restrict__ row, int obs_dim) {
-  row[obs_dim] = B.step_reward[i];
-  row[obs_dim + 1] = B.crashes[i] ? 1.0f : 0.0f;
-  row[obs_dim + 2] = B.truncations[i] ? 1.0f : 0.0f;
+  row_store(row + obs_dim, B.step_reward[i]);
+  row_store(row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
+  row_store(row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
 }
 AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target, float *__restrict__ obs,
                                 const EnvState &s, const Derived &d) {
@@ -631,14 +632,14 @@ AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const floa
   if (float *rows = B.step_rows[B.flag_parity]) {
     float *r = rows + (size_t)i * 16;
 #pragma unroll
-    for (int c = 0; c < 13; ++c) r[c] = v[c];
+    for (int c = 0; c < 13; ++c) row_store(r + c, v[c]);
     write_step_row_tail(B, i, r, 13);
   }
 }
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  if (i < n) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  step_rows_signal(B);
 }
 
 struct NavParams {
@@ -672,12 +673,10 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
 }
 
 // navigation_task.py:369-393; one wave per env so the depth min-pool is a coalesced sweep
-__global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
-                                                         const float *__restrict__ u_vec, const float *__restrict__ u_euler,
-                                                         const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
-                                                         int obs_dim, float *__restrict__ obs) {
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= n) return;
+AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target,
+                                const float *__restrict__ u_vec, const float *__restrict__ u_euler,
+                                const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw, int obs_dim,
+                                float *__restrict__ obs) {
   const int lane = threadIdx.x & 63;
   float *o = obs + (size_t)i * obs_dim;
   float *row = B.step_rows[B.flag_parity] ? B.step_rows[B.flag_parity] + (size_t)i * (obs_dim + 3) : nullptr;
@@ -705,7 +704,7 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
     o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
     o[13] = B.actions[0 * n + i]; o[14] = B.actions[1 * n + i]; o[15] = B.actions[2 * n + i]; o[16] = B.actions[3 * n + i];
     if (row) {
-      for (int c = 0; c < 17 && c < obs_dim; ++c) row[c] = o[c];  // this lane's own stores
+      for (int c = 0; c < 17 && c < obs_dim; ++c) row_store(row + c, o[c]);  // this lane's own stores
       write_step_row_tail(B, i, row, obs_dim);
     }
   }
@@ -719,10 +718,18 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
         for (int x = cx * cw; x < min((cx + 1) * cw, W); ++x) m = fminf(m, img[(size_t)y * W + x]);
       if (17 + cell < obs_dim) {
         o[17 + cell] = m;
-        if (row) row[17 + cell] = m;
+        if (row) row_store(row + 17 + cell, m);
       }
     }
   }
+}
+__global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
+                                                         const float *__restrict__ u_vec, const float *__restrict__ u_euler,
+                                                         const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
+                                                         int obs_dim, float *__restrict__ obs) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per env
+  if (i < n) obs_navigation_env(B, n, i, target, u_vec, u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs);
+  step_rows_signal(B);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -815,16 +822,18 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
                                                       const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
-  if (i >= n) return;
-  if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
-    if (WITH_OBS) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
-    return;
+  if (i < n) {
+    if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
+      if (WITH_OBS) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+    } else {
+      EnvState s = reset_env<M>(P, B, n, R, i);
+      // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
+      Derived d = update_states(s);
+      store_derived(B.derived, n, i, d);
+      if (WITH_OBS) write_obs_position(B, n, i, target, obs, s, d);
+    }
   }
-  EnvState s = reset_env<M>(P, B, n, R, i);
-  // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
-  Derived d = update_states(s);
-  store_derived(B.derived, n, i, d);
-  if (WITH_OBS) write_obs_position(B, n, i, target, obs, s, d);
+  if (WITH_OBS) step_rows_signal(B);
 }
 
 // AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295)

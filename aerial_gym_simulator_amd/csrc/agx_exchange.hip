@@ -1,0 +1,341 @@
+// The per-step observation exchange of the sharded simulator: ONE RCCL all-gather
+// per env step of the [N_local, obs_dim + 3] rows the observation kernel wrote, issued from a
+// worker thread of this library so that the stepping thread pays one hipEventRecord + one
+// hipStreamWaitEvent per step instead of a collective enqueue (14 us through torch's process
+// group, 27 us with its work-handle bookkeeping -- more than the 18 us env step itself).
+//
+//   stepping thread                      worker thread                     GPU
+//   ---------------                      -------------                     ---
+//   obs kernel(step t) -> rows[p],                                         step stream
+//     last wave: signal[p] = t + 1
+//   agx_exchange_step(p):
+//     push job (no HIP call)          -> k_wait_signal(signal[p] >= t+1)   comm stream
+//                                        ncclAllGather(rows[p] -> all[p])  comm stream (xGMI)
+//     step stream waits done[1-p]        record done[p]
+//   obs kernel(step t+1) -> rows[1-p]    ...                               overlaps the gather of t
+//
+// Why a flag in device memory and not an event for the producer side: a cross-queue
+// hipStreamWaitEvent makes the HIP runtime lock and flush the OTHER queue -- measured on one MI355X
+// (profiles/r01_exchange_probe.txt), env step 19.1 us; + worker with events 36-41 us; + worker with the
+// flag 21 us.  Rows produced by anything but the simulator's kernels (StepGather.pack) still use the
+// ready[p] event (signal == NULL).
+//
+// RCCL is bound at run time (dlopen of the librccl torch already loaded, path handed in by the
+// host) so that the simulator library itself links against nothing but the HIP runtime.
+// The reference has no distributed path at all (replicas only): there is no upstream interface
+// this replaces; the host-side mirror is aerial_gym_simulator_amd/sharding.py:StepGather.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "agx_common.h"
+
+namespace {
+
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+// one binding per process (the path of the first call wins; later calls must agree or pass NULL)
+int bind_rccl(const char *path, Rccl **out) {
+  static std::mutex m;
+  static Rccl r;
+  std::lock_guard<std::mutex> lock(m);
+  if (!r.handle) {
+    const char *p = (path && path[0]) ? path : "librccl.so";
+    void *h = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return agx::fail(AGX_E_ARG, "agx_exchange: cannot load RCCL from '%s': %s", p, dlerror());
+#define AGX_BIND(field, sym)                                                                         \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, sym));                                      \
+  if (!r.field) {                                                                                    \
+    dlclose(h);                                                                                      \
+    return agx::fail(AGX_E_ARG, "agx_exchange: '%s' has no symbol %s", p, sym);                      \
+  }
+    AGX_BIND(GetUniqueId, "ncclGetUniqueId")
+    AGX_BIND(CommInitRank, "ncclCommInitRank")
+    AGX_BIND(CommDestroy, "ncclCommDestroy")
+    AGX_BIND(AllGather, "ncclAllGather")
+    AGX_BIND(GetErrorString, "ncclGetErrorString")
+#undef AGX_BIND
+    r.handle = h;
+  }
+  *out = &r;
+  return AGX_OK;
+}
+
+constexpr int kRing = 8;  // jobs in flight between the two threads (2 are ever used: one per parity)
+
+struct Job {
+  const float *send;
+  float *recv;
+  size_t count;
+  int parity;
+  const uint32_t *signal;  // AgxEnvBuffers.step_signal, or NULL: the ready[parity] event orders the gather
+  uint32_t seq;
+};
+
+// 10 s of the 100 MHz wall clock: a producer that never signals (or a communication stream that ended up
+// in the producer's hardware queue) becomes an error instead of a hung GPU
+constexpr uint64_t kSpinLimitTicks = 1000000000ull;
+
+// Communication-stream side of AgxEnvBuffers.step_signal (agx_step_signal.h): one lane waits until the
+// row-writing kernel of step `seq` has published its rows, then the all-gather behind it may read them
+// (acquire here + the cache invalidate at the start of the next kernel).
+__global__ void k_set_signal(uint32_t *flag, uint32_t value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_wait_signal(const uint32_t *flag, uint32_t seq, uint32_t *timed_out, uint64_t limit_ticks) {
+  if (threadIdx.x != 0) return;
+  const uint64_t t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > limit_ticks) {
+      __hip_atomic_store(timed_out, seq ? seq : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+
+}  // namespace
+
+struct AgxExchange {
+  Rccl *rccl = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  bool concurrent = false;  // agx_exchange_probe found the comm stream independent of the producer's queue
+  uint32_t *probe_flag = nullptr;
+  hipStream_t retired[8] = {};
+  int num_retired = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ready[2] = {nullptr, nullptr};  // rows[p] written (recorded on the stepping stream)
+  hipEvent_t done[2] = {nullptr, nullptr};   // gather of parity p finished (recorded on the comm stream)
+  uint32_t *timed_out_host = nullptr;        // pinned, device-visible: set by k_wait_signal when it gives up
+  uint32_t *timed_out_dev = nullptr;
+  // single producer (stepping thread) / single consumer (worker)
+  Job ring[kRing];
+  std::atomic<uint64_t> pushed{0}, issued{0};
+  uint64_t last_job[2] = {0, 0};  // sequence number (1-based) of the latest job of each parity
+  std::atomic<int> failed{0};
+  char error[256] = {0};
+  std::atomic<bool> stop{false}, sleeping{false};
+  std::mutex m;
+  std::condition_variable cv;
+  std::thread worker;
+
+  void fail_worker(const char *what, const char *detail) {
+    snprintf(error, sizeof(error), "%s: %s", what, detail);
+    failed.store(1, std::memory_order_release);
+  }
+
+  void run() {
+    if (hipSetDevice(device) != hipSuccess) fail_worker("hipSetDevice", "worker thread");
+    auto last_work = std::chrono::steady_clock::now();
+    for (;;) {
+      const uint64_t done_n = issued.load(std::memory_order_relaxed);
+      if (pushed.load(std::memory_order_acquire) == done_n) {
+        if (stop.load(std::memory_order_acquire)) return;
+        // stay hot for 2 ms after the last job (a step is tens of microseconds), then sleep
+        if (std::chrono::steady_clock::now() - last_work < std::chrono::milliseconds(2)) {
+          std::this_thread::yield();
+          continue;
+        }
+        std::unique_lock<std::mutex> lock(m);
+        sleeping.store(true, std::memory_order_seq_cst);
+        cv.wait(lock, [&] { return pushed.load(std::memory_order_seq_cst) != done_n || stop.load(std::memory_order_seq_cst); });
+        sleeping.store(false, std::memory_order_seq_cst);
+        continue;
+      }
+      const Job j = ring[done_n % kRing];
+      if (!failed.load(std::memory_order_relaxed)) {
+        hipError_t e;
+        if (j.signal) {  // producer = a simulator kernel: spin on its flag, no cross-queue event
+          hipLaunchKernelGGL(k_wait_signal, dim3(1), dim3(64), 0, comm_stream, j.signal + j.parity, j.seq, timed_out_dev,
+                             kSpinLimitTicks);
+          e = hipGetLastError();
+          if (e != hipSuccess) fail_worker("k_wait_signal", hipGetErrorString(e));
+        } else {
+          e = hipStreamWaitEvent(comm_stream, ready[j.parity], 0);
+          if (e != hipSuccess) fail_worker("hipStreamWaitEvent", hipGetErrorString(e));
+        }
+        ncclResult_t r = rccl->AllGather(j.send, j.recv, j.count, ncclFloat32, comm, comm_stream);
+        if (r != ncclSuccess) fail_worker("ncclAllGather", rccl->GetErrorString(r));
+        e = hipEventRecord(done[j.parity], comm_stream);
+        if (e != hipSuccess) fail_worker("hipEventRecord", hipGetErrorString(e));
+      }
+      issued.store(done_n + 1, std::memory_order_release);
+      last_work = std::chrono::steady_clock::now();
+    }
+  }
+
+  // host-blocks until the worker has ISSUED (not finished) every job up to `seq`: after that
+  // done[parity] refers to that job and stream waits on it are meaningful
+  void wait_issued(uint64_t seq) const {
+    while (issued.load(std::memory_order_acquire) < seq) std::this_thread::yield();
+  }
+};
+
+extern "C" int agx_exchange_unique_id(const char *rccl_path, void *id_out, int id_bytes) {
+  AGX_REQUIRE(id_out && id_bytes == NCCL_UNIQUE_ID_BYTES, "agx_exchange_unique_id: id buffer must be %d bytes", NCCL_UNIQUE_ID_BYTES);
+  Rccl *r;
+  if (int e = bind_rccl(rccl_path, &r)) return e;
+  ncclUniqueId id;
+  ncclResult_t st = r->GetUniqueId(&id);
+  if (st != ncclSuccess) return agx::fail(AGX_E_LAUNCH, "ncclGetUniqueId: %s", r->GetErrorString(st));
+  memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return AGX_OK;
+}
+
+extern "C" int agx_exchange_create(const char *rccl_path, const void *id, int id_bytes, int rank, int world, int device,
+                                   AgxExchange **out) {
+  AGX_REQUIRE(out && id && id_bytes == NCCL_UNIQUE_ID_BYTES, "agx_exchange_create: null argument or wrong id size");
+  AGX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "agx_exchange_create: rank %d of %d", rank, world);
+  *out = nullptr;
+  Rccl *r;
+  if (int e = bind_rccl(rccl_path, &r)) return e;
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipSetDevice(%d): %s", device, hipGetErrorString(he));
+  AgxExchange *x = new AgxExchange();
+  x->rccl = r;
+  x->rank = rank;
+  x->world = world;
+  x->device = device;
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclResult_t st = r->CommInitRank(&x->comm, world, uid, rank);  // collective over the ranks
+  if (st != ncclSuccess) {
+    delete x;
+    return agx::fail(AGX_E_LAUNCH, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString(st));
+  }
+  bool ok = hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&x->timed_out_host, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+  if (ok) {
+    x->timed_out_host[0] = x->timed_out_host[1] = 0;
+    ok = hipHostGetDevicePointer((void **)&x->timed_out_dev, x->timed_out_host, 0) == hipSuccess;
+  }
+  ok = ok && hipMalloc((void **)&x->probe_flag, sizeof(uint32_t)) == hipSuccess &&
+       hipMemset(x->probe_flag, 0, sizeof(uint32_t)) == hipSuccess;
+  for (int p = 0; p < 2 && ok; ++p)
+    ok = hipEventCreateWithFlags(&x->ready[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&x->done[p], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    r->CommDestroy(x->comm);
+    delete x;
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange_create: stream / event creation failed");
+  }
+  x->worker = std::thread([x] { x->run(); });
+  *out = x;
+  return AGX_OK;
+}
+
+static int check_failed(AgxExchange *x) {
+  if (x->failed.load(std::memory_order_acquire)) return agx::fail(AGX_E_LAUNCH, "agx_exchange worker: %s", x->error);
+  if (*(volatile uint32_t *)x->timed_out_host)
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange: the rows of step %u were never signalled (10 s): gathered rows are stale",
+                     *(volatile uint32_t *)x->timed_out_host);
+  return AGX_OK;
+}
+
+// HIP multiplexes streams onto a few hardware queues.  If the communication stream shares the producer's
+// queue, a k_wait_signal waits for a kernel queued behind itself.  Probe: a waiter on the communication
+// stream (5 ms limit) and a setter on the producer's stream; on a time-out retire the stream (kept alive so
+// that the runtime hands out a different queue) and try the next.  Returns 1 = flags usable, 0 = use events.
+extern "C" int agx_exchange_probe(AgxExchange *x, void *producer_stream) {
+  AGX_REQUIRE(x, "agx_exchange_probe: null exchange");
+  x->concurrent = false;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    x->timed_out_host[1] = 0;
+    if (hipMemsetAsync(x->probe_flag, 0, sizeof(uint32_t), (hipStream_t)producer_stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)producer_stream) != hipSuccess)
+      return agx::fail(AGX_E_LAUNCH, "agx_exchange_probe: memset failed");
+    hipLaunchKernelGGL(k_wait_signal, dim3(1), dim3(64), 0, x->comm_stream, x->probe_flag, 1u, x->timed_out_dev + 1, 500000ull);
+    hipLaunchKernelGGL(k_set_signal, dim3(1), dim3(64), 0, (hipStream_t)producer_stream, x->probe_flag, 1u);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(x->comm_stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)producer_stream) != hipSuccess)
+      return agx::fail(AGX_E_LAUNCH, "agx_exchange_probe: launch failed");
+    if (x->timed_out_host[1] == 0) {
+      x->concurrent = true;
+      return 1;
+    }
+    if (x->num_retired == 8) break;
+    x->retired[x->num_retired++] = x->comm_stream;
+    if (hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking) != hipSuccess)
+      return agx::fail(AGX_E_LAUNCH, "agx_exchange_probe: stream creation failed");
+  }
+  return 0;
+}
+
+extern "C" int agx_exchange_post(AgxExchange *x, int parity, const float *send, float *recv, size_t count_per_rank,
+                                 const uint32_t *signal, uint32_t seq, void *producer_stream) {
+  AGX_REQUIRE(x && send && recv && (parity == 0 || parity == 1) && count_per_rank > 0, "agx_exchange_post: bad argument");
+  AGX_REQUIRE(!signal || x->concurrent, "agx_exchange_post: step_signal mode needs a successful agx_exchange_probe first");
+  if (int e = check_failed(x)) return e;
+  const uint64_t n = x->pushed.load(std::memory_order_relaxed);
+  // the ring slot and the two events of this parity are free once the previous job of this parity was issued
+  x->wait_issued(x->last_job[parity]);
+  AGX_REQUIRE(n - x->issued.load(std::memory_order_acquire) < kRing, "agx_exchange_post: more than %d exchanges in flight", kRing);
+  if (!signal) {
+    hipError_t e = hipEventRecord(x->ready[parity], (hipStream_t)producer_stream);
+    if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e));
+  }
+  x->ring[n % kRing] = Job{send, recv, count_per_rank, parity, signal, seq};
+  x->last_job[parity] = n + 1;
+  x->pushed.store(n + 1, std::memory_order_seq_cst);
+  if (x->sleeping.load(std::memory_order_seq_cst)) {
+    std::lock_guard<std::mutex> lock(x->m);
+    x->cv.notify_one();
+  }
+  return AGX_OK;
+}
+
+extern "C" int agx_exchange_wait(AgxExchange *x, int parity, void *consumer_stream) {
+  AGX_REQUIRE(x && (parity == 0 || parity == 1), "agx_exchange_wait: bad argument");
+  if (x->last_job[parity] == 0) return AGX_OK;  // nothing was ever posted for this parity
+  x->wait_issued(x->last_job[parity]);
+  if (int e = check_failed(x)) return e;
+  // (measured and dropped, profiles/r01_exchange_probe.txt: eliding this wait with a host-side hipEventQuery
+  //  when the gather has already finished; pinning the worker next to the stepping thread)
+  hipError_t e = hipStreamWaitEvent((hipStream_t)consumer_stream, x->done[parity], 0);
+  if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+  return AGX_OK;
+}
+
+extern "C" int agx_exchange_step(AgxExchange *x, int parity, const float *send, float *recv, size_t count_per_rank,
+                                 const uint32_t *signal, uint32_t seq, int wait_parity, void *stream) {
+  if (int e = agx_exchange_post(x, parity, send, recv, count_per_rank, signal, seq, stream)) return e;
+  if (wait_parity == 0 || wait_parity == 1) return agx_exchange_wait(x, wait_parity, stream);
+  return AGX_OK;
+}
+
+extern "C" int agx_exchange_destroy(AgxExchange *x) {
+  if (!x) return AGX_OK;
+  x->stop.store(true, std::memory_order_seq_cst);
+  {
+    std::lock_guard<std::mutex> lock(x->m);
+    x->cv.notify_one();
+  }
+  if (x->worker.joinable()) x->worker.join();
+  (void)hipSetDevice(x->device);
+  if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+  if (x->comm) x->rccl->CommDestroy(x->comm);
+  for (int p = 0; p < 2; ++p) {
+    if (x->ready[p]) (void)hipEventDestroy(x->ready[p]);
+    if (x->done[p]) (void)hipEventDestroy(x->done[p]);
+  }
+  if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+  for (int i = 0; i < x->num_retired; ++i) (void)hipStreamDestroy(x->retired[i]);
+  if (x->probe_flag) (void)hipFree(x->probe_flag);
+  if (x->timed_out_host) (void)hipHostFree(x->timed_out_host);
+  delete x;
+  return AGX_OK;
+}

@@ -11,6 +11,7 @@
 #include "agx_common.h"
 #include "agx_device_math.h"
 #include "agx_rng.h"
+#include "agx_step_signal.h"
 
 namespace agx {
 
@@ -147,14 +148,10 @@ __global__ void __launch_bounds__(256) k_reward_lidar_navigation(AgxEnvBuffers B
 }
 
 // one wave per env: lane 0 writes the 17 state entries, all lanes copy the pooled LiDAR cells
-__global__ void __launch_bounds__(256) k_obs_lidar_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
-                                                               const float *__restrict__ target_yaw,
-                                                               const float *__restrict__ u_vec,
-                                                               const float *__restrict__ u_euler,
-                                                               const float *__restrict__ downsampled, int cells,
-                                                               float *__restrict__ obs) {
-  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (i >= n) return;
+AGX_DEV void obs_lidar_navigation_env(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target,
+                                      const float *__restrict__ target_yaw, const float *__restrict__ u_vec,
+                                      const float *__restrict__ u_euler, const float *__restrict__ downsampled, int cells,
+                                      float *__restrict__ obs) {
   const int lane = threadIdx.x & 63;
   const int obs_dim = 17 + cells;
   float *o = obs + (size_t)i * obs_dim;
@@ -192,17 +189,27 @@ __global__ void __launch_bounds__(256) k_obs_lidar_navigation(AgxEnvBuffers B, i
     for (int c = 0; c < 17; ++c) o[c] = s[c];
     if (row) {
 #pragma unroll
-      for (int c = 0; c < 17; ++c) row[c] = s[c];
-      row[obs_dim] = B.step_reward[i];
-      row[obs_dim + 1] = B.crashes[i] ? 1.0f : 0.0f;
-      row[obs_dim + 2] = B.truncations[i] ? 1.0f : 0.0f;
+      for (int c = 0; c < 17; ++c) row_store(row + c, s[c]);
+      row_store(row + obs_dim, B.step_reward[i]);
+      row_store(row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
+      row_store(row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
     }
   }
   for (int c = lane; c < cells; c += 64) {
     float d = downsampled[(size_t)i * cells + c];
     o[17 + c] = d;
-    if (row) row[17 + c] = d;
+    if (row) row_store(row + 17 + c, d);
   }
+}
+__global__ void __launch_bounds__(256) k_obs_lidar_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
+                                                               const float *__restrict__ target_yaw,
+                                                               const float *__restrict__ u_vec,
+                                                               const float *__restrict__ u_euler,
+                                                               const float *__restrict__ downsampled, int cells,
+                                                               float *__restrict__ obs) {
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per env
+  if (i < n) obs_lidar_navigation_env(B, n, i, target, target_yaw, u_vec, u_euler, downsampled, cells, obs);
+  step_rows_signal(B);
 }
 
 }  // namespace agx

@@ -232,14 +232,17 @@ class EnvManager(BaseManager):
         R.kT_min, R.kT_max = rng["kT"]
         self._reset_args = R
 
-    def bind_step_rows(self, rows, reward):
+    def bind_step_rows(self, rows, reward, signal=None):
         """Multi-GPU exchange rows (sharding.StepGather): `rows` [2, N, obs_dim + 3], one per step
-        parity, written by the observation kernels next to the observation itself."""
+        parity, written by the observation kernels next to the observation itself.  `signal` (int32 [4],
+        zeros): the last wave of such a kernel stores signal[parity] = step_counter + 1 once every row
+        is visible device-wide (AgxEnvBuffers.step_signal); the exchange waits on it on the device."""
         self._require_device()
         B = self._buffers
         B.step_rows[0], B.step_rows[1] = _lib.dptr(rows[0]), _lib.dptr(rows[1])
         B.step_reward = _lib.dptr(reward)
-        self._step_rows = (rows, reward)  # keep alive
+        B.step_signal = _lib.dptr(signal) if signal is not None else None
+        self._step_rows = (rows, reward, signal)  # keep alive
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):

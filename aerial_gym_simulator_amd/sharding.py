@@ -9,10 +9,24 @@ latency bound on a fully connected xGMI node -- hence
   * the send rows are written by the observation kernel itself (AgxEnvBuffers.step_rows), so
     the exchange adds no launch to the step;
   * rows and receive buffers are double buffered by step parity and the collective runs
-    asynchronously on RCCL's own stream: the gather of step t overlaps the kernels of step t+1.
+    asynchronously on its own stream: the gather of step t overlaps the kernels of step t+1;
+  * on HIP devices the collective is enqueued by a worker thread of the simulator library on a
+    communicator of its own (csrc/agx_exchange.cpp, `backend="rccl_thread"`): the stepping thread
+    pays one event record + one stream wait per step.  Going through torch's process group
+    (`backend="process_group"`, the only choice on CPU/gloo) costs 27 us of host time per step --
+    more than the 18 us dynamics-only step itself (profiles/r01_exchange_world1.json).
 """
+import ctypes as C
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def rccl_library_path():
+    """The librccl.so this process already uses (torch bundles its own); None = loader default."""
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else None
 
 
 def shard_range(total_envs, rank, world_size):
@@ -43,17 +57,91 @@ class StepGather:
                      as the reference's Sample Factory recipe tolerate the one-step delay.
     """
 
-    def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None):
+    def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None, backend="auto", ready="signal"):
+        """backend: "process_group" (torch.distributed collective), "rccl_thread" (the library's worker
+        thread on its own RCCL communicator; HIP devices only) or "auto" (rccl_thread when the group runs
+        on RCCL and every rank could set it up, else process_group).
+        ready (rccl_thread with `env` only): "signal" = the observation kernel publishes a flag in device
+        memory that the communication stream spins on (no HIP call per step on this thread); "event" = an
+        event recorded after the step (what rows filled by `pack()` always use)."""
         self.group = group
         self.collective = dist.is_initialized()  # a world of one still goes through RCCL (bench debugging aid)
         self.world = dist.get_world_size(group) if self.collective else 1
         self.n, self.obs_dim = num_envs_local, obs_dim
+        self.device = torch.device(device)
         self.rows = torch.zeros(2, num_envs_local, obs_dim + 3, device=device)
         self.gathered = torch.zeros(2, self.world * num_envs_local, obs_dim + 3, device=device) if self.collective else self.rows
         self._work = [None, None]
         self._last = None
+        self._native = None
+        self._env = env
+        self.signal = None
+        if ready not in ("signal", "event"):
+            raise ValueError(f"unknown ready mode {ready!r}")
+        if backend not in ("auto", "process_group", "rccl_thread"):
+            raise ValueError(f"unknown exchange backend {backend!r}")
+        if backend == "rccl_thread" and not (self.collective and self.device.type == "cuda"):
+            raise RuntimeError("backend='rccl_thread' needs an initialised process group and a HIP device")
+        if self.collective and self.device.type == "cuda" and backend != "process_group" and (
+                backend == "rccl_thread" or dist.get_backend(group) == "nccl"):
+            self._native = self._create_native(required=backend == "rccl_thread")
+        self.backend = "rccl_thread" if self._native is not None else ("process_group" if self.collective else "none")
         if env is not None:
-            env.bind_step_rows(self.rows, reward)
+            if self._native is not None and ready == "signal":
+                rc = self._lib.agx_exchange_probe(self._native, torch.cuda.current_stream(self.device).cuda_stream)
+                if rc < 0:
+                    from . import _lib
+
+                    _lib.check(rc, "agx_exchange_probe")
+                if rc == 1:  # else: no communication stream independent of this one -> events
+                    self.signal = torch.zeros(4, dtype=torch.int32, device=device)
+                    self._signal_ptr = self.signal.data_ptr()
+            env.bind_step_rows(self.rows, reward, self.signal)
+
+    def _create_native(self, required):
+        from . import _lib
+
+        lib = _lib.load()
+        path = rccl_library_path()
+        cpath = path.encode() if path else None
+        uid = (C.c_char * 128)()
+        # every rank binds RCCL and draws an id (only rank 0's is used): a rank that cannot must be known
+        # BEFORE ncclCommInitRank, which blocks until all ranks have joined
+        rc = lib.agx_exchange_unique_id(cpath, uid, 128)
+        err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
+        ok = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            if required:
+                raise RuntimeError(f"rccl_thread exchange unavailable on some rank ({err or 'see the other ranks'})")
+            return None
+        idt = torch.tensor(list(uid.raw), dtype=torch.uint8, device=self.device)
+        dist.broadcast(idt, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        torch.cuda.synchronize(self.device)
+        raw = bytes(idt.cpu().tolist())
+        handle = C.c_void_p()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(lib.agx_exchange_create(cpath, raw, 128, dist.get_rank(self.group), self.world, index, C.byref(handle)),
+                   "agx_exchange_create")
+        self._lib = lib
+        self._count = self.n * (self.obs_dim + 3)
+        self._ptr = [(self.rows[p].data_ptr(), self.gathered[p].data_ptr()) for p in (0, 1)]  # tensor indexing costs microseconds
+        return handle
+
+    def close(self):
+        """Drains and frees the library-side communicator (collective-free, but call it on every rank)."""
+        h, self._native = self._native, None
+        if h is not None:
+            self._lib.agx_exchange_destroy(h)  # drains the communication stream
+            if self.signal is not None and self._env is not None:
+                self._env.bind_step_rows(self.rows, self._env._step_rows[1], None)
+                self.signal = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def pack(self, parity, obs, reward, terminated, truncated):
         p, d = self.rows[parity], self.obs_dim
@@ -64,6 +152,8 @@ class StepGather:
         return p
 
     def exchange(self, parity, overlap=False):
+        if self._native is not None:
+            return self._exchange_native(parity, overlap)
         if self.collective:
             self._work[parity] = dist.all_gather_into_tensor(self.gathered[parity], self.rows[parity], group=self.group,
                                                              async_op=True)
@@ -77,7 +167,32 @@ class StepGather:
         self.wait(prev)
         return self.gathered[prev]
 
+    def _exchange_native(self, parity, overlap):
+        from . import _lib
+
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if overlap:
+            prev, self._last = self._last, parity
+            wait_parity = -1 if prev is None else prev
+        else:
+            prev = wait_parity = parity
+        send, recv = self._ptr[parity]
+        if self.signal is not None:  # the kernels of the step just enqueued publish signal[parity] = step_counter
+            rc = self._lib.agx_exchange_step(self._native, parity, send, recv, self._count, self._signal_ptr,
+                                             self._env.step_counter & 0x7FFFFFFF, wait_parity, stream)
+        else:
+            rc = self._lib.agx_exchange_step(self._native, parity, send, recv, self._count, None, 0, wait_parity, stream)
+        if rc:
+            _lib.check(rc, "agx_exchange_step")
+        return None if prev is None else self.gathered[prev]
+
     def wait(self, parity):
+        if self._native is not None:
+            from . import _lib
+
+            _lib.check(self._lib.agx_exchange_wait(self._native, parity, torch.cuda.current_stream(self.device).cuda_stream),
+                       "agx_exchange_wait")
+            return
         w, self._work[parity] = self._work[parity], None
         if w is not None:
             w.wait()

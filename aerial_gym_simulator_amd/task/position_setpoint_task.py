@@ -112,6 +112,7 @@ class PositionSetpointTask(BaseTask):
             self.actions = actions
             env = self.sim_env
             env._new_call()
+            env._buffers.step_counter = env.step_counter & 0x7FFFFFFF  # as EnvManager.step (RNG streams, step_signal)
             self._plan.task.contents.episode_len = self.task_config.episode_len_steps
             rc = self._plan_fn(self._plan, actions.data_ptr(), env._stream())
             if rc != 0:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 4
+#define AGX_ABI_VERSION 5
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -138,6 +138,12 @@ typedef struct AgxEnvBuffers {
      the gather of step t may overlap step t+1.                                                 */
   float *step_rows[2];
   const float *step_reward; /* [N] the task's reward buffer (required when step_rows is set)     */
+  /* optional, with step_rows: uint32 [4] in device memory, zero-initialised by the host.  The LAST
+     wave of a row-writing kernel to finish stores step_signal[flag_parity] = step_counter + 1 (release,
+     agent scope) after every row of that launch is visible device-wide ([2] is the kernel's own arrival
+     counter).  The exchange's communication stream spins on it (agx_exchange_post, signal != NULL)
+     instead of a cross-queue event: no host call per step for the producer side.                   */
+  uint32_t *step_signal;
   float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
                             the body frame = allocator output + drag + disturbance; read by agx_imu_update */
 } AgxEnvBuffers;
@@ -467,6 +473,42 @@ int agx_sensor_postprocess_points(size_t count, float *pixels, const float *z_no
  * (navigation_task.py:351-357): min_pixel[N] = min(10*img, with img<0 -> 10).          */
 int agx_image_min(int num_envs, int pixels_per_env, const float *pixels, float *min_pixel,
                   void *stream);
+
+/* ---- sharded stepping: the per-step observation exchange -----------------------
+ * One RCCL all-gather per env step of the [N_local][obs_dim + 3] fp32 rows the observation kernels
+ * write (AgxEnvBuffers.step_rows), enqueued by a worker thread of this library on its own stream so
+ * that the gather of step t overlaps the kernels of step t+1 and costs the stepping thread one
+ * event record + one stream wait.  The reference has no distributed path (replicas only), so this
+ * replaces nothing upstream; the host mirror is sharding.StepGather.
+ *   rccl_path: the librccl.so to bind at run time (the one torch loaded); NULL = "librccl.so".
+ *   agx_exchange_unique_id: rank 0 only; the 128 id bytes travel to the other ranks out of band
+ *                           (torch.distributed broadcast in the host mirror).
+ *   agx_exchange_create:    collective over all ranks (ncclCommInitRank), `device` = HIP ordinal.
+ *   agx_exchange_post:      rows `send` [count] of this step (written on `stream`) -> `recv`
+ *                           [world * count]; returns at once.  One post per parity in flight.
+ *                           signal = AgxEnvBuffers.step_signal of the env whose kernels write `send`
+ *                           and seq = its step_counter + 1 for this step: the gather waits for
+ *                           signal[parity] >= seq on the device (no HIP call on this thread);
+ *                           signal = NULL: an event recorded on `stream` now orders the gather.
+ *   agx_exchange_probe:     must return 1 before a post with signal != NULL: checks (and arranges) that
+ *                           the communication stream does not share a hardware queue with `stream`,
+ *                           where a device-side wait would block its own producer; 0 = use events.
+ *   agx_exchange_wait:      `stream` waits (no host block beyond the enqueue hand-off) for the
+ *                           latest posted gather of `parity`: after it the stream may read that
+ *                           recv buffer and overwrite that send buffer.
+ *   agx_exchange_step:      post(parity) then wait(wait_parity) in one call (wait_parity < 0: none). */
+typedef struct AgxExchange AgxExchange;
+int agx_exchange_unique_id(const char *rccl_path, void *id_out, int id_bytes);
+int agx_exchange_create(const char *rccl_path, const void *id, int id_bytes, int rank, int world,
+                        int device, AgxExchange **out);
+int agx_exchange_post(AgxExchange *x, int parity, const float *send, float *recv,
+                      size_t count_per_rank, const uint32_t *signal, uint32_t seq, void *stream);
+int agx_exchange_probe(AgxExchange *x, void *stream);
+int agx_exchange_wait(AgxExchange *x, int parity, void *stream);
+int agx_exchange_step(AgxExchange *x, int parity, const float *send, float *recv,
+                      size_t count_per_rank, const uint32_t *signal, uint32_t seq, int wait_parity,
+                      void *stream);
+int agx_exchange_destroy(AgxExchange *x);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,181 @@
+"""The library-side step exchange (csrc/agx_exchange.cpp) on one GPU: a world of one still goes
+through ncclCommInitRank / ncclAllGather, the worker thread, both streams and all four events.
+(World sizes > 1 need one GPU per rank: the host logic of the N > 1 path is covered by the gloo
+tests in test_abi_and_host.py, the RCCL leg by bench.py --gpus N.)"""
+import os
+import socket
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def world_of_one():
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_rccl_thread_exchange_matches_process_group(world_of_one):
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    dev = torch.device("cuda:0")
+    n, d = 1000, 13
+    a = StepGather(n, d, dev, backend="rccl_thread")
+    b = StepGather(n, d, dev, backend="process_group")
+    assert a.backend == "rccl_thread" and b.backend == "process_group"
+    assert StepGather(n, d, dev).backend == "rccl_thread"  # what "auto" picks on RCCL
+    g = torch.Generator(device=dev).manual_seed(3)
+    # synchronous form: this step's rows
+    for step in range(6):
+        p = step & 1
+        rows = torch.rand(n, d + 3, device=dev, generator=g)
+        for x in (a, b):
+            x.rows[p].copy_(rows)
+        ga, gb = a.exchange(p, overlap=False), b.exchange(p, overlap=False)
+        torch.cuda.synchronize()
+        assert torch.equal(ga, rows) and torch.equal(gb, rows)
+    # overlapped form: the previous step's rows come back, nothing on the first call
+    a._last = b._last = None
+    sent = []
+    for step in range(40):
+        p = step & 1
+        rows = torch.rand(n, d + 3, device=dev, generator=g)
+        sent.append(rows)
+        for x in (a, b):
+            x.rows[p].copy_(rows)
+        ga, gb = a.exchange(p, overlap=True), b.exchange(p, overlap=True)
+        if step == 0:
+            assert ga is None and gb is None
+        else:
+            ga, gb = ga.clone(), gb.clone()  # stream-ordered snapshot before the next overwrite
+            torch.cuda.synchronize()
+            assert torch.equal(ga, sent[step - 1]) and torch.equal(gb, sent[step - 1]), step
+        if step == 20:
+            time.sleep(0.05)  # let the worker thread fall asleep: the next post must wake it
+    a.flush()
+    b.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(a.gathered[1], sent[-1]) and torch.equal(b.gathered[1], sent[-1])
+    a.close()
+    a.close()  # idempotent
+
+
+def test_rccl_thread_exchange_orders_against_the_stepping_stream(world_of_one):
+    """2000 back-to-back steps on a side stream: every gathered buffer must hold exactly the rows of its step
+    (the rows are rewritten by the very next-but-one step, so a missing stream dependency shows up as a
+    newer or older counter)."""
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    dev = torch.device("cuda:0")
+    n, d = 8192, 13
+    x = StepGather(n, d, dev, backend="rccl_thread")
+    side = torch.cuda.Stream(device=dev)
+    seen = torch.zeros(2000, device=dev)
+    with torch.cuda.stream(side):
+        for step in range(2000):
+            p = step & 1
+            x.rows[p].fill_(float(step))  # stands in for the observation kernel of this step
+            buf = x.exchange(p, overlap=True)
+            if buf is not None:
+                seen[step - 1] = buf[::97].max() + buf[::89].min()  # both == step - 1
+        x.flush()
+        last = x.gathered[1].clone()
+    side.synchronize()
+    assert torch.equal(seen[:-1].cpu(), 2.0 * torch.arange(1999, dtype=torch.float32))
+    assert float(last.min()) == float(last.max()) == 1999.0
+    x.close()
+
+
+def test_exchange_argument_errors(world_of_one):
+    import ctypes as C
+
+    from aerial_gym_simulator_amd import _lib
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    lib = _lib.load()
+    assert lib.agx_exchange_unique_id(None, None, 128) != 0
+    uid = (C.c_char * 128)()
+    assert lib.agx_exchange_unique_id(b"/nonexistent/librccl.so", uid, 64) != 0
+    h = C.c_void_p()
+    assert lib.agx_exchange_create(None, uid.raw, 128, 3, 2, 0, C.byref(h)) != 0  # rank outside the world
+    assert "rank" in lib.agx_last_error().decode()
+    with pytest.raises(ValueError):
+        StepGather(4, 13, torch.device("cuda:0"), backend="mpi")
+    assert lib.agx_exchange_destroy(None) == 0
+
+
+@pytest.mark.parametrize("which", ["position", "navigation"])
+@pytest.mark.parametrize("ready", ["signal", "event"])
+def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
+    """The rows the observation kernels write travel through the library-side exchange, ordered by the
+    kernels' own step_signal flag (or by an event): every gathered buffer is exactly the step's
+    obs | reward | terminated | truncated, in the synchronous and in the overlapped form, across resets."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    dev = "cuda:0"
+    cfg = position_setpoint_task_config if which == "position" else navigation_task_config
+    old = (cfg.episode_len_steps, cfg.args, getattr(cfg, "controller_name", None))
+    cfg.device, cfg.episode_len_steps, cfg.args = dev, 9, {}
+    if which == "position":
+        cfg.controller_name = "lee_position_control"
+    try:
+        n = 8192 if which == "position" else 96
+        task = task_registry.make_task(which + ("_setpoint_task" if which == "position" else "_task"), seed=5, num_envs=n, headless=True)
+        task.reset()
+        d = task.task_obs["observations"].shape[1]
+        sg = StepGather(n, d, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread", ready=ready)
+        assert ready == "signal" or sg.signal is None  # "signal" may fall back to events (agx_exchange_probe)
+        g = torch.Generator(device=dev).manual_seed(9)
+        acts = [torch.rand(n, 4, device=dev, generator=g) * 2 - 1 for _ in range(4)]
+
+        def snapshot(ret):
+            obs, rew, term, trunc, _ = ret
+            return torch.cat([obs["observations"], rew[:, None], term.float()[:, None], trunc.float()[:, None]], dim=1)
+
+        steps = 60 if which == "position" else 12
+        for step in range(steps):  # synchronous form
+            want = snapshot(task.step(acts[step & 3]))
+            got = sg.exchange(task.sim_env._parity, overlap=False).clone()
+            assert torch.equal(got, want), (which, ready, step)
+        sg.flush()
+        sg._last = None
+        prev, checks, truncs = None, [], 0
+        for step in range(steps):  # overlapped form, no host synchronisation inside the loop
+            ret = task.step(acts[step & 3])
+            cur = snapshot(ret)
+            truncs += int(ret[3].sum()) if step % 5 == 0 else 0
+            buf = sg.exchange(task.sim_env._parity, overlap=True)
+            if prev is not None:
+                checks.append((buf.clone(), prev))
+            prev = cur
+        sg.flush()
+        torch.cuda.synchronize()
+        assert len(checks) == steps - 1
+        for step, (got, want) in enumerate(checks):
+            assert torch.equal(got, want), (which, ready, step)
+        if sg.signal is not None:
+            assert int(sg.signal[2]) == 0  # the arrival counter is back at zero after every launch
+            assert int(sg.signal[:2].max()) == task.sim_env.step_counter
+        sg.close()
+        assert task.sim_env._buffers.step_signal is None
+        task.step(acts[0])  # stepping goes on without the exchange
+        torch.cuda.synchronize()
+    finally:
+        cfg.episode_len_steps, cfg.args = old[0], old[1]
+        if old[2] is not None:
+            cfg.controller_name = old[2]
