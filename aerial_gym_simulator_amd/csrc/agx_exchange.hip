@@ -98,8 +98,12 @@ __global__ void k_set_signal(uint32_t *flag, uint32_t value) {
 __global__ void k_wait_signal(const uint32_t *flag, uint32_t seq, uint32_t *timed_out, uint64_t limit_ticks) {
   if (threadIdx.x != 0) return;
   const uint64_t t0 = wall_clock64();
+  uint32_t polls = 0;
   while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
-    __builtin_amdgcn_s_sleep(16);
+    // a 20 us dynamics step is caught within a fraction of a microsecond; behind a 3 ms ray-cast step the
+    // lane backs off to one poll per ~3 us
+    if (++polls < 128) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(127);
     if (wall_clock64() - t0 > limit_ticks) {
       __hip_atomic_store(timed_out, seq ? seq : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;

@@ -7,9 +7,10 @@
 // kernel.  Instead
 //   * exchange rows are stored with agent-scope atomic stores (row_store: write-through, `sc1`), so an
 //     acknowledged store is already visible device-wide;
-//   * every wave of a row-writing kernel calls step_rows_signal() exactly once, after its last row
-//     store and on every control path (no early return in front of it): it waits for its own stores to
-//     be acknowledged and counts itself in; the last wave to arrive publishes the step number.
+//   * every thread of a row-writing kernel calls step_rows_signal() exactly once, after its last row
+//     store and on every control path (no early return in front of it: it holds a workgroup barrier):
+//     each wave waits for its own stores to be acknowledged, the workgroup counts itself in, and the
+//     last workgroup to arrive publishes the step number.
 // The all-gather behind the flag is a new kernel on the communication stream: its start invalidates
 // the caches it reads through.
 #pragma once
@@ -28,10 +29,11 @@ __device__ __forceinline__ void step_rows_signal(const AgxEnvBuffers &B) {
   if (B.step_signal == nullptr) return;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the row stores above
   __builtin_amdgcn_s_waitcnt(0);                          // hardware: all of this wave's stores acknowledged
-  if ((threadIdx.x & 63) == 0) {
-    const uint32_t waves = gridDim.x * gridDim.y * gridDim.z * ((blockDim.x + 63) >> 6);
+  __syncthreads();                                        // ... and those of the other waves of the workgroup
+  if (threadIdx.x == 0) {
+    const uint32_t groups = gridDim.x * gridDim.y * gridDim.z;
     const uint32_t arrived = __hip_atomic_fetch_add(B.step_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (arrived == waves) {
+    if (arrived == groups) {
       __hip_atomic_store(B.step_signal + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (same stream)
       __hip_atomic_store(B.step_signal + B.flag_parity, (uint32_t)B.step_counter + 1u, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);

@@ -18,16 +18,20 @@ os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
 dev = "cuda:0"
-task = bench.make_task("dynamics", 8192, dev, False)
+WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "dynamics"
+task = bench.make_task(WORKLOAD, 8192, dev, False)
 task.reset()
 g = torch.Generator(device=dev).manual_seed(1)
 acts = [torch.rand(8192, 4, device=dev, generator=g) * 2 - 1 for _ in range(16)]
-gb = StepGather(8192, 13, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread")
+OBS = task.task_obs["observations"].shape[1]
+STEPS = 3000 if WORKLOAD == "dynamics" else 100
+gb = StepGather(8192, OBS, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread")
 lib, h = gb._lib, gb._native
 env = task.sim_env
 
 
-def run(mode, steps=3000):
+def run(mode, steps=None):
+    steps = steps or STEPS
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -51,7 +55,7 @@ ev = torch.cuda.Event()
 for m in ("none", "record", "api", "none"):
     run(m)
 gb.close()
-gbe = StepGather(8192, 13, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread", ready="event")
+gbe = StepGather(8192, OBS, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread", ready="event")
 for m in ("api-event", "none"):
     run(m)
 gbe.close()
