@@ -124,6 +124,30 @@ def test_stepping_without_hip_device_fails_loudly():
         _lib.dptr(torch.zeros(4))
 
 
+def test_exchange_entry_points_reject_bad_arguments_without_a_gpu():
+    """agx_exchange_* argument checks and the run-time RCCL binding fail with a message, not a crash; the
+    process-group backend is the one a CPU job gets."""
+    import ctypes as C
+
+    from aerial_gym_simulator_amd import _lib
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    assert lib.agx_exchange_unique_id(b"/nonexistent/librccl.so", uid, 128) != 0
+    assert "cannot load RCCL" in lib.agx_last_error().decode()
+    assert lib.agx_exchange_unique_id(None, uid, 64) != 0
+    h = C.c_void_p()
+    assert lib.agx_exchange_create(None, uid.raw, 128, 2, 2, 0, C.byref(h)) != 0 and h.value is None
+    assert lib.agx_exchange_post(None, 0, None, None, 0, None, 0, None) != 0
+    assert lib.agx_exchange_probe(None, None) < 0
+    assert lib.agx_exchange_destroy(None) == 0
+    sg = StepGather(4, 13, "cpu")
+    assert sg.backend == "none" and sg.signal is None
+    with pytest.raises(RuntimeError, match="HIP device"):
+        StepGather(4, 13, "cpu", backend="rccl_thread")
+
+
 def test_scene_manager_semantics():
     from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
 
