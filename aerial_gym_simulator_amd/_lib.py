@@ -175,6 +175,7 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
+ABI_VERSION = 5  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -281,8 +282,8 @@ def load():
             raise RuntimeError(f"{path} does not export {name}: stale build? ({e})") from None
         fn.restype = res
         fn.argtypes = args
-    if lib.agx_abi_version() != 5:
-        raise RuntimeError("libaerialgym_hip.so ABI version mismatch")
+    if lib.agx_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libaerialgym_hip.so ABI version {lib.agx_abi_version()} != {ABI_VERSION}: stale build?")
     _lib = lib
     return lib
 

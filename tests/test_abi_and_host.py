@@ -24,12 +24,19 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/aerial_gym_hip.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     L = _lib.load()
-    assert L.agx_abi_version() == 5
+    assert L.agx_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define AGX_ABI_VERSION (\d+)", header).group(1))
     # links only against the HIP runtime / libc: no torch, no python in the C ABI library
     needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
     libs = re.findall(r"Shared library: \[(.*?)\]", needed)
     assert any("amdhip64" in x for x in libs)
     assert not any(("torch" in x) or ("python" in x) or ("c10" in x) or ("rccl" in x) for x in libs), libs  # RCCL is bound at run time
+
+
+def test_graft_entry_build_runs_on_cpu():
+    """The driver's "does it build" check: hipcc cross-compile + oracle + import, no GPU needed."""
+    import __graft_entry__ as entry
+
+    assert os.path.exists(entry.build())
 
 
 def test_struct_layouts_match_header():
