@@ -11,7 +11,7 @@ latency bound on a fully connected xGMI node -- hence
   * rows and receive buffers are double buffered by step parity and the collective runs
     asynchronously on its own stream: the gather of step t overlaps the kernels of step t+1;
   * on HIP devices the collective is enqueued by a worker thread of the simulator library on a
-    communicator of its own (csrc/agx_exchange.cpp, `backend="rccl_thread"`): the stepping thread
+    communicator of its own (csrc/agx_exchange.hip, `backend="rccl_thread"`): the stepping thread
     pays one event record + one stream wait per step.  Going through torch's process group
     (`backend="process_group"`, the only choice on CPU/gloo) costs 27 us of host time per step --
     more than the 18 us dynamics-only step itself (profiles/r01_exchange_world1.json).

@@ -237,7 +237,7 @@ def exchange_diagnostics(task, actions, args, world, gather_buf, dt_with):
 
 def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
     """Second pass of the N > 1 job with the all-gather enqueued by the library's worker thread on its own
-    RCCL communicator (csrc/agx_exchange.cpp) instead of torch's process group: same tasks, same K and W.
+    RCCL communicator (csrc/agx_exchange.hip) instead of torch's process group: same tasks, same K and W.
     The faster of the two becomes `value`; both are reported.  A watchdog prints the line measured so far
     and ends the process if this leg does not finish (a second communicator cannot be recovered in-process)."""
     import threading
@@ -251,8 +251,10 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
                                "plus_depth_value": out.get("plus_depth", {}).get("value"),
                                "plus_depth_ms_per_step": out.get("plus_depth", {}).get("ms_per_step")}
 
+    res = {}
+
     def give_up():
-        report["rccl_thread"] = {"error": f"did not finish within {limit_s:.0f} s"}
+        report["rccl_thread"] = dict(res, error=res.get("error", "") + f" [no agreement of the ranks within {limit_s:.0f} s]")
         if rank == 0:
             print(json.dumps(out), flush=True)
         os._exit(0)
@@ -260,7 +262,6 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
     dog = threading.Timer(limit_s, give_up)
     dog.daemon = True
     dog.start()
-    res = {}
     try:
         torch.cuda.empty_cache()
         task = make_task("dynamics", args.num_envs, device, args.strict_rng, rank)
@@ -288,8 +289,17 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
             gb2.close()
     except Exception as e:  # noqa: BLE001  (reported, the process-group numbers stand)
         res["error"] = f"{type(e).__name__}: {e}"
+    # a rank that failed alone leaves the others inside a collective: the watchdog stays armed until every rank
+    # has reached this barrier, and all ranks agree on whether the numbers of this leg count
+    ok = torch.tensor([0 if "error" in res else 1], device=device, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    all_ok = int(ok.item()) == 1
     dog.cancel()
+    if not all_ok and "error" not in res:
+        res["error"] = "another rank failed"
     report["rccl_thread"] = res
+    if not all_ok:
+        return
     if "value" in res and res["value"] > out["value"]:
         out["value"], out["ms_per_step"] = res["value"], res["ms_per_step"]
         out["config"]["sharding"] = out["config"]["sharding"].replace("enqueued by process_group", "enqueued by rccl_thread (library worker thread)")

@@ -1,4 +1,4 @@
-"""The library-side step exchange (csrc/agx_exchange.cpp) on one GPU: a world of one still goes
+"""The library-side step exchange (csrc/agx_exchange.hip) on one GPU: a world of one still goes
 through ncclCommInitRank / ncclAllGather, the worker thread, both streams and all four events.
 (World sizes > 1 need one GPU per rank: the host logic of the N > 1 path is covered by the gloo
 tests in test_abi_and_host.py, the RCCL leg by bench.py --gpus N.)"""
