@@ -120,6 +120,51 @@ def test_sync_free_mode_runs_and_resets():
         cfg.episode_len_steps = 500
 
 
+def test_step_is_graph_capture_safe():
+    """Sync-free task.step() issues no host synchronisation and no allocation: two steps (one per reset-flag
+    parity) captured into a hipGraph and replayed give the same trajectory as eager stepping, resets included."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg.device, cfg.controller_name, cfg.episode_len_steps, cfg.args = DEV, "lee_position_control", 13, {}
+    try:
+        n = 2048
+        ta = task_registry.make_task("position_setpoint_task", seed=8, num_envs=n, headless=True)
+        tb = task_registry.make_task("position_setpoint_task", seed=8, num_envs=n, headless=True)
+        ta.reset()
+        tb.reset()
+        act = torch.rand(n, 4, device=DEV) * 2 - 1
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture wants it
+            for _ in range(2):
+                ta.step(act)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):
+            tb.step(act)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(2):
+                ta.step(act)
+        for _ in range(2):
+            tb.step(act)  # the capture itself does not execute
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ta.obs_dict["robot_state_tensor"], tb.obs_dict["robot_state_tensor"])
+        for _ in range(20):  # 40 more steps: past the 13-step episode limit several times
+            graph.replay()
+            for _ in range(2):
+                tb.step(act)
+        torch.cuda.synchronize()
+        assert torch.equal(ta.obs_dict["robot_state_tensor"], tb.obs_dict["robot_state_tensor"])
+        assert torch.equal(ta.task_obs["observations"], tb.task_obs["observations"])
+        assert torch.equal(ta.rewards, tb.rewards) and torch.equal(ta.truncations, tb.truncations)
+        assert int(tb.sim_env.sim_steps.max()) <= 14
+    finally:
+        cfg.episode_len_steps = 500
+
+
 def test_config4_octarotor_lidar_task_runs():
     """BASELINE config 4 at small N: base_octarotor + octarotor_velocity_control + 32x512 LiDAR
     (range + segmentation), 10 sub-steps, disturbances on, sync-free."""
