@@ -18,7 +18,9 @@
 #define AGX_DYN_CONTRACT 1
 #endif
 #ifndef AGX_DYN_WAVES
-#define AGX_DYN_WAVES 2
+// waves per SIMD the env-step kernel is compiled for.  With the scalar-base SoA addressing (soa_at) it needs 160
+// VGPRs and fits 3; a limit of 4 (128 VGPRs) spills.  Measured (profiles/r01_soa_addressing.txt).
+#define AGX_DYN_WAVES 3
 #endif
 #if AGX_DYN_CONTRACT
 #pragma clang fp contract(fast)
@@ -26,6 +28,8 @@
 #include "agx_device_math.h"
 #include "agx_rng.h"
 #include "agx_step_signal.h"
+
+#include <type_traits>
 
 namespace agx {
 
@@ -46,34 +50,45 @@ struct Wrench {
   V3 f, t;
 };
 
+
+// SoA element (component c of env i): uniform column base (scalar unit) + one 32-bit byte offset per lane,
+// i.e. the `global_load v, v_off, s[base]` addressing form instead of a 64-bit VGPR address per access.
+template <class T>
+AGX_DEV T &soa_at(T *base, int c, int n, int i) {
+  T *col = base + (ptrdiff_t)c * (ptrdiff_t)n;
+  return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(col)) +
+                                (size_t)((unsigned)i * (unsigned)sizeof(T)));
+}
+#define AGX_AT(p, c) agx::soa_at((p), (c), n, i)
+
 AGX_DEV EnvState load_state(const float *__restrict__ s, int n, int i) {
   EnvState e;
-  e.p = V3{s[0 * n + i], s[1 * n + i], s[2 * n + i]};
-  e.q = Q4{s[3 * n + i], s[4 * n + i], s[5 * n + i], s[6 * n + i]};
-  e.v = V3{s[7 * n + i], s[8 * n + i], s[9 * n + i]};
-  e.w = V3{s[10 * n + i], s[11 * n + i], s[12 * n + i]};
+  e.p = V3{AGX_AT(s, 0), AGX_AT(s, 1), AGX_AT(s, 2)};
+  e.q = Q4{AGX_AT(s, 3), AGX_AT(s, 4), AGX_AT(s, 5), AGX_AT(s, 6)};
+  e.v = V3{AGX_AT(s, 7), AGX_AT(s, 8), AGX_AT(s, 9)};
+  e.w = V3{AGX_AT(s, 10), AGX_AT(s, 11), AGX_AT(s, 12)};
   return e;
 }
 AGX_DEV void store_state(float *__restrict__ s, int n, int i, const EnvState &e) {
-  s[0 * n + i] = e.p.x; s[1 * n + i] = e.p.y; s[2 * n + i] = e.p.z;
-  s[3 * n + i] = e.q.x; s[4 * n + i] = e.q.y; s[5 * n + i] = e.q.z; s[6 * n + i] = e.q.w;
-  s[7 * n + i] = e.v.x; s[8 * n + i] = e.v.y; s[9 * n + i] = e.v.z;
-  s[10 * n + i] = e.w.x; s[11 * n + i] = e.w.y; s[12 * n + i] = e.w.z;
+  AGX_AT(s, 0) = e.p.x; AGX_AT(s, 1) = e.p.y; AGX_AT(s, 2) = e.p.z;
+  AGX_AT(s, 3) = e.q.x; AGX_AT(s, 4) = e.q.y; AGX_AT(s, 5) = e.q.z; AGX_AT(s, 6) = e.q.w;
+  AGX_AT(s, 7) = e.v.x; AGX_AT(s, 8) = e.v.y; AGX_AT(s, 9) = e.v.z;
+  AGX_AT(s, 10) = e.w.x; AGX_AT(s, 11) = e.w.y; AGX_AT(s, 12) = e.w.z;
 }
 AGX_DEV void store_derived(float *__restrict__ d, int n, int i, const Derived &x) {
-  d[0 * n + i] = x.euler.x; d[1 * n + i] = x.euler.y; d[2 * n + i] = x.euler.z;
-  d[3 * n + i] = x.qveh.x; d[4 * n + i] = x.qveh.y; d[5 * n + i] = x.qveh.z; d[6 * n + i] = x.qveh.w;
-  d[7 * n + i] = x.vveh.x; d[8 * n + i] = x.vveh.y; d[9 * n + i] = x.vveh.z;
-  d[10 * n + i] = x.vbody.x; d[11 * n + i] = x.vbody.y; d[12 * n + i] = x.vbody.z;
-  d[13 * n + i] = x.wbody.x; d[14 * n + i] = x.wbody.y; d[15 * n + i] = x.wbody.z;
+  AGX_AT(d, 0) = x.euler.x; AGX_AT(d, 1) = x.euler.y; AGX_AT(d, 2) = x.euler.z;
+  AGX_AT(d, 3) = x.qveh.x; AGX_AT(d, 4) = x.qveh.y; AGX_AT(d, 5) = x.qveh.z; AGX_AT(d, 6) = x.qveh.w;
+  AGX_AT(d, 7) = x.vveh.x; AGX_AT(d, 8) = x.vveh.y; AGX_AT(d, 9) = x.vveh.z;
+  AGX_AT(d, 10) = x.vbody.x; AGX_AT(d, 11) = x.vbody.y; AGX_AT(d, 12) = x.vbody.z;
+  AGX_AT(d, 13) = x.wbody.x; AGX_AT(d, 14) = x.wbody.y; AGX_AT(d, 15) = x.wbody.z;
 }
 AGX_DEV Derived load_derived(const float *__restrict__ d, int n, int i) {
   Derived x;
-  x.euler = V3{d[0 * n + i], d[1 * n + i], d[2 * n + i]};
-  x.qveh = Q4{d[3 * n + i], d[4 * n + i], d[5 * n + i], d[6 * n + i]};
-  x.vveh = V3{d[7 * n + i], d[8 * n + i], d[9 * n + i]};
-  x.vbody = V3{d[10 * n + i], d[11 * n + i], d[12 * n + i]};
-  x.wbody = V3{d[13 * n + i], d[14 * n + i], d[15 * n + i]};
+  x.euler = V3{AGX_AT(d, 0), AGX_AT(d, 1), AGX_AT(d, 2)};
+  x.qveh = Q4{AGX_AT(d, 3), AGX_AT(d, 4), AGX_AT(d, 5), AGX_AT(d, 6)};
+  x.vveh = V3{AGX_AT(d, 7), AGX_AT(d, 8), AGX_AT(d, 9)};
+  x.vbody = V3{AGX_AT(d, 10), AGX_AT(d, 11), AGX_AT(d, 12)};
+  x.wbody = V3{AGX_AT(d, 13), AGX_AT(d, 14), AGX_AT(d, 15)};
   return x;
 }
 AGX_DEV Gains uniform_gains(const AgxRobotParams &P) {
@@ -86,10 +101,10 @@ AGX_DEV Gains uniform_gains(const AgxRobotParams &P) {
 }
 AGX_DEV Gains load_gains(const float *__restrict__ g, int n, int i) {
   Gains k;
-  k.kp = V3{g[0 * n + i], g[1 * n + i], g[2 * n + i]};
-  k.kv = V3{g[3 * n + i], g[4 * n + i], g[5 * n + i]};
-  k.kr = V3{g[6 * n + i], g[7 * n + i], g[8 * n + i]};
-  k.kw = V3{g[9 * n + i], g[10 * n + i], g[11 * n + i]};
+  k.kp = V3{AGX_AT(g, 0), AGX_AT(g, 1), AGX_AT(g, 2)};
+  k.kv = V3{AGX_AT(g, 3), AGX_AT(g, 4), AGX_AT(g, 5)};
+  k.kr = V3{AGX_AT(g, 6), AGX_AT(g, 7), AGX_AT(g, 8)};
+  k.kw = V3{AGX_AT(g, 9), AGX_AT(g, 10), AGX_AT(g, 11)};
   return k;
 }
 
@@ -423,10 +438,10 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
     float u[M], kT[M], tinc[M], tdec[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      u[j] = B.motor_thrust[j * n + i];
-      kT[j] = P.use_rps ? B.motor_kT[j * n + i] : 1.0f;
-      tinc[j] = B.motor_tau_inc ? B.motor_tau_inc[j * n + i] : P.tau_inc_uniform;
-      tdec[j] = B.motor_tau_dec ? B.motor_tau_dec[j * n + i] : P.tau_dec_uniform;
+      u[j] = AGX_AT(B.motor_thrust, j);
+      kT[j] = P.use_rps ? AGX_AT(B.motor_kT, j) : 1.0f;
+      tinc[j] = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, j) : P.tau_inc_uniform;
+      tdec[j] = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, j) : P.tau_dec_uniform;
     }
     Gains g{};
     if (CTRL != AGX_CTRL_NONE) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
@@ -434,7 +449,7 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
       a_in[c] = (c < A) ? actions_in[(size_t)i * A + c] : 0.0f;
-      a_old[c] = (c < A) ? B.actions[c * n + i] : 0.0f;
+      a_old[c] = (c < A) ? AGX_AT(B.actions, c) : 0.0f;
     }
     Derived d{};
     if (k == 0 && T.kind != AGX_TASK_NONE) d = load_derived(B.derived, n, i);
@@ -497,7 +512,7 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
         }
       }
       if (B.body_force && sub == k - 1) {  // what the IMU's force sensor sees (agx_imu_update)
-        B.body_force[0 * n + i] = bw[0]; B.body_force[1 * n + i] = bw[1]; B.body_force[2 * n + i] = bw[2];
+        AGX_AT(B.body_force, 0) = bw[0]; AGX_AT(B.body_force, 1) = bw[1]; AGX_AT(B.body_force, 2) = bw[2];
       }
       integrate(P, s, V3{bw[0], bw[1], bw[2]}, V3{bw[3], bw[4], bw[5]});
       if (B.boxes) {
@@ -516,10 +531,10 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
     if (k > 0) {
       store_derived(B.derived, n, i, d);
 #pragma unroll
-      for (int j = 0; j < M; ++j) B.motor_thrust[j * n + i] = u[j];
+      for (int j = 0; j < M; ++j) AGX_AT(B.motor_thrust, j) = u[j];
       if (B.wrench_cmd) {
-        B.wrench_cmd[0 * n + i] = wc.f.x; B.wrench_cmd[1 * n + i] = wc.f.y; B.wrench_cmd[2 * n + i] = wc.f.z;
-        B.wrench_cmd[3 * n + i] = wc.t.x; B.wrench_cmd[4 * n + i] = wc.t.y; B.wrench_cmd[5 * n + i] = wc.t.z;
+        AGX_AT(B.wrench_cmd, 0) = wc.f.x; AGX_AT(B.wrench_cmd, 1) = wc.f.y; AGX_AT(B.wrench_cmd, 2) = wc.f.z;
+        AGX_AT(B.wrench_cmd, 3) = wc.t.x; AGX_AT(B.wrench_cmd, 4) = wc.t.y; AGX_AT(B.wrench_cmd, 5) = wc.t.z;
       }
     }
     // RobotManagerIGE.pre_physics_step runs every sub-step: prev <- cur, cur <- action
@@ -527,25 +542,25 @@ __global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams 
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
       a_cur[c] = (k > 0) ? a_in[c] : a_old[c];
-      a_prev[c] = (k >= 2) ? a_in[c] : ((k == 1) ? a_old[c] : ((c < A) ? B.prev_actions[c * n + i] : 0.0f));
+      a_prev[c] = (k >= 2) ? a_in[c] : ((k == 1) ? a_old[c] : ((c < A) ? AGX_AT(B.prev_actions, c) : 0.0f));
       if (c < A && k > 0) {
-        B.prev_actions[c * n + i] = a_prev[c];
-        B.actions[c * n + i] = a_cur[c];
+        AGX_AT(B.prev_actions, c) = a_prev[c];
+        AGX_AT(B.actions, c) = a_cur[c];
       }
     }
     const int steps = B.sim_steps[i] + 1;
     B.sim_steps[i] = steps;
     bool trunc = false;
     if (T.kind != AGX_TASK_NONE) {
-      V3 tgt = V3{T.target[0 * n + i], T.target[1 * n + i], T.target[2 * n + i]};
+      V3 tgt = V3{AGX_AT(T.target, 0), AGX_AT(T.target, 1), AGX_AT(T.target, 2)};
       float rew;
       if (T.kind == AGX_TASK_POSITION) {
         rew = reward_position(s, d.qveh, d.wbody, tgt, crashed);
       } else {
-        V3 ppe = V3{T.pos_err[0 * n + i], T.pos_err[1 * n + i], T.pos_err[2 * n + i]};
-        T.prev_pos_err[0 * n + i] = ppe.x; T.prev_pos_err[1 * n + i] = ppe.y; T.prev_pos_err[2 * n + i] = ppe.z;
+        V3 ppe = V3{AGX_AT(T.pos_err, 0), AGX_AT(T.pos_err, 1), AGX_AT(T.pos_err, 2)};
+        AGX_AT(T.prev_pos_err, 0) = ppe.x; AGX_AT(T.prev_pos_err, 1) = ppe.y; AGX_AT(T.prev_pos_err, 2) = ppe.z;
         V3 pe = quat_rotate_inverse(d.qveh, tgt - s.p);
-        T.pos_err[0 * n + i] = pe.x; T.pos_err[1 * n + i] = pe.y; T.pos_err[2 * n + i] = pe.z;
+        AGX_AT(T.pos_err, 0) = pe.x; AGX_AT(T.pos_err, 1) = pe.y; AGX_AT(T.pos_err, 2) = pe.z;
         rew = reward_navigation(T.rp, T.curriculum_progress, pe, ppe, a_cur[0], a_cur[2], a_cur[3], a_prev[0], a_prev[2],
                                 a_prev[3], crashed);
       }
@@ -588,8 +603,8 @@ __global__ void __launch_bounds__(256) k_controller_wrench(AgxRobotParams P, Agx
     case AGX_CTRL_FULLY_ACTUATED: wc = run_controller<AGX_CTRL_FULLY_ACTUATED>(P, s, d, a, g); break;
     default: break;
   }
-  B.wrench_cmd[0 * n + i] = wc.f.x; B.wrench_cmd[1 * n + i] = wc.f.y; B.wrench_cmd[2 * n + i] = wc.f.z;
-  B.wrench_cmd[3 * n + i] = wc.t.x; B.wrench_cmd[4 * n + i] = wc.t.y; B.wrench_cmd[5 * n + i] = wc.t.z;
+  AGX_AT(B.wrench_cmd, 0) = wc.f.x; AGX_AT(B.wrench_cmd, 1) = wc.f.y; AGX_AT(B.wrench_cmd, 2) = wc.f.z;
+  AGX_AT(B.wrench_cmd, 3) = wc.t.x; AGX_AT(B.wrench_cmd, 4) = wc.t.y; AGX_AT(B.wrench_cmd, 5) = wc.t.z;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -601,9 +616,9 @@ __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n,
   bool reset = false;
   if (i < n) {
     EnvState s = load_state(B.state, n, i);
-    Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
-    V3 wb = V3{B.derived[13 * n + i], B.derived[14 * n + i], B.derived[15 * n + i]};
-    V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
+    Q4 qveh = Q4{AGX_AT(B.derived, 3), AGX_AT(B.derived, 4), AGX_AT(B.derived, 5), AGX_AT(B.derived, 6)};
+    V3 wb = V3{AGX_AT(B.derived, 13), AGX_AT(B.derived, 14), AGX_AT(B.derived, 15)};
+    V3 tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
     bool crash = B.crashes[i] != 0;
     reward[i] = reward_position(s, qveh, wb, tgt, crash);
     B.crashes[i] = crash ? 1 : 0;
@@ -624,7 +639,7 @@ AGX_DEV void write_step_row_tail(const AgxEnvBuffers &B, int i, float *__restric
 }
 AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target, float *__restrict__ obs,
                                 const EnvState &s, const Derived &d) {
-  float v[13] = {target[0 * n + i] - s.p.x, target[1 * n + i] - s.p.y, target[2 * n + i] - s.p.z, s.q.x, s.q.y, s.q.z, s.q.w,
+  float v[13] = {AGX_AT(target, 0) - s.p.x, AGX_AT(target, 1) - s.p.y, AGX_AT(target, 2) - s.p.z, s.q.x, s.q.y, s.q.z, s.q.w,
                  d.vbody.x, d.vbody.y, d.vbody.z, d.wbody.x, d.wbody.y, d.wbody.z};
   float *o = obs + (size_t)i * 13;
 #pragma unroll
@@ -654,16 +669,16 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool reset = false;
   if (i < n) {
-    V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
-    Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
-    V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
-    V3 ppe = V3{pos_err[0 * n + i], pos_err[1 * n + i], pos_err[2 * n + i]};
-    prev_pos_err[0 * n + i] = ppe.x; prev_pos_err[1 * n + i] = ppe.y; prev_pos_err[2 * n + i] = ppe.z;
+    V3 p = V3{AGX_AT(B.state, 0), AGX_AT(B.state, 1), AGX_AT(B.state, 2)};
+    Q4 qveh = Q4{AGX_AT(B.derived, 3), AGX_AT(B.derived, 4), AGX_AT(B.derived, 5), AGX_AT(B.derived, 6)};
+    V3 tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
+    V3 ppe = V3{AGX_AT(pos_err, 0), AGX_AT(pos_err, 1), AGX_AT(pos_err, 2)};
+    AGX_AT(prev_pos_err, 0) = ppe.x; AGX_AT(prev_pos_err, 1) = ppe.y; AGX_AT(prev_pos_err, 2) = ppe.z;
     V3 pe = quat_rotate_inverse(qveh, tgt - p);
-    pos_err[0 * n + i] = pe.x; pos_err[1 * n + i] = pe.y; pos_err[2 * n + i] = pe.z;
+    AGX_AT(pos_err, 0) = pe.x; AGX_AT(pos_err, 1) = pe.y; AGX_AT(pos_err, 2) = pe.z;
     bool crash = B.crashes[i] != 0;
-    reward[i] = reward_navigation(R.rp, cpf, pe, ppe, B.actions[0 * n + i], B.actions[2 * n + i], B.actions[3 * n + i],
-                                  B.prev_actions[0 * n + i], B.prev_actions[2 * n + i], B.prev_actions[3 * n + i], crash);
+    reward[i] = reward_navigation(R.rp, cpf, pe, ppe, AGX_AT(B.actions, 0), AGX_AT(B.actions, 2), AGX_AT(B.actions, 3),
+                                  AGX_AT(B.prev_actions, 0), AGX_AT(B.prev_actions, 2), AGX_AT(B.prev_actions, 3), crash);
     bool trunc = B.sim_steps[i] > episode_len;
     B.truncations[i] = trunc ? 1 : 0;
     reset = (crash && reset_on_collision) || trunc;
@@ -681,9 +696,9 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
   float *o = obs + (size_t)i * obs_dim;
   float *row = B.step_rows[B.flag_parity] ? B.step_rows[B.flag_parity] + (size_t)i * (obs_dim + 3) : nullptr;
   if (lane == 0) {
-    V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
-    Q4 qveh = Q4{B.derived[3 * n + i], B.derived[4 * n + i], B.derived[5 * n + i], B.derived[6 * n + i]};
-    V3 tgt = V3{target[0 * n + i], target[1 * n + i], target[2 * n + i]};
+    V3 p = V3{AGX_AT(B.state, 0), AGX_AT(B.state, 1), AGX_AT(B.state, 2)};
+    Q4 qveh = Q4{AGX_AT(B.derived, 3), AGX_AT(B.derived, 4), AGX_AT(B.derived, 5), AGX_AT(B.derived, 6)};
+    V3 tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
     V3 v = quat_rotate_inverse(qveh, tgt - p);
     float u6[6];
     if (u_vec) {
@@ -696,13 +711,13 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     V3 pv = V3{v.x + 0.1f * 2.0f * u6[0], v.y + 0.1f * 2.0f * u6[1], v.z + 0.1f * 2.0f * u6[2]};
     float dist = norm(v);
     o[0] = pv.x / dist; o[1] = pv.y / dist; o[2] = pv.z / dist; o[3] = dist;
-    float e0 = ssa(B.derived[0 * n + i]), e1 = ssa(B.derived[1 * n + i]);
+    float e0 = ssa(AGX_AT(B.derived, 0)), e1 = ssa(AGX_AT(B.derived, 1));
     o[4] = e0 + 0.1f * (u6[3] - 0.5f);
     o[5] = e1 + 0.1f * (u6[4] - 0.5f);
     o[6] = 0.0f;
-    o[7] = B.derived[10 * n + i]; o[8] = B.derived[11 * n + i]; o[9] = B.derived[12 * n + i];
-    o[10] = B.derived[13 * n + i]; o[11] = B.derived[14 * n + i]; o[12] = B.derived[15 * n + i];
-    o[13] = B.actions[0 * n + i]; o[14] = B.actions[1 * n + i]; o[15] = B.actions[2 * n + i]; o[16] = B.actions[3 * n + i];
+    o[7] = AGX_AT(B.derived, 10); o[8] = AGX_AT(B.derived, 11); o[9] = AGX_AT(B.derived, 12);
+    o[10] = AGX_AT(B.derived, 13); o[11] = AGX_AT(B.derived, 14); o[12] = AGX_AT(B.derived, 15);
+    o[13] = AGX_AT(B.actions, 0); o[14] = AGX_AT(B.actions, 1); o[15] = AGX_AT(B.actions, 2); o[16] = AGX_AT(B.actions, 3);
     if (row) {
       for (int c = 0; c < 17 && c < obs_dim; ++c) row_store(row + c, o[c]);  // this lane's own stores
       write_step_row_tail(B, i, row, obs_dim);
@@ -766,8 +781,8 @@ AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int 
   sample_bounds(R, i, ep, bmin, bmax);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    B.bounds_min[c * n + i] = bmin[c];
-    B.bounds_max[c * n + i] = bmax[c];
+    AGX_AT(B.bounds_min, c) = bmin[c];
+    AGX_AT(B.bounds_max, c) = bmax[c];
   }
   float r[13], us[13];
   if (R.u_state) {
@@ -792,7 +807,7 @@ AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int 
       rng_fill<12>(R.seed, i, ep, RNG_GAINS, ug);
     }
 #pragma unroll
-    for (int c = 0; c < 12; ++c) B.gains[c * n + i] = (R.gains_max[c] - R.gains_min[c]) * ug[c] + R.gains_min[c];
+    for (int c = 0; c < 12; ++c) AGX_AT(B.gains, c) = (R.gains_max[c] - R.gains_min[c]) * ug[c] + R.gains_min[c];
   }
 #pragma unroll
   for (int j = 0; j < M; ++j) {
@@ -802,12 +817,12 @@ AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int 
     float u0 = R.u_state ? R.u_tau_inc[k] : um.v[0];
     float u1 = R.u_state ? R.u_tau_dec[k] : um.v[1];
     float u2 = R.u_state ? R.u_thrust[k] : um.v[2];
-    if (B.motor_tau_inc) B.motor_tau_inc[j * n + i] = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
-    if (B.motor_tau_dec) B.motor_tau_dec[j * n + i] = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
-    B.motor_thrust[j * n + i] = (P.max_thrust - P.min_thrust) * u2 + P.min_thrust;
+    if (B.motor_tau_inc) AGX_AT(B.motor_tau_inc, j) = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
+    if (B.motor_tau_dec) AGX_AT(B.motor_tau_dec, j) = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
+    AGX_AT(B.motor_thrust, j) = (P.max_thrust - P.min_thrust) * u2 + P.min_thrust;
     if (P.use_rps) {
       float u3 = R.u_state ? R.u_kT[k] : um.v[3];
-      B.motor_kT[j * n + i] = (R.kT_max - R.kT_min) * u3 + R.kT_min;
+      AGX_AT(B.motor_kT, j) = (R.kT_max - R.kT_min) * u3 + R.kT_min;
     }
   }
   B.sim_steps[i] = 0;
