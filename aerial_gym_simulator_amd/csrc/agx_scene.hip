@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_prims_from_assets(int n, int np_, int n
                                                             const uint8_t *__restrict__ mask, float *__restrict__ prim_state) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * np_) return;
-  const int env = idx / np_, p = idx % np_;
+  const int env = idx / np_;
   if (mask && !mask[env]) return;
   const float *as = asset_state + ((size_t)env * na + prim_asset[idx]) * 13;  // per env: the free assets are shuffled
   const float *lp = local_pos + (size_t)idx * 3, *lq = local_quat + (size_t)idx * 4;
