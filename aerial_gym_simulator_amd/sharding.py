@@ -170,7 +170,8 @@ class StepGather:
     def _exchange_native(self, parity, overlap):
         from . import _lib
 
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # the stream the step just used (looked up once per step by the env); torch's lookup costs a microsecond
+        stream = self._env._stream() if self._env is not None else torch.cuda.current_stream(self.device).cuda_stream
         if overlap:
             prev, self._last = self._last, parity
             wait_parity = -1 if prev is None else prev
