@@ -31,6 +31,33 @@
 
 #include <type_traits>
 
+// State path only (controller, motor model, integrator: graded on the 1e-5 per-step tolerance, like the fma
+// contraction above): 1-ulp hardware reciprocal / square root / reciprocal square root instead of the
+// correctly rounded sequences (11 / 9 vector instructions each; the env step is bound by instruction issue).
+// Never used below the `contract(off)` line.
+#ifndef AGX_DYN_FAST_RCP
+#define AGX_DYN_FAST_RCP 1
+#endif
+namespace agx {
+#if AGX_DYN_FAST_RCP
+// one Newton step each: 1 ulp -> about 0.5 ulp (not correctly rounded, not meant to be), 3 / 4 instructions
+AGX_DEV float srcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(r, fmaf(-x, r, 1.0f), r);
+}
+AGX_DEV float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+AGX_DEV float srsq(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  float h = 0.5f * y;
+  return fmaf(h, fmaf(-x * y, y, 1.0f), y);
+}
+#else
+AGX_DEV float srcp(float x) { return 1.0f / x; }
+AGX_DEV float ssqrt(float x) { return sqrtf(x); }
+AGX_DEV float srsq(float x) { return 1.0f / sqrtf(x); }
+#endif
+}  // namespace agx
+
 namespace agx {
 
 struct EnvState {
@@ -147,12 +174,12 @@ AGX_DEV V3 compute_body_torque(const AgxRobotParams &P, Q4 q, V3 wb, Q4 qd, V3 &
 
 // base_lee_controller.py:173-194
 AGX_DEV Q4 desired_orientation_pos_vel(V3 f, float yaw) {
-  V3 b3 = f / norm(f);
+  V3 b3 = f * srsq(dot(f, f));
   float sy, cy;
   sincos_bounded(yaw, sy, cy);
   V3 tmp = V3{cy, sy, 0.0f};
   V3 b2 = cross(b3, tmp);
-  b2 = b2 / norm(b2);
+  b2 = b2 * srsq(dot(b2, b2));
   V3 b1 = cross(b2, b3);
   M33 R{b1.x, b2.x, b3.x, b1.y, b2.y, b3.y, b1.z, b2.z, b3.z};
   return rotmat_to_quat(R);
@@ -262,10 +289,11 @@ AGX_DEV float motor_update(const AgxRobotParams &P, float ref, float cur, float 
   ref = fminf(fmaxf(ref, P.min_thrust), P.max_thrust);
   float err = ref - cur;
   float tc = (sgnf(cur) * sgnf(err) < 0.0f) ? tau_dec : tau_inc;
-  float mix = P.use_discrete_approximation ? 1.0f / (dt + tc) : 1.0f / tc;
+  float mix = srcp(P.use_discrete_approximation ? dt + tc : tc);
   if (P.use_rps) {
-    float cur_rpm = sqrtf(cur / kT);
-    float des_rpm = sqrtf(ref / kT);
+    const float inv_kT = srcp(kT);
+    float cur_rpm = ssqrt(cur * inv_kT);
+    float des_rpm = ssqrt(ref * inv_kT);
     if (P.integration_rk4)
       cur_rpm += rk4_delta(des_rpm, cur_rpm, mix, P.max_rate, dt);
     else
@@ -290,23 +318,24 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
               P.inertia_inv[6] * rhs.x + P.inertia_inv[7] * rhs.y + P.inertia_inv[8] * rhs.z};
   V3 wb_new = V3{wb.x + dt * dwb.x, wb.y + dt * dwb.y, wb.z + dt * dwb.z};
   V3 w_new = quat_rotate(s.q, wb_new);
-  V3 v_new = V3{s.v.x + dt * (Fw.x / P.mass), s.v.y + dt * (Fw.y / P.mass), s.v.z + dt * (Fw.z / P.mass)};
+  const float inv_mass = srcp(P.mass);
+  V3 v_new = V3{s.v.x + dt * (Fw.x * inv_mass), s.v.y + dt * (Fw.y * inv_mass), s.v.z + dt * (Fw.z * inv_mass)};
   v_new = V3{v_new.x + P.gravity[0] * dt, v_new.y + P.gravity[1] * dt, v_new.z + P.gravity[2] * dt};
   float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
   float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
   v_new = v_new * ml;
   w_new = w_new * ma;
   float v2 = dot(v_new, v_new), w2 = dot(w_new, w_new);
-  if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * (P.max_linear_velocity / sqrtf(v2));
-  if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * (P.max_angular_velocity / sqrtf(w2));
+  if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * (P.max_linear_velocity * srsq(v2));
+  if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * (P.max_angular_velocity * srsq(w2));
   s.p = V3{s.p.x + v_new.x * dt, s.p.y + v_new.y * dt, s.p.z + v_new.z * dt};
   float wm2 = dot(w_new, w_new);
   if (wm2 != 0.0f) {
-    float wm = sqrtf(wm2);
+    float wm = ssqrt(wm2);
     float half = dt * wm * 0.5f;
     float sn, cs;
     sincos_bounded(half, sn, cs);  // |half| = dt |w| / 2 <= 0.5 (|w| <= 100 rad/s)
-    float sc = sn / wm;
+    float sc = sn * srcp(wm);
     float x1 = w_new.x * sc, y1 = w_new.y * sc, z1 = w_new.z * sc;
     Q4 q = s.q;
     float rx = x1 * q.w + y1 * q.z - z1 * q.y;
@@ -314,8 +343,8 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
     float rz = z1 * q.w + x1 * q.y - y1 * q.x;
     float rw = -(x1 * q.x) - y1 * q.y - z1 * q.z;
     rx += q.x * cs; ry += q.y * cs; rz += q.z * cs; rw += q.w * cs;
-    float nn = sqrtf(rx * rx + ry * ry + rz * rz + rw * rw);
-    s.q = Q4{rx / nn, ry / nn, rz / nn, rw / nn};
+    float inv_nn = srsq(rx * rx + ry * ry + rz * rz + rw * rw);
+    s.q = Q4{rx * inv_nn, ry * inv_nn, rz * inv_nn, rw * inv_nn};
   }
   s.v = v_new;
   s.w = w_new;
