@@ -483,8 +483,8 @@ def main():
             out["roofline_at_scale"] = {"num_envs": 1 << 21, "bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": ach2 / HBM_PEAK_GBS, "launch_us": kt2 * 1e6,
                                         "env_steps_per_s_kernel_only": (1 << 21) / kt2,
-                                        "note": "vector-ALU issue bound here, not HBM bound: 2.7 k VALU instructions per env step x 4 cycles "
-                                                "x 32 waves per SIMD = 144 us at 2.4 GHz (DESIGN.md 3.1)"}
+                                        "note": "instruction-issue / latency bound here, not HBM bound: 1766 VALU instructions per wave (SQ_INSTS_VALU) "
+                                                "x 4 cycles x 32 waves per SIMD = 94 us of vector issue at 2.4 GHz (DESIGN.md 3.1)"}
             del big
         except Exception as e:  # noqa: BLE001
             out["roofline_at_scale"] = {"error": str(e)}
