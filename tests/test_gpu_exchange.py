@@ -168,6 +168,22 @@ def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
         assert len(checks) == steps - 1
         for step, (got, want) in enumerate(checks):
             assert torch.equal(got, want), (which, ready, step)
+        if which == "position":
+            # long run without any host synchronisation: a row read before it was visible device-wide (the flag
+            # protocol of agx_step_signal.h) would show up as a mismatch counted on the device
+            bad = torch.zeros((), device=dev, dtype=torch.int64)
+            prev = None
+            sg.flush()
+            sg._last = None
+            for step in range(2000):
+                cur = snapshot(task.step(acts[step & 3]))
+                buf = sg.exchange(task.sim_env._parity, overlap=True)
+                if prev is not None:
+                    bad += (buf != prev).sum()
+                prev = cur
+            sg.flush()
+            torch.cuda.synchronize()
+            assert int(bad) == 0
         if sg.signal is not None:
             assert int(sg.signal[2]) == 0  # the arrival counter is back at zero after every launch
             assert int(sg.signal[:2].max()) == task.sim_env.step_counter
