@@ -273,6 +273,8 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
         res["backend"] = gb.backend
         if gb.backend != "rccl_thread":
             raise RuntimeError("the library-side exchange could not be set up on every rank")
+        if os.environ.get("AGX_BENCH_INJECT_EXCHANGE_FAILURE") == str(rank):  # exercises the abandon path below
+            raise RuntimeError("injected failure")
         dt = timed_steps(task, actions, args.steps, args.warmup, world, gb, overlap=not args.sync_gather)
         res.update(value=n_gpus * N * args.steps / dt, ms_per_step=1e3 * dt / args.steps)
         gb.close()
@@ -299,13 +301,21 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
         res["error"] = "another rank failed"
     report["rccl_thread"] = res
     if not all_ok:
-        return
+        # whatever is left of this leg (a communicator some rank never joined, a device-side wait nobody will
+        # release) must not get a chance to block a destructor before rank 0 has printed: keep it alive and let
+        # main() leave through os._exit right after the line
+        _ABANDONED.append(dict(locals()))
+        return False
     if "value" in res and res["value"] > out["value"]:
         out["value"], out["ms_per_step"] = res["value"], res["ms_per_step"]
         out["config"]["sharding"] = out["config"]["sharding"].replace("enqueued by process_group", "enqueued by rccl_thread (library worker thread)")
     if "plus_depth_value" in res and "plus_depth" in out and res["plus_depth_value"] > out["plus_depth"]["value"]:
         out["plus_depth"]["value"], out["plus_depth"]["ms_per_step"] = res["plus_depth_value"], res["plus_depth_ms_per_step"]
         out["plus_depth"]["exchange"] = "rccl_thread"
+    return True
+
+
+_ABANDONED = []
 
 
 def cpu_baseline_dynamics(num_envs, budget_s=12.0):
@@ -528,6 +538,9 @@ def main():
         rccl_thread_leg(args, world, rank, device, out)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if _ABANDONED:  # every rank took the same decision (all-reduced): no teardown of a half-built exchange
+        sys.stdout.flush()
+        os._exit(0)
     if use_dist:
         import torch.distributed as dist
 
