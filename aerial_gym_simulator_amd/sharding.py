@@ -83,7 +83,7 @@ class StepGather:
         if backend == "rccl_thread" and not (self.collective and self.device.type == "cuda"):
             raise RuntimeError("backend='rccl_thread' needs an initialised process group and a HIP device")
         if self.collective and self.device.type == "cuda" and backend != "process_group" and (
-                backend == "rccl_thread" or dist.get_backend(group) == "nccl"):
+                backend == "rccl_thread" or "nccl" in str(dist.get_backend(group))):
             self._native = self._create_native(required=backend == "rccl_thread")
         self.backend = "rccl_thread" if self._native is not None else ("process_group" if self.collective else "none")
         if env is not None:
