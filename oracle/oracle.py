@@ -186,6 +186,14 @@ def update_states(state):
     return euler, qveh, vveh, vbody, wbody
 
 
+def rotmat_to_quat(m):
+    """pytorch3d.transforms.matrix_to_quaternion as restated in the oracle; m [n,3,3] -> xyzw [n,4]."""
+    m = _f(np.asarray(m).reshape(-1, 9))
+    q = np.zeros((m.shape[0], 4), np.float32)
+    lib().orc_rotmat_to_quat(m.shape[0], _p(m), _p(q))
+    return q
+
+
 def integrate(P, state, body_wrench):
     lib().orc_integrate(C.byref(P), state.shape[0], _p(state), _p(_f(body_wrench)))
 

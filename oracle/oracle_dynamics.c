@@ -191,6 +191,12 @@ static void rotmat_to_quat_xyzw(const float m[9], float q[4]) {
   q[2] = c[3] / den;
 }
 
+/* test access to the restated third-party routine (tests/test_oracle_physics_kat.py pins it against an
+ * independent implementation, scipy.spatial.transform): m [n][9] row-major -> q [n][4] xyzw               */
+void orc_rotmat_to_quat(int n, const float *m, float *q) {
+  for (int i = 0; i < n; ++i) rotmat_to_quat_xyzw(m + 9 * i, q + 4 * i);
+}
+
 /* ------------------------------------------------------------------ */
 /* a1: BaseMultirotor.update_states, base_multirotor.py:287-294         */
 /* ------------------------------------------------------------------ */

@@ -155,3 +155,30 @@ def test_sphere_box_collision_flag(orc):
     assert crashes[0] == 1
     orc.collide_sphere_boxes(r, _state(p=(5, 5, 5)), boxes, crashes)
     assert crashes[0] == 1
+
+
+def test_matrix_to_quaternion_against_an_independent_implementation(orc):
+    """pytorch3d's matrix_to_quaternion (a dependency the reference does not pin or vendor) as restated in the
+    oracle and in oracle/ref_shells.py, against scipy's Rotation.from_matrix: same rotation up to the sign the
+    controller does not care about, on all four branches of the algorithm (largest of w, x, y, z)."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(11)
+    rots = [Rotation.random(2000, random_state=5)]
+    for axis in np.eye(3):  # half turns and near-half turns about each axis: the x / y / z branches
+        ang = np.pi - np.abs(rng.normal(0, 1e-3, 200))
+        rots.append(Rotation.from_rotvec(axis[None] * ang[:, None]))
+    rots.append(Rotation.from_rotvec(rng.normal(0, 1e-4, (200, 3))))  # near identity: the w branch at its edge
+    R = np.concatenate([r.as_matrix() for r in rots]).astype(np.float32)
+    q = orc.rotmat_to_quat(R).astype(np.float64)
+    q_ref = Rotation.from_matrix(R.astype(np.float64)).as_quat()  # xyzw
+    assert np.abs(np.linalg.norm(q, axis=1) - 1.0).max() < 5e-6
+    dots = np.abs((q * q_ref).sum(axis=1))
+    assert dots.min() > 1.0 - 1e-6
+    branches = np.argmax(np.abs(q[:, [3, 0, 1, 2]]), axis=1)
+    assert set(branches.tolist()) == {0, 1, 2, 3}
+    import torch
+    from ref_shells import _matrix_to_quaternion
+
+    q_shell = _matrix_to_quaternion(torch.from_numpy(R).reshape(-1, 3, 3)).numpy()[:, [1, 2, 3, 0]]  # wxyz -> xyzw
+    assert np.abs(q_shell - q).max() < 2e-6  # the shell the goldens were generated through is the same function
