@@ -1,6 +1,7 @@
 """CPU: known-answer tests that pin the ray-cast oracle geometrically (the reference ships no
 vectors for this path: Warp is a third-party dependency), and BVH == brute force."""
 import numpy as np
+import pytest
 from scene_util import random_box_scene, random_robot_states
 
 
@@ -173,3 +174,65 @@ def test_stereo_occlusion_against_analytic_visibility(orc):
     pcb, spcb = orc.raycast_stereo_camera(W, H, kinv, far, base, cx, cy, "pointcloud_world", pos, quat, tris, seg, use_bvh=True)
     assert np.array_equal(pc, pcb) and np.array_equal(spc, spcb)
     assert np.allclose(pc[0, 0][sure_wall_visible][:, 0], 3.0, rtol=1e-5) and np.all(spc[0, 0][sure_wall_hidden] == -2)
+
+
+@pytest.mark.parametrize("walls", [True, False])
+def test_range_and_segmentation_against_moller_trumbore_in_float64(orc, walls):
+    """An independent algorithm for the same question: the oracle restates Warp's watertight Woop test in fp32,
+    this check intersects every ray with every triangle by Moller-Trumbore in float64.  Ranges agree to fp32
+    accuracy, the segmentation id agrees wherever the two nearest surfaces are not within that accuracy of each
+    other, and so does hit / miss away from grazing rays."""
+    sc = random_box_scene(2, 30, seed=9, walls=walls)  # without the room's walls many rays miss everything
+    tris = orc.scene_transform(sc["tri_local"], sc["tri_asset"], sc["asset_state"])
+    st = random_robot_states(2, 3, *sc["bounds"])
+    pos = st[:, None, 0:3].copy()
+    quat = st[:, None, 3:7].copy()
+    rv = orc.lidar_ray_table(24, 64, -180, 180, -60, 60)
+    far = 12.0
+    rng_img, seg = orc.raycast_lidar(rv, far, "range", pos, quat, tris, sc["tri_seg"])
+    tri_seg_all = np.asarray(sc["tri_seg"])
+
+    def rotate(q, v):  # xyzw, float64
+        x, y, z, w = q
+        u = np.array([x, y, z])
+        return v * (2 * w * w - 1) + 2 * w * np.cross(u, v) + 2 * u * (v @ u)[..., None]
+
+    checked = 0
+    for env in range(2):
+        tri_seg = tri_seg_all[env] if tri_seg_all.ndim == 2 else tri_seg_all
+        o = pos[env, 0].astype(np.float64)
+        d = rotate(quat[env, 0].astype(np.float64), rv.reshape(-1, 3).astype(np.float64))  # [R,3] world directions
+        T = tris[env].astype(np.float64).reshape(-1, 3, 3)
+        a, e1, e2 = T[:, 0], T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]
+        p = np.cross(d[:, None, :], e2[None])                      # [R,T,3]
+        det = (p * e1[None]).sum(-1)
+        ok = np.abs(det) > 1e-12
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = o[None, None] - a[None]
+        u = (tv * p).sum(-1) * inv
+        qv = np.cross(tv, e1[None])
+        v = (d[:, None, :] * qv).sum(-1) * inv
+        t = (e2[None] * qv).sum(-1) * inv
+        margin = np.minimum(np.minimum(u, v), 1.0 - u - v)         # barycentric distance to the triangle's border
+        hit = ok & (margin >= 0) & (t > 0) & (t <= far)
+        t_hit = np.where(hit, t, np.inf)
+        best = t_hit.min(axis=1)
+        got_r, got_s = rng_img[env, 0].reshape(-1).astype(np.float64), seg[env, 0].reshape(-1)
+        # rays that clearly hit (not through an edge / grazing, not at the range limit)
+        clear = np.isfinite(best) & (np.where(hit, margin, -1.0).max(axis=1) > 1e-4) & (best < far - 1e-3)
+        assert clear.mean() > (0.3 if walls else 0.02)
+        assert np.abs(got_r[clear] - best[clear]).max() < 2e-5 * far
+        # segmentation id where the runner-up surface of a DIFFERENT asset is not within fp32 noise of the winner
+        first = t_hit.argmin(axis=1)
+        other = np.where(tri_seg[None, :] != tri_seg[first][:, None], t_hit, np.inf).min(axis=1)
+        with np.errstate(invalid="ignore"):
+            unique = clear & (other - best > 1e-4)
+        assert np.array_equal(got_s[unique], tri_seg[first][unique])
+        # clear misses: no triangle within a small margin of the ray
+        near_miss = (ok & (margin >= -1e-4) & (t > -1e-3) & (t <= far + 1e-3)).any(axis=1)
+        miss = ~near_miss
+        # a miss carries the kernels' sentinel (1000, mapped to the far value by post-processing) and id -2
+        assert (got_s[miss] == -2).all() and (got_r[miss] == 1000.0).all()
+        assert walls or miss.mean() > 0.2
+        checked += int(clear.sum()) + int(miss.sum())
+    assert checked > 2000
