@@ -236,3 +236,53 @@ def test_range_and_segmentation_against_moller_trumbore_in_float64(orc, walls):
         assert walls or miss.mean() > 0.2
         checked += int(clear.sum()) + int(miss.sum())
     assert checked > 2000
+
+
+def test_sensor_front_end_matches_the_reference_classes(orc):
+    """tests/golden/sensor_frontend.npz comes from RUNNING the reference's WarpLidar / WarpCam constructors and
+    WarpSensor's post-processing methods (oracle/gen_golden_sensors.py; only the Warp kernels are out of reach):
+    LiDAR ray tables, camera intrinsics, noise -> range limits -> normalisation."""
+    from conftest import load_golden
+
+    g = load_golden("sensor_frontend")
+    n_tables = 0
+    for key in g.files:
+        if key.endswith("_rays"):
+            h, w, hmin, hmax, vmin, vmax = g[key.replace("_rays", "_params")]
+            ours = orc.lidar_ray_table(int(h), int(w), hmin, hmax, vmin, vmax)
+            assert ours.shape == g[key].shape and np.abs(ours - g[key]).max() < 1.5e-7, key  # python float64 -> fp32 store
+            n_tables += 1
+        if key.endswith("_K"):
+            W, H, hfov, cx, cy = g[key.replace("_K", "_params")]
+            kinv, ocx, ocy = orc.camera_kinv(int(W), int(H), float(hfov))
+            assert (ocx, ocy) == (int(cx), int(cy)), key
+            K = g[key]
+            # our intrinsics are the inverse of the reference's pinhole matrix: pixel -> ray and back
+            ki = np.asarray(kinv, np.float64).reshape(-1)
+            Kinv = np.linalg.inv(K)
+            ours = np.array([ki[0], ki[1], ki[2], ki[3]]) if ki.size == 4 else ki
+            ref4 = np.array([Kinv[0, 0], Kinv[0, 2], Kinv[1, 1], Kinv[1, 2]])
+            assert ours.size in (4, 16)
+            got4 = ours if ours.size == 4 else np.array([ours[0], ours[2], ours[5], ours[6]])
+            assert np.abs(got4 - ref4).max() < 1e-6 * (1 + np.abs(ref4).max()), key
+    assert n_tables == 3
+    for tag in ("depth_plain", "depth_unnormalised", "depth_noise"):
+        cfg = g["pp_%s_cfg" % tag]
+        px = g["pp_%s_in" % tag].copy()
+        noise = cfg[7] > 0
+        out = orc.sensor_postprocess(px, cfg[0], cfg[1], cfg[2], cfg[3], bool(cfg[4]),
+                                     z_normal=g["pp_%s_z" % tag] if noise else None, u_dropout=g["pp_%s_u" % tag] if noise else None,
+                                     std_a=cfg[8], std_b=cfg[9], std_c=cfg[10], mean_offset=cfg[11], dropout_prob=cfg[12] if noise else 0.0)
+        ref = g["pp_%s_out" % tag]
+        assert np.array_equal(out, ref), tag  # bit for bit, noise included (the recorded draws are the reference's)
+    for tag in ("points_sensor_frame", "points_world_frame", "points_noise"):
+        cfg = g["pp_%s_cfg" % tag]
+        px = g["pp_%s_in" % tag].copy()
+        noise = cfg[7] > 0
+        world = cfg[6] > 0
+        out = orc.sensor_postprocess_points(px, cfg[0], cfg[1], cfg[2], cfg[3], not world, bool(cfg[4]) and not world,
+                                            z_normal=g["pp_%s_z" % tag] if noise else None, u_dropout=g["pp_%s_u" % tag] if noise else None,
+                                            std_a=cfg[8], std_b=cfg[9], std_c=cfg[10], mean_offset=cfg[11],
+                                            dropout_prob=cfg[12] if noise else 0.0)
+        ref = g["pp_%s_out" % tag]
+        assert np.array_equal(out, ref), tag  # bit for bit, noise included (the recorded draws are the reference's)

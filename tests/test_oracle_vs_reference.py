@@ -244,12 +244,12 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
         "import gen_golden as gg\n"
         "gg.OUT = %r\n"
         "gg.main()\n"
-        "import gen_golden_imu as gi, gen_golden_lidar_nav as gl\n"
-        "[m.main() for m in (gi, gl) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
+        "import gen_golden_imu as gi, gen_golden_lidar_nav as gl, gen_golden_sensors as gs\n"
+        "[m.main() for m in (gi, gl, gs) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
     )
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
     made = sorted(os.listdir(tmp_path))
-    assert len(made) >= 21
+    assert len(made) >= 22
     for name in made:
         new, old = np.load(tmp_path / name), np.load(os.path.join(ROOT, "tests", "golden", name))
         assert set(new.files) == set(old.files), name
