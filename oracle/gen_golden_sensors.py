@@ -159,12 +159,60 @@ def postprocess_cases():
     return out
 
 
+def pose_cases():
+    """A REAL WarpSensor object (its Warp calls land on the inert stand-in): init_tensors -> reset() (mount
+    randomisation, warp_sensor.py:139-161, draws replayed from the seeded global generator) -> update() (pose composition,
+    :177-187).  Rows a20 (sensor mount) and a22."""
+    install_warp_stub()
+    ws_mod = ref_shells.ref("sensors.warp.warp_sensor")
+    WS = ws_mod.WarpSensor
+    real_lidar = ref_shells.ref("sensors.warp.warp_lidar").WarpLidar
+    ws_mod.WarpLidar = lambda **kw: real_lidar(device="cpu", **kw)  # WarpSensor relies on the "cuda:0" default
+    out = {}
+    g = torch.Generator().manual_seed(123)
+    for tag, mod, cls in (("camera", "camera_config.base_depth_camera_config", "BaseDepthCameraConfig"),
+                          ("lidar", "lidar_config.osdome_64_config", "OSDome_64_Config")):
+        cfg = getattr(ref_shells.ref("config.sensor_config." + mod), cls)
+        n = 48
+        q = torch.randn(n, 4, generator=g)
+        q = q / q.norm(dim=1, keepdim=True)
+        gtd = {"robot_position": (torch.rand(n, 3, generator=g) - 0.5) * 12.0, "robot_orientation": q,
+               "gravity": torch.tensor([0.0, 0.0, -9.81]), "dt": 0.01, "robot_mass": torch.ones(n),
+               "depth_range_pixels": torch.zeros(n, cfg.num_sensors, cfg.height, cfg.width),
+               "segmentation_pixels": torch.zeros(n, cfg.num_sensors, cfg.height, cfg.width, dtype=torch.int32)}
+        # torch_rand_float_tensor is TorchScript (aten::rand_like on the global generator, not patchable from
+        # python): seed, run, then replay the same two draws (translation, rotation: [n, ns, 3] each)
+        sensor = WS(sensor_config=cfg, num_envs=n, mesh_id_list=[0] * n, device="cpu")
+        torch.manual_seed(4242)
+        sensor.init_tensors(gtd)  # ends with reset(): all envs
+        sensor.update()
+        draws = []
+        if cfg.randomize_placement:
+            torch.manual_seed(4242)
+            draws = [torch.rand(n, cfg.num_sensors, 3), torch.rand(n, cfg.num_sensors, 3)]
+        out["pose_%s_robot_position" % tag] = gtd["robot_position"].numpy()
+        out["pose_%s_robot_orientation" % tag] = gtd["robot_orientation"].numpy()
+        out["pose_%s_cfg" % tag] = np.array(list(cfg.min_translation) + list(cfg.max_translation) + list(cfg.min_euler_rotation_deg)
+                                            + list(cfg.max_euler_rotation_deg) + list(cfg.euler_frame_rot_deg)
+                                            + [float(cfg.randomize_placement), cfg.num_sensors], np.float64)
+        for i, u in enumerate(draws):
+            out["pose_%s_u%d" % (tag, i)] = u.numpy()
+        out["pose_%s_local_position" % tag] = sensor.sensor_local_position.numpy().copy()
+        out["pose_%s_local_orientation" % tag] = sensor.sensor_local_orientation.numpy().copy()
+        out["pose_%s_frame_quat" % tag] = sensor.sensor_data_frame_quat[0, 0].numpy().copy()
+        out["pose_%s_sensor_position" % tag] = sensor.sensor_position.numpy().copy()
+        out["pose_%s_sensor_orientation" % tag] = sensor.sensor_orientation.numpy().copy()
+        print("pose", tag, "draws", len(draws), "randomize", cfg.randomize_placement)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     out = {}
     out.update(lidar_tables())
     out.update(camera_matrices())
     out.update(postprocess_cases())
+    out.update(pose_cases())
     np.savez_compressed(os.path.join(OUT, "sensor_frontend.npz"), **out)
     print("sensor_frontend: ok ", len(out), "arrays:", ", ".join(sorted(k for k in out if k.endswith("_params") or k.endswith("_cfg"))))
 

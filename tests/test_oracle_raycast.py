@@ -286,3 +286,38 @@ def test_sensor_front_end_matches_the_reference_classes(orc):
                                             dropout_prob=cfg[12] if noise else 0.0)
         ref = g["pp_%s_out" % tag]
         assert np.array_equal(out, ref), tag  # bit for bit, noise included (the recorded draws are the reference's)
+
+
+@pytest.mark.parametrize("tag", ["camera", "lidar"])
+def test_sensor_mount_and_pose_match_a_real_reference_sensor(orc, tag):
+    """A real WarpSensor of the reference (Warp calls inert) was initialised, reset and updated
+    (oracle/gen_golden_sensors.py): its mount randomisation (rows a20: (max - min) * u + min, quat_from_euler_xyz)
+    and its world pose (row a22: tf_apply and the quat_mul chain with the data-frame rotation) against the
+    formulas the product's kernels and the oracle use."""
+    from conftest import load_golden
+
+    g = load_golden("sensor_frontend")
+    f32 = np.float32
+    cfg = g["pose_%s_cfg" % tag]
+    lo_p, hi_p, lo_e, hi_e, frame_e = (cfg[0:3].astype(f32), cfg[3:6].astype(f32), np.radians(cfg[6:9]).astype(f32),
+                                        np.radians(cfg[9:12]).astype(f32), np.radians(cfg[12:15]).astype(f32))
+    randomize, ns = bool(cfg[15]), int(cfg[16])
+    lpos, lquat = g["pose_%s_local_position" % tag], g["pose_%s_local_orientation" % tag]
+    n = lpos.shape[0]
+    assert lpos.shape == (n, ns, 3)
+    if randomize:
+        u_p, u_e = g["pose_%s_u0" % tag], g["pose_%s_u1" % tag]  # translation draws, then rotation draws
+        assert np.array_equal(lpos, (hi_p - lo_p) * u_p + lo_p)
+        q = orc.quat_from_euler(((hi_e - lo_e) * u_e + lo_e).astype(f32).reshape(-1, 3)).reshape(n, ns, 4)
+        assert np.abs(lquat - q).max() < 2e-7
+    else:
+        assert not any(k.startswith("pose_%s_u" % tag) for k in g.files)
+        assert np.array_equal(lpos, np.zeros_like(lpos))
+        q = orc.quat_from_euler(np.tile(((lo_e + hi_e) / f32(2.0))[None], (n * ns, 1)).astype(f32)).reshape(n, ns, 4)
+        assert np.abs(lquat - q).max() < 2e-7
+    assert np.abs(orc.quat_from_euler(frame_e[None])[0] - g["pose_%s_frame_quat" % tag]).max() < 2e-7
+    state = np.zeros((n, 13), f32)
+    state[:, 0:3], state[:, 3:7] = g["pose_%s_robot_position" % tag], g["pose_%s_robot_orientation" % tag]
+    pos, quat = orc.sensor_pose(state, lpos, lquat, g["pose_%s_frame_quat" % tag])
+    assert np.abs(pos - g["pose_%s_sensor_position" % tag]).max() < 1e-6
+    assert np.abs(quat - g["pose_%s_sensor_orientation" % tag]).max() < 3e-7
