@@ -244,12 +244,12 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
         "import gen_golden as gg\n"
         "gg.OUT = %r\n"
         "gg.main()\n"
-        "import gen_golden_imu as gi, gen_golden_lidar_nav as gl, gen_golden_sensors as gs\n"
-        "[m.main() for m in (gi, gl, gs) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
+        "import gen_golden_imu as gi, gen_golden_lidar_nav as gl, gen_golden_sensors as gs, gen_golden_assets as ga\n"
+        "[m.main() for m in (gi, gl, gs, ga) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
     )
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
     made = sorted(os.listdir(tmp_path))
-    assert len(made) >= 22
+    assert len(made) >= 23
     for name in made:
         new, old = np.load(tmp_path / name), np.load(os.path.join(ROOT, "tests", "golden", name))
         assert set(new.files) == set(old.files), name
@@ -259,3 +259,24 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
                 assert str(a) == str(b), (name, k)
             else:
                 assert a.shape == b.shape and np.array_equal(a, b), (name, k)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_asset_reset_matches_the_reference_asset_manager(orc, tag):
+    """AssetManager.reset_idx of the reference, driven as EnvManager.reset_idx drives it (full reset of the reset
+    envs + half-obstacle resample of a bernoulli subset), vs orc_reset_assets on the replayed draws: which envs
+    change, parked obstacles at -1000 m, positions inside the env bounds, orientations (oracle/gen_golden_assets.py)."""
+    g = load_golden("asset_reset")
+    num_obstacles, num_keep = (int(x) for x in g[f"{tag}_params"])
+    mask, sel = g[f"{tag}_mask"], g[f"{tag}_sel"]
+    u = np.where(sel[:, None, None] > 0, g[f"{tag}_u2"], g[f"{tag}_u1"])  # the draw each env ends up with
+    state = g["state_before"].copy()
+    orc.reset_assets(mask, u, sel, g["min_ratio"], g["max_ratio"], g["bounds_min"], g["bounds_max"], num_obstacles, num_keep, state)
+    ref = g[f"{tag}_state_after"]
+    assert np.array_equal(state[mask == 0], g["state_before"][mask == 0])          # untouched envs
+    assert np.array_equal(ref[mask == 0], g["state_before"][mask == 0])
+    assert np.array_equal(state[..., 0:3] == -1000.0, ref[..., 0:3] == -1000.0)   # the same obstacles are parked
+    assert (ref[mask > 0][..., 0] == -1000.0).any() or num_obstacles >= ref.shape[1]
+    assert np.array_equal(state[..., 0:3], ref[..., 0:3])                         # positions: bit for bit
+    assert np.abs(state[..., 3:7] - ref[..., 3:7]).max() < 2e-7                    # quat_from_euler: 1 ulp (libm vs torch sin/cos)
+    assert np.array_equal(state[..., 7:], ref[..., 7:])                            # velocities are not touched
