@@ -185,3 +185,54 @@ def test_navigation_task_step_by_step_vs_oracle(orc):
         assert n_resets >= 2 * n and n_crashes >= 1, (n_resets, n_crashes)  # the run exercised truncations and collisions
     finally:
         cfg.args, cfg.episode_len_steps = {}, 100
+
+
+def test_bookkeeping_and_target_reset_kernels_vs_the_reference_task_glue():
+    """agx_nav_bookkeeping / agx_nav_target_reset on the 60-step sequence recorded from the reference's REAL
+    NavigationTask (tests/golden/navigation_glue.npz, oracle/gen_golden_nav_glue.py): success / timeout flags,
+    the three curriculum counters, and the resampled targets (bit for bit)."""
+    import ctypes as C
+
+    from conftest import golden_params, load_golden
+    from gpu_harness import DynHarness
+
+    from aerial_gym_simulator_amd import _lib
+
+    g = load_golden("navigation_glue")
+    T, n = g["position"].shape[0], g["position"].shape[1]
+    H = DynHarness(golden_params(load_golden("step_quad_position")), n)
+    lib = H.lib
+    target = torch.from_numpy(np.ascontiguousarray(g["initial_target"].T)).to(DEV)          # SoA [3][N]
+    succ = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    tout = torch.zeros(n, dtype=torch.uint8, device=DEV)
+    counters = torch.zeros(3, dtype=torch.int32, device=DEV)
+    lo = (C.c_float * 3)(*g["target_min_ratio"].tolist())
+    hi = (C.c_float * 3)(*g["target_max_ratio"].tolist())
+    state = np.zeros((n, 13), np.float32)
+    state[:, 6] = 1.0
+    want = np.zeros(3, np.int64)
+    for t in range(T):
+        state[:, 0:3] = g["position"][t]
+        H.set(state=state)
+        H.crashes.copy_(torch.from_numpy(g["crashes"][t].astype(bool)))
+        H.trunc.copy_(torch.from_numpy(g["truncations"][t].astype(bool)))
+        _lib.check(lib.agx_nav_bookkeeping(H.B, n, _lib.dptr(target), 1.0, _lib.dptr(succ), _lib.dptr(tout), _lib.dptr(counters),
+                                           H.stream()), "agx_nav_bookkeeping")
+        d = g["target_before"][t] - g["position"][t]
+        edge = np.abs(np.sqrt((d.astype(np.float64) ** 2).sum(axis=1)) - 1.0) < 1e-6
+        got_s, got_t = succ.cpu().numpy().astype(bool), tout.cpu().numpy().astype(bool)
+        assert np.array_equal(got_s[~edge], g["successes"][t].astype(bool)[~edge]), t
+        assert np.array_equal(got_t[~edge], g["timeouts"][t].astype(bool)[~edge]), t
+        want += [int(got_s.sum()), int(g["crashes"][t].sum()), int(got_t.sum())]
+        assert counters.cpu().tolist() == want.tolist(), t
+        # the simulator resets (new bounds), then the task resamples the targets of those envs
+        mask = g["reset_mask"][t]
+        H.reset_mask.copy_(torch.from_numpy(mask))
+        H.reset_flag[0] = int(mask.any())
+        H.set(bmin=g["bounds_min"][t], bmax=g["bounds_max"][t])
+        u = torch.zeros(n, 4, device=DEV)
+        u[:, 0:3] = torch.from_numpy(g["u_target"][t])
+        _lib.check(lib.agx_nav_target_reset(H.B, n, 4, lo, hi, _lib.dptr(u), _lib.dptr(target), None, 0, H.stream()),
+                   "agx_nav_target_reset")
+        assert np.array_equal(target.cpu().numpy().T, g["target_after"][t]), t
+    assert want[0] > 100 and want[2] > 100

@@ -245,11 +245,12 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
         "gg.OUT = %r\n"
         "gg.main()\n"
         "import gen_golden_imu as gi, gen_golden_lidar_nav as gl, gen_golden_sensors as gs, gen_golden_assets as ga\n"
-        "[m.main() for m in (gi, gl, gs, ga) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
+        "import gen_golden_nav_glue as gn\n"
+        "[m.main() for m in (gi, gl, gs, ga, gn) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
     )
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
     made = sorted(os.listdir(tmp_path))
-    assert len(made) >= 23
+    assert len(made) >= 24
     for name in made:
         new, old = np.load(tmp_path / name), np.load(os.path.join(ROOT, "tests", "golden", name))
         assert set(new.files) == set(old.files), name
@@ -280,3 +281,59 @@ def test_asset_reset_matches_the_reference_asset_manager(orc, tag):
     assert np.array_equal(state[..., 0:3], ref[..., 0:3])                         # positions: bit for bit
     assert np.abs(state[..., 3:7] - ref[..., 3:7]).max() < 2e-7                    # quat_from_euler: 1 ulp (libm vs torch sin/cos)
     assert np.array_equal(state[..., 7:], ref[..., 7:])                            # velocities are not touched
+
+
+def test_navigation_glue_matches_the_reference_task():
+    """tests/golden/navigation_glue.npz: 60 steps of the reference's REAL NavigationTask (constructor, step, reset_idx,
+    curriculum) on a scripted simulator (oracle/gen_golden_nav_glue.py).  Checked here: the flag definitions the
+    bookkeeping kernel implements, the host mirror's curriculum rule, and the target resampling formula."""
+    import types
+
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.task.navigation_task import NavigationTask
+
+    g = load_golden("navigation_glue")
+    T, n = g["position"].shape[0], g["position"].shape[1]
+    cur = g["curriculum"]
+
+    class curriculum:
+        min_level, max_level, check_after_log_instances = int(cur[0]), int(cur[1]), int(cur[2])
+        increase_step, decrease_step = int(cur[3]), int(cur[4])
+        success_rate_for_increase, success_rate_for_decrease = float(cur[5]), float(cur[6])
+
+    me = types.SimpleNamespace(task_config=types.SimpleNamespace(curriculum=curriculum), curriculum_level=int(g["initial_level"]),
+                               obs_dict={}, success_aggregate=0, crashes_aggregate=0, timeouts_aggregate=0,
+                               curriculum_progress_fraction=0.0)
+    me._update_progress = types.MethodType(NavigationTask._update_progress, me)
+    target = g["initial_target"].copy()
+    lo, hi = g["target_min_ratio"], g["target_max_ratio"]
+    levels = set()
+    for t in range(T):
+        assert np.array_equal(g["target_before"][t], target), t
+        trunc = g["sim_steps"][t] > int(g["episode_len_steps"])
+        assert np.array_equal(trunc, g["truncations"][t]), t
+        d = (target - g["position"][t]).astype(np.float32)
+        dist = np.sqrt((d * d).sum(axis=1, dtype=np.float32))
+        crashes = g["crashes"][t].astype(bool)
+        succ = trunc & (dist < 1.0) & ~crashes
+        tout = trunc & ~succ & ~crashes
+        edge = np.abs(dist - 1.0) < 1e-6  # torch.norm may round the last bit differently
+        assert np.array_equal(succ[~edge], g["successes"][t].astype(bool)[~edge]), t
+        assert np.array_equal(tout[~edge], g["timeouts"][t].astype(bool)[~edge]), t
+        # curriculum: the mirror's rule on the reference's own flags
+        me.success_aggregate += int(g["successes"][t].sum())
+        me.crashes_aggregate += int(crashes.sum())
+        me.timeouts_aggregate += int(g["timeouts"][t].sum())
+        NavigationTask._curriculum_decision(me, me.success_aggregate, me.crashes_aggregate, me.timeouts_aggregate)
+        assert me.curriculum_level == int(g["level"][t]), t
+        assert abs(me.curriculum_progress_fraction - float(g["progress"][t])) < 1e-7, t
+        assert [me.success_aggregate, me.crashes_aggregate, me.timeouts_aggregate] == g["aggregates"][t].tolist(), t
+        levels.add(me.curriculum_level)
+        # reset_idx: targets of the envs the simulator reset, inside their NEW bounds
+        m = g["reset_mask"][t] > 0
+        assert np.array_equal(m, trunc | crashes), t
+        ratio = (hi - lo) * g["u_target"][t] + lo
+        new = g["bounds_min"][t] + (g["bounds_max"][t] - g["bounds_min"][t]) * ratio
+        target = np.where(m[:, None], new, target).astype(np.float32)
+        assert np.array_equal(target, g["target_after"][t]), t
+    assert len(levels) >= 4 and g["successes"].sum() > 100 and g["timeouts"].sum() > 100
