@@ -182,3 +182,29 @@ def test_matrix_to_quaternion_against_an_independent_implementation(orc):
 
     q_shell = _matrix_to_quaternion(torch.from_numpy(R).reshape(-1, 3, 3)).numpy()[:, [1, 2, 3, 0]]  # wxyz -> xyzw
     assert np.abs(q_shell - q).max() < 2e-6  # the shell the goldens were generated through is the same function
+
+
+def test_kinematic_obstacles_follow_their_twist(orc):
+    """f4: obstacle twists -> poses over k sub-steps (orc_assets_integrate; Isaac Gym moves these bodies inside PhysX,
+    nothing to pin against).  Constant twist has a closed form: p + k dt v, and a rotation about w by k dt |w|."""
+    from scipy.spatial.transform import Rotation
+
+    rng = np.random.default_rng(3)
+    n, K, dt, k = 4, 5, 0.01, 10
+    st = np.zeros((n, K, 13), np.float32)
+    st[..., 0:3] = rng.normal(0, 3, (n, K, 3))
+    q0 = Rotation.random(n * K, random_state=1)
+    st[..., 3:7] = q0.as_quat().reshape(n, K, 4)
+    tw = rng.normal(0, 1.0, (n, K, 6)).astype(np.float32)
+    tw[0, 0, 3:6] = 0.0  # no spin at all
+    tw[0, 1, :] = 0.0    # a static obstacle
+    before = st.copy()
+    orc.assets_integrate(st, tw, dt, k)
+    # k fp32 additions at |p| up to ~8 m: a few ulps of 8
+    assert np.abs(st[..., 0:3] - (before[..., 0:3].astype(np.float64) + k * dt * tw[..., 0:3])).max() < 6e-6
+    w = tw[..., 3:6].reshape(-1, 3).astype(np.float64)
+    want = (Rotation.from_rotvec(w * k * dt) * q0).as_quat()  # world-frame angular velocity: left multiplication
+    got = st[..., 3:7].reshape(-1, 4).astype(np.float64)
+    assert (np.abs((got * want).sum(axis=1)) > 1 - 1e-6).all()
+    assert np.array_equal(st[..., 7:13], tw)                      # the twist is what the state then reports as velocity
+    assert np.array_equal(st[0, 1, 0:7], before[0, 1, 0:7])       # zero twist: pose untouched, bit for bit
