@@ -37,6 +37,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _run_parallel(cmds, verbose=False):
+    """the translation units are independent: compile them side by side (agx_dynamics.hip alone takes ~50 s)"""
+    if not cmds:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
+        list(ex.map(one, cmds))
+
+
 def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
     """extra_flags / lib_path: build an experimental variant next to the default library."""
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -45,7 +64,7 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "aerial_gym_hip.h"))
-    objs = []
+    objs, cmds = [], []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -53,10 +72,8 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            cmds.append([hipcc] + FLAGS + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj])
+    _run_parallel(cmds, verbose)
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
@@ -67,15 +84,13 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
 
 def _build_variant(extra_flags, lib_path, verbose):
     hipcc = _hipcc()
-    objs = []
+    objs, cmds = [], []
     tag = os.path.splitext(os.path.basename(lib_path))[0]
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, f"{tag}_{os.path.splitext(src)[0]}.o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        cmds.append([hipcc] + FLAGS + list(extra_flags) + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
+    _run_parallel(cmds, verbose)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs, check=True)
     for o in objs:
         os.remove(o)

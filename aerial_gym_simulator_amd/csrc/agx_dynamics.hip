@@ -22,6 +22,11 @@
 // VGPRs and fits 3; a limit of 4 (128 VGPRs) spills.  Measured (profiles/r01_soa_addressing.txt).
 #define AGX_DYN_WAVES 3
 #endif
+#ifndef AGX_DYN_WAVES_LOOP
+// the k-loop variants (k > 1 sub-steps per launch) keep the loop-carried motor / action state next to everything the
+// straight-line kernel needs: at 3 waves per SIMD (168 VGPRs) they spilled 24-136 VGPRs to scratch; 2 waves (256) fit.
+#define AGX_DYN_WAVES_LOOP 2
+#endif
 #if AGX_DYN_CONTRACT
 #pragma clang fp contract(fast)
 #endif
@@ -453,9 +458,12 @@ AGX_DEV float reward_navigation(const float *rp, float cpf, V3 pe, V3 ppe, float
 // ---------------------------------------------------------------------------------------
 // SINGLE: exactly one sub-step (empty_env, BASELINE config 1/2): straight-line code, no loop-
 // carried copies of the loop invariants.
-template <int M, int CTRL, bool SINGLE>
-__global__ void __launch_bounds__(256, AGX_DYN_WAVES) k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n,
-                                                                 const float *__restrict__ actions_in, int k_arg, AgxTaskArgs T) {
+// WIDE: the launch uses one-wave workgroups (n <= 65536 envs: at most one wave per SIMD is resident anyway), so the
+// kernel is compiled for ONE wave per SIMD and may use the whole 512-entry register file: no spill in any variant.
+// !WIDE: 256-thread workgroups at AGX_DYN_WAVES waves per SIMD for batches that fill the chip several times over.
+template <int M, int CTRL, bool SINGLE, bool WIDE>
+__global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_WAVES : AGX_DYN_WAVES_LOOP))
+    k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k_arg, AgxTaskArgs T) {
   const int k = SINGLE ? 1 : k_arg;
   extern __shared__ float traj[];  // [k][3][blockDim] sub-step positions (only with obstacles)
   const int tid = threadIdx.x, bd = blockDim.x;
@@ -966,6 +974,15 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   return AGX_OK;
 }
 
+template <int M, int CTRL, bool WIDE>
+static void launch_env_step(int k, int n, int block, size_t lds, hipStream_t stream, const AgxRobotParams &P, const AgxEnvBuffers &B,
+                            const float *actions_in, const AgxTaskArgs &T) {
+  if (k == 1)
+    hipLaunchKernelGGL((k_env_step<M, CTRL, true, WIDE>), dim3(blocks_for(n, block)), dim3(block), lds, stream, P, B, n, actions_in, k, T);
+  else
+    hipLaunchKernelGGL((k_env_step<M, CTRL, false, WIDE>), dim3(blocks_for(n, block)), dim3(block), lds, stream, P, B, n, actions_in, k, T);
+}
+
 extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *actions_in, int k,
                             const AgxTaskArgs *task, void *stream) {
   if (int e = check_common(P, B, n)) return e;
@@ -987,12 +1004,10 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   const size_t lds = B->boxes ? (size_t)k * 3 * block * sizeof(float) : 0;
   AGX_DISPATCH_M(P->num_motors,
                  AGX_DISPATCH_CTRL(P->controller, {
-                   if (k == 1)
-                     hipLaunchKernelGGL((k_env_step<kM, kC, true>), dim3(blocks_for(n, block)), dim3(block), lds,
-                                        (hipStream_t)stream, *P, *B, n, actions_in, k, T);
+                   if (block == 64)
+                     launch_env_step<kM, kC, true>(k, n, block, lds, (hipStream_t)stream, *P, *B, actions_in, T);
                    else
-                     hipLaunchKernelGGL((k_env_step<kM, kC, false>), dim3(blocks_for(n, block)), dim3(block), lds,
-                                        (hipStream_t)stream, *P, *B, n, actions_in, k, T);
+                     launch_env_step<kM, kC, false>(k, n, block, lds, (hipStream_t)stream, *P, *B, actions_in, T);
                  }));
   return check_launch("agx_env_step");
 }

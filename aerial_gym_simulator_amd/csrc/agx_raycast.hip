@@ -265,8 +265,14 @@ struct LidarArgs {
 enum { RAY_BASIC = 0, RAY_NORMAL = 1, RAY_STEREO = 2 };
 constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
 
+// Register budget: BASIC / NORMAL need 57-61 VGPRs (8 waves per SIMD); STEREO carries two rays' worth of state over the
+// second traversal: 67 VGPRs (7 waves per SIMD).  AGX_RAY_STEREO_WAVES=8 forces it under 64 at the price of 31 more
+// SGPR spills (v_readlane in the traversal loop); the default keeps the compiler's choice.
+#ifndef AGX_RAY_STEREO_WAVES
+#define AGX_RAY_STEREO_WAVES 1
+#endif
 template <bool LIDAR, bool USE_LDS, int VARIANT>
-__global__ void __launch_bounds__(kRayThreads) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
+__global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : 1) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
                                                           const float *__restrict__ sensor_pos,
                                                           const float *__restrict__ sensor_quat,
                                                           const float *__restrict__ tri_world,
@@ -489,12 +495,14 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
                           int32_t *seg, void *stream) {
   const int n = LIDAR ? LA.n : CA.n, ns = LIDAR ? LA.ns : CA.ns;
   size_t lds = ray_lds_bytes(nt);
+#if AGX_RAY_USE_LDS
   static bool attr_set = false;
-  if (AGX_RAY_USE_LDS && !attr_set) {
+  if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_raycast<LIDAR, true, VARIANT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+#endif
   // 256 CUs x 32 waves = 8192 resident waves, and tails want ~2x that in the grid: split an image's 8x8 tiles over several workgroups when the
   // batch alone cannot provide them (256 envs: 199 -> see profiles/r01_small_batch.txt us per frame)
   const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
@@ -503,13 +511,16 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
   const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
   split = split < 1 ? 1 : (split > max_split ? max_split : split);
   dim3 grid(n, ns, AGX_RAY_USE_LDS ? 1 : split);
-  if (AGX_RAY_USE_LDS && lds <= 160 * 1024) {
+#if AGX_RAY_USE_LDS  // experimental builds only: the LDS-staged kernels are not instantiated otherwise
+  if (lds <= 160 * 1024) {
     hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors,
                        pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
-  } else {  // default: traverse from L2 with wave-uniform loads
-    hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, ray_vectors,
-                       pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+    return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
   }
+#endif
+  (void)lds;  // default: traverse from L2 with wave-uniform loads
+  hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, ray_vectors,
+                     pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
   return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
 }
 

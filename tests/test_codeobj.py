@@ -1,0 +1,100 @@
+"""CPU: register / scratch budget of the shipped gfx950 kernels, read from the code-object metadata of
+libaerialgym_hip.so (no GPU needed).  Guards what DESIGN.md section 3 states about occupancy:
+
+* every k_env_step instance launched for n <= 65536 envs (`WIDE`: one-wave workgroups, compiled for one wave
+  per SIMD) has no VGPR spill and not a single scratch instruction;
+* the straight-line quadrotor kernels of BASELINE configs 1/2 (`SINGLE`, 256-thread workgroups, 3 waves per
+  SIMD) have no spill and no scratch either;
+* the ray-cast kernels of configs 3/4 (BASIC / NORMAL, camera and LiDAR) stay at <= 64 VGPRs (8 waves per
+  SIMD), none of them uses scratch or static LDS; the stereo variant is allowed 72 (7 waves per SIMD)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import codeobj
+from aerial_gym_simulator_amd import _build
+
+pytestmark = pytest.mark.skipif(not codeobj.tools_available(), reason="objcopy / ROCm LLVM tools not found")
+
+
+@pytest.fixture(scope="module")
+def meta():
+    assert os.path.exists(_build.LIB_PATH), "build the library first (python -m aerial_gym_simulator_amd._build)"
+    return codeobj.kernel_metadata(_build.LIB_PATH)
+
+
+def _env_step(meta):
+    out = {}
+    for name, rec in meta.items():
+        m = re.match(r"void agx::k_env_step<(\d+), (\d+), (true|false), (true|false)>", name)
+        if m:
+            out[(int(m.group(1)), int(m.group(2)), m.group(3) == "true", m.group(4) == "true")] = rec
+    return out
+
+
+def test_env_step_instances_and_spills(meta):
+    ks = _env_step(meta)
+    assert len(ks) == 3 * 8 * 2 * 2  # motors {4,6,8} x 8 controllers x {single, k-loop} x {wide, 256-thread}
+    report = []
+    for (M, C, single, wide), r in sorted(ks.items()):
+        if wide:
+            assert r["vgpr_spill_count"] == 0, (M, C, single, r)
+            assert r["max_flat_workgroup_size"] == 64
+        elif single and M == 4:
+            assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (M, C, r)
+            assert r["vgpr_count"] <= 168  # 3 waves per SIMD
+        elif not single:
+            assert r["vgpr_count"] <= 256  # 2 waves per SIMD
+            assert r["vgpr_spill_count"] <= 24, (M, C, r)  # M = 8 only; n > 65536 envs with k > 1: not a BASELINE config
+        if r["vgpr_spill_count"] or r["private_segment_fixed_size"]:
+            report.append((M, C, single, wide, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
+    print("k_env_step instances with spills or a private segment (M, ctrl, single, wide, vgpr spills, bytes):", report)
+
+
+def test_wide_env_step_kernels_issue_no_scratch_instruction():
+    """`.private_segment_fixed_size` of some WIDE k-loop instances is non-zero (frame slots the SGPR spiller
+    reserved and then did not need); what matters is that no scratch instruction is ever issued."""
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        obj = os.path.join(_build.LIB_DIR, "agx_dynamics.o")
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+        co = os.path.join(tmp, "dyn.co")
+        subprocess.run([os.path.join(codeobj.LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        f"--targets={codeobj.TARGET}", f"--output={co}"], check=True)
+        asm = subprocess.run([os.path.join(codeobj.LLVM_BIN, "llvm-objdump"), "-d", co], check=True, capture_output=True,
+                             text=True).stdout
+    cur, scratch, seen = None, {}, 0
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            continue
+        if cur and "k_env_step" in cur and ("scratch_" in line or re.search(r"\bbuffer_(load|store).*\boffen\b", line)):
+            scratch[cur] = scratch.get(cur, 0) + 1
+        if cur and "k_env_step" in cur and "s_endpgm" in line:
+            seen += 1
+    assert seen >= 96
+    wide = {k: v for k, v in scratch.items() if re.search(r"k_env_stepILi\dELi\dELb[01]ELb1E", k)}
+    assert not wide, wide
+    single_quad = {k: v for k, v in scratch.items() if re.search(r"k_env_stepILi4ELi\dELb1ELb0E", k)}
+    assert not single_quad, single_quad
+
+
+def test_raycast_kernels_fit_eight_waves_per_simd(meta):
+    rays = {n: r for n, r in meta.items() if n.startswith("void agx::k_raycast<")}
+    assert len(rays) == 5  # camera {basic, normal, stereo}, LiDAR {basic, normal}; the LDS-staged variants are not built
+    for name, r in rays.items():
+        variant = int(re.match(r"void agx::k_raycast<(true|false), false, (\d)>", name).group(2))
+        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["group_segment_fixed_size"] == 0, name
+        assert r["vgpr_count"] <= (72 if variant == 2 else 64), (name, r["vgpr_count"])
+
+
+def test_no_kernel_of_the_hot_path_uses_scratch(meta):
+    """Every other kernel of the library: no scratch at all."""
+    bad = {n: r["private_segment_fixed_size"] for n, r in meta.items()
+           if r["private_segment_fixed_size"] and "k_env_step" not in n}
+    assert not bad, bad
