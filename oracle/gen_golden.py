@@ -358,7 +358,9 @@ def gen_rewards(rng):
 
 # --------------------------------------------------------------------------------------
 def gen_trace(consts, controller_name="lee_position_control", ctrl_key="position", tag="position", n=64, T=260,
-              episode_len=100, seed=1):
+              episode_len=100, seed=1, zero_steps=40, sparse_every=0, hold=1):
+    """sparse_every > 0 (the 1000-step trace of SURVEY 8d config 1): actions (held for `hold` steps) are stored as int16 multiples of 1/256,
+    observations / states only every `sparse_every` steps and the reset draws only for steps with a reset."""
     """BASELINE config 1 assembled from reference pieces + oracle integrator.
 
     Follows EnvManager.step (env_manager.py:399-432) / PositionSetpointTask.step
@@ -398,7 +400,14 @@ def gen_trace(consts, controller_name="lee_position_control", ctrl_key="position
     prev_actions = torch.zeros(n, 4)
     actions = torch.zeros(n, 4)
     for t in range(T):
-        new_action = torch.zeros(n, 4) if t < 40 else (torch.rand(n, 4, generator=act_rng) * 2 - 1)
+        if t < zero_steps:
+            new_action = torch.zeros(n, 4)
+        elif sparse_every:
+            if (t - zero_steps) % hold == 0:  # a new U(-1, 1) set-point every `hold` steps, held in between
+                held = torch.randint(-256, 257, (n, 4), generator=act_rng).to(torch.float32) / 256.0
+            new_action = held.clone()
+        else:
+            new_action = torch.rand(n, 4, generator=act_rng) * 2 - 1
         prev_actions[:] = actions
         actions = new_action
         crashes = torch.zeros(n, dtype=torch.bool)
@@ -437,6 +446,19 @@ def gen_trace(consts, controller_name="lee_position_control", ctrl_key="position
                         (actions, reward, crashes, trunc, obs, reset_mask, *draws)):
             rec[k].append(v.clone())
     out = {k: torch.stack(v).numpy() for k, v in rec.items()}
+    if sparse_every:
+        steps = np.nonzero(out["reset_mask"].any(axis=1))[0].astype(np.int32)
+        for k in ("u_state", "u_tau_inc", "u_tau_dec", "u_thrust", "u_kT"):
+            out[k] = out[k][steps]
+        out["reset_steps"] = steps
+        keep = np.arange(sparse_every - 1, T, sparse_every)
+        out["kept_steps"] = keep.astype(np.int32)
+        for k in ("obs", "state_after_step"):
+            out[k] = out[k][keep]
+        a16 = np.round(out["action"] * 256.0).astype(np.int16)
+        assert np.array_equal(a16.astype(np.float32) / 256.0, out["action"])
+        out["action_q8"] = a16
+        del out["action"]
     out.update(init_state=init_state.numpy(), init_thrust=init_motor[0].numpy(), init_kT=init_motor[1].numpy(),
                init_tau_inc=init_motor[2].numpy(), init_tau_dec=init_motor[3].numpy(),
                init_u_state=init[0].numpy(), init_u_tau_inc=init[1].numpy(), init_u_tau_dec=init[2].numpy(),
@@ -446,9 +468,35 @@ def gen_trace(consts, controller_name="lee_position_control", ctrl_key="position
                min_init_state=np.array(BaseQuadCfg.init_config.min_init_state, dtype=np.float32),
                max_init_state=np.array(BaseQuadCfg.init_config.max_init_state, dtype=np.float32),
                params_json=np.array(json.dumps(pd)))
-    np.savez_compressed(os.path.join(OUT, f"trace_{tag}_64.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"trace_{tag}_64.npz" if not sparse_every else f"trace_{tag}_64_long.npz"), **out)
     print(f"trace_{tag}: ok, mean reward first/last = {out['reward'][0].mean():.4f} / {out['reward'][-1].mean():.4f}, "
           f"resets = {int(out['reset_mask'].sum())}")
+
+
+def register_unregistered_reference_controllers():
+    """Two controller classes of the reference cannot be reached through its registry as shipped:
+
+    * LeeVelocitySteeringAngleController (velocity_steeing_angle_controller.py:15-45) is imported by
+      control/__init__.py:8-10 but never registered: registered here, unmodified, with lee_controller_config.
+    * LeeRatesController.update (rates_control.py:16-30) raises for every batch size: line 25 subtracts the
+      [N, 3] gravity tensor from the [N] thrust column.  The golden case runs the reference's class with that ONE
+      line restated on the z component of gravity (what the attitude controller's thrust law implies); everything
+      else -- reset_commands, compute_body_torque incl. the in-place yaw-rate clamp on the action view, allocation,
+      motor model -- is the reference's code.  SURVEY appendix A lists this as a reference bug."""
+    ctrl = ref_shells.ref("control")
+    from aerial_gym.registry.controller_registry import controller_registry
+
+    controller_registry.register_controller("lee_velocity_steering_angle_control", ctrl.LeeVelocitySteeringAngleController,
+                                            ctrl.lee_controller_config)
+
+    class LeeRatesControllerZ(ctrl.LeeRatesController):
+        def update(self, command_actions):
+            self.reset_commands()
+            self.wrench_command[:, 2] = (command_actions[:, 0] - self.gravity[:, 2]) * self.mass[:, 0]
+            self.wrench_command[:, 3:6] = self.compute_body_torque(self.robot_orientation, command_actions[:, 1:4])
+            return self.wrench_command
+
+    controller_registry.register_controller("lee_rates_control_zfix", LeeRatesControllerZ, ctrl.lee_controller_config)
 
 
 def main():
@@ -471,9 +519,17 @@ def main():
     for ctrl_name, key in (("octarotor_position_control", "position"), ("octarotor_velocity_control", "velocity"),
                            ("rov_fully_actuated_control", "fully_actuated")):
         gen_step("octarotor", BaseOctarotorCfg, ctrl_name, key, consts["octarotor"])
+    register_unregistered_reference_controllers()
+    gen_step("quad", BaseQuadCfg, "lee_velocity_steering_angle_control", "velocity_steering", consts["quad"])
+    gen_step("quad", BaseQuadCfg, "lee_rates_control_zfix", "rates", consts["quad"], action_scale=2.0)
     gen_rewards(rng)
     gen_trace(consts["quad"], "lee_position_control", "position", "position")
     gen_trace(consts["quad"], "lee_attitude_control", "attitude", "attitude", T=160)
+    # SURVEY 8d config 1 as written: 1000 steps, the task's real episode length (500), zero set-point then U(-1, 1)
+    # (each drawn set-point is held for 25 steps: per-step white-noise set-points, as in the 260-step trace above, make
+    # the vehicles tumble away from the origin within ~400 steps and turn the comparison into a chaos test)
+    gen_trace(consts["quad"], "lee_position_control", "position", "position", T=1000, episode_len=500, zero_steps=500,
+              sparse_every=10, hold=25)
 
 
 if __name__ == "__main__":

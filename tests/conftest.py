@@ -25,6 +25,41 @@ def golden_params(g):
     return json.loads(str(g["params_json"]))
 
 
+class TraceReader:
+    """Uniform access to the dense (trace_*_64.npz) and sparse (trace_*_64_long.npz: int16 actions in 1/256 units,
+    reset draws only for steps with a reset, obs / state every 10th step) trace fixtures."""
+
+    DRAWS = ("u_state", "u_tau_inc", "u_tau_dec", "u_thrust", "u_kT")
+
+    def __init__(self, g):
+        self.g = g
+        self.sparse = "action_q8" in g.files
+        self.T = (g["action_q8"] if self.sparse else g["action"]).shape[0]
+        if self.sparse:
+            self._reset_row = {int(t): i for i, t in enumerate(g["reset_steps"])}
+            self._kept_row = {int(t): i for i, t in enumerate(g["kept_steps"])}
+            self._act = g["action_q8"].astype(np.float32) / np.float32(256.0)
+        else:
+            self._act = g["action"]
+
+    def action(self, t):
+        return self._act[t]
+
+    def draws(self, t):
+        """the five uniform tensors of the reset at step t, or None when no env resets"""
+        if self.sparse:
+            i = self._reset_row.get(t)
+            return None if i is None else tuple(self.g[k][i] for k in self.DRAWS)
+        return tuple(self.g[k][t] for k in self.DRAWS) if self.g["reset_mask"][t].any() else None
+
+    def kept(self, name, t):
+        """obs / state_after_step of step t, or None if the sparse fixture did not keep it"""
+        if self.sparse:
+            i = self._kept_row.get(t)
+            return None if i is None else self.g[name][i]
+        return self.g[name][t]
+
+
 @pytest.fixture(scope="session")
 def orc():
     import oracle
@@ -34,8 +69,67 @@ def orc():
 
 
 def rel_err(a, b):
+    """Blended error max|a - b| / (1 + max|b|): kept for quantities whose scale is O(1) by construction (unit
+    quaternions, normalised images) and for the CPU oracle-vs-reference pins; the per-step state gates use
+    `max_abs` / `elem_err` below (north_star: fp32 state within 1e-5 per step, absolute)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (1.0 + np.abs(b).max()))
+
+
+def max_abs(a, b):
+    """max over components of |a - b| -- the gate north_star states for the fp32 state (1e-5 per step)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+def max_rel(a, b, floor=0.0):
+    """max over components of |a - b| / max(|b|, floor): for small-magnitude quantities (kT ~ 1e-5, thrusts)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    den = np.maximum(np.abs(b), floor)
+    ok = den > 0
+    return float((np.abs(a - b)[ok] / den[ok]).max()) if ok.any() else 0.0
+
+
+class ParityLog:
+    """Collects the measured maxima behind the gates so that they can be printed with the test run and echoed by
+    bench.py (`"parity"` key): name -> {"max": worst value seen, "gate": bound asserted, "unit": ...}."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def record(self, name, value, gate=None, unit="abs"):
+        r = self.rows.setdefault(name, {"max": 0.0, "gate": gate, "unit": unit, "n": 0})
+        r["max"] = max(r["max"], float(value))
+        r["n"] += 1
+        return value
+
+    def check(self, name, value, gate, unit="abs", ctx=None):
+        self.record(name, value, gate, unit)
+        assert value <= gate, (name, value, gate, ctx)
+
+
+PARITY = ParityLog()
+
+
+@pytest.fixture(scope="session")
+def parity():
+    return PARITY
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY.rows:
+        return
+    terminalreporter.write_sep("-", "measured parity maxima (value / gate)")
+    for k in sorted(PARITY.rows):
+        r = PARITY.rows[k]
+        terminalreporter.write_line(f"  {k:58s} {r['max']:.3e} / {r['gate'] if r['gate'] is not None else '-'}  [{r['unit']}, {r['n']} checks]")
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(PARITY.rows, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 @pytest.fixture(autouse=True)

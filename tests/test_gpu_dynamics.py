@@ -4,12 +4,12 @@ the same inputs, and vs the golden vectors of the reference.  Tolerance: fp32 st
 import numpy as np
 import pytest
 import torch
-from conftest import golden_params, load_golden, rel_err
+from conftest import golden_params, load_golden, max_abs, max_rel, rel_err
 
 pytestmark = pytest.mark.gpu
 
 STEP_CASES = ["quad_position", "quad_velocity", "quad_attitude", "quad_acceleration", "quad_no_control",
-              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated"]
+              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated", "quad_rates", "quad_velocity_steering"]
 TOL = 1e-5
 
 
@@ -22,8 +22,22 @@ def _derived_split(d):
     return d[:, 0:3], d[:, 3:7], d[:, 7:10], d[:, 10:13], d[:, 13:16]
 
 
+STATE_PARTS = (("position", slice(0, 3)), ("quaternion", slice(3, 7)), ("linvel", slice(7, 10)), ("angvel", slice(10, 13)))
+
+
+def state_gate(parity, tag, got, ref, gate=TOL, ctx=None):
+    """north_star: fp32 state within 1e-5 per step -- max ABSOLUTE error per component group, no blending with
+    the magnitude of the state (|angvel| reaches 12 rad/s in the clipped-action cases)."""
+    for name, sl in STATE_PARTS:
+        parity.check(f"{tag}/{name}", max_abs(got[:, sl], ref[:, sl]), gate, "abs", ctx)
+
+
 @pytest.mark.parametrize("case", STEP_CASES)
-def test_single_substep_vs_oracle_and_golden(orc, case):
+def test_single_substep_vs_oracle_and_golden(orc, parity, case):
+    """One physics sub-step through the C ABI on the reference's recorded inputs.  Gates (all per step):
+    state vs the oracle and vs the golden's next state (reference control + oracle integrator): 1e-5 absolute per
+    component; derived body-frame velocities / vehicle quaternion vs the REFERENCE's own outputs: 1e-5 absolute;
+    controller wrench vs the reference: 1e-5 absolute (N, N m); motor thrusts: 1e-5 relative to max(|u|, 1e-2 N)."""
     from gpu_harness import DynHarness
 
     g = load_golden("step_" + case)
@@ -33,7 +47,8 @@ def test_single_substep_vs_oracle_and_golden(orc, case):
     H = DynHarness(pd, n)
     H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"])
     H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
-    for k in range(g["state"].shape[0]):
+    K = g["state"].shape[0]
+    for k in range(K):
         st, th = g["state"][k].copy(), g["thrust_in"][k].copy()
         dist = g["disturb"][k] if g["disturb"][k].any() else None
         o = orc.substep(P, st, g["action"][k], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"],
@@ -43,23 +58,26 @@ def test_single_substep_vs_oracle_and_golden(orc, case):
             H.set_disturb(dist[None], g["disturb_max"])
         H.substeps(g["action"][k], 1)
         gs, gt, gd = H.get("state"), H.get("thrust"), H.get("derived")
-        assert rel_err(gs, st) < TOL, (case, k, "state vs oracle")
-        assert rel_err(gt, th) < TOL, (case, k)
+        state_gate(parity, f"substep_vs_oracle[{case}]", gs, st, ctx=k)
+        if k + 1 < K:  # the generator advanced the reference's wrench with the oracle integrator: state[k + 1]
+            state_gate(parity, f"substep_vs_golden_next_state[{case}]", gs, g["state"][k + 1], ctx=k)
+        parity.check(f"substep_thrust_vs_oracle[{case}]", max_rel(gt, th, 1e-2), TOL, "rel(floor 1e-2 N)", k)
+        parity.check(f"substep_thrust_vs_reference[{case}]", max_rel(gt, g["thrust_out"][k], 1e-2), TOL, "rel(floor 1e-2 N)", k)
         e, qv, vv, vb, wb = _derived_split(gd)
-        assert _angle_err(e, o.euler) < TOL
-        for got, ref, gold in ((qv, o.qveh, g["qveh"][k]), (vv, o.vveh, g["vveh"][k]), (vb, o.vbody, g["vbody"][k]),
-                               (wb, o.wbody, g["wbody"][k])):
-            assert rel_err(got, ref) < TOL
-            assert rel_err(got, gold) < TOL  # the reference's own numbers
-        assert rel_err(gt, g["thrust_out"][k]) < TOL
+        parity.check(f"substep_euler_vs_oracle[{case}]", _angle_err(e, o.euler), TOL, "rad", k)
+        parity.check(f"substep_euler_vs_reference[{case}]", _angle_err(e, g["euler"][k]), TOL, "rad", k)
+        for name, got, ref, gold in (("qveh", qv, o.qveh, g["qveh"][k]), ("vveh", vv, o.vveh, g["vveh"][k]),
+                                     ("vbody", vb, o.vbody, g["vbody"][k]), ("wbody", wb, o.wbody, g["wbody"][k])):
+            parity.check(f"substep_{name}_vs_oracle[{case}]", max_abs(got, ref), TOL, "abs", k)
+            parity.check(f"substep_{name}_vs_reference[{case}]", max_abs(got, gold), TOL, "abs", k)  # the reference's own numbers
         if "no_control" not in case:
-            assert rel_err(H.get("wrench"), g["wrench_cmd"][k]) < TOL
-            assert rel_err(H.get("wrench"), o.wrench_cmd) < TOL
-        assert np.array_equal(H.get("actions"), g["action"][k])
+            parity.check(f"substep_wrench_vs_reference[{case}]", max_abs(H.get("wrench"), g["wrench_cmd"][k]), TOL, "abs", k)
+            parity.check(f"substep_wrench_vs_oracle[{case}]", max_abs(H.get("wrench"), o.wrench_cmd), TOL, "abs", k)
+        assert np.array_equal(H.get("actions"), g["action"][k])  # robot_actions: what the policy handed in (un-clipped)
 
 
 @pytest.mark.parametrize("case", ["quad_position", "octarotor_velocity"])
-def test_fused_k_substeps_equal_k_launches(orc, case):
+def test_fused_k_substeps_equal_k_launches(orc, parity, case):
     """10 fused sub-steps == 10 oracle sub-steps (config 3/4 use 10, env_with_obstacles.py:29)."""
     from gpu_harness import DynHarness
 
@@ -84,10 +102,12 @@ def test_fused_k_substeps_equal_k_launches(orc, case):
         o = orc.substep(P, st, act, th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"], g["Kw"],
                         disturb=dist[s] if use_dist else None, disturb_max=g["disturb_max"])
     H.substeps(act, K)
-    assert rel_err(H.get("state"), st) < 5e-5  # 10 steps of <= 1e-5 each
-    assert rel_err(H.get("thrust"), th) < 5e-5
+    # 10 free-running sub-steps: the gate is 10 x the per-step bound, absolute, per component group
+    state_gate(parity, f"fused_10_substeps_vs_oracle[{case}]", H.get("state"), st, gate=10 * TOL)
+    parity.check(f"fused_10_substeps_thrust[{case}]", max_rel(H.get("thrust"), th, 1e-2), 10 * TOL, "rel(floor 1e-2 N)")
     # derived tensors are those of the LAST sub-step's pre-physics state (stale by one step)
-    assert rel_err(H.get("derived")[:, 10:16], np.concatenate([o.vbody, o.wbody], axis=1)) < 5e-5
+    parity.check(f"fused_10_substeps_body_velocities[{case}]",
+                 max_abs(H.get("derived")[:, 10:16], np.concatenate([o.vbody, o.wbody], axis=1)), 10 * TOL, "abs")
     assert np.array_equal(H.get("prev_actions"), act)  # appendix A #2
     assert int(H.sim_steps.cpu()[0]) == 1
 
@@ -136,7 +156,7 @@ def test_reward_obs_position(orc):
     H.crashes.copy_(torch.from_numpy(g["crashes_in"]))
     H.sim_steps.copy_(torch.arange(n, dtype=torch.int32) % 7 + 498)
     r = H.reward_position(g["target"], 500)
-    assert rel_err(r, g["reward"]) < TOL
+    assert max_abs(r, g["reward"]) < TOL  # rewards are O(1..20): absolute
     assert np.array_equal(H.crashes.cpu().numpy(), g["crashes_out"])
     trunc = (np.arange(n) % 7 + 498) > 500
     assert np.array_equal(H.trunc.cpu().numpy(), trunc)
@@ -158,9 +178,9 @@ def test_reward_navigation(orc):
     H.crashes.copy_(torch.from_numpy(g["crashes"]))
     r, pe, ppe = H.reward_navigation(g["target"], g["rp"], float(g["curriculum_progress"]), g["prev_pos_err"],
                                      np.zeros_like(g["pos_err"]), 100)
-    assert rel_err(pe, g["pos_err"]) < TOL
+    assert max_abs(pe, g["pos_err"]) < TOL
     assert np.array_equal(ppe, g["prev_pos_err"])
-    assert rel_err(r, g["reward"]) < TOL
+    assert max_rel(r, g["reward"], 1.0) < TOL  # navigation rewards reach -100 (collision penalty)
 
 
 def test_reset_masked_vs_oracle(orc):
@@ -184,17 +204,17 @@ def test_reset_masked_vs_oracle(orc):
     orc.reset_robot_state(mask, g["init_u_state"], g["min_init_state"], g["max_init_state"], -np.ones((n, 3), np.float32),
                           np.ones((n, 3), np.float32), ref)
     got = H.get("state")
-    assert rel_err(got, ref) < 1e-6
+    assert max_abs(got, ref) < 2e-6
     m = mask.astype(bool)
     assert np.array_equal(got[~m], state0[~m])
-    assert rel_err(H.get("thrust")[m], g["init_thrust"][m]) < 1e-6  # same draws as the reference's initial reset
+    assert max_rel(H.get("thrust")[m], g["init_thrust"][m], 1e-2) < 1e-6  # same draws as the reference's initial reset
     assert np.array_equal(H.get("thrust")[~m], g["init_thrust"][~m])
-    assert rel_err(H.get("kT")[m], g["init_kT"][m]) < 1e-6
+    assert max_rel(H.get("kT")[m], g["init_kT"][m]) < 1e-6  # kT ~ 1e-5: a relative gate (an absolute one would pass anything)
     steps = H.sim_steps.cpu().numpy()
     assert np.all(steps[m] == 0) and np.all(steps[~m] == 7)
     # derived refreshed for ALL envs
     eu, qv, vv, vb, wb = orc.update_states(got)
-    assert rel_err(H.get("derived")[:, 3:7], qv) < TOL and rel_err(H.get("derived")[:, 13:16], wb) < TOL
+    assert max_abs(H.get("derived")[:, 3:7], qv) < TOL and max_abs(H.get("derived")[:, 13:16], wb) < TOL
     # nothing happens when no env resets
     before = H.get("derived").copy()
     H.set(state=state0)
@@ -235,7 +255,7 @@ def test_large_batch_properties(orc):
     for _ in range(3):
         orc.substep(P, st, act[sub], th, arrs["kT"][sub], arrs["tau_inc"][sub], arrs["tau_dec"][sub], g["Kp"][idx][sub],
                     g["Kv"][idx][sub], g["KR"][idx][sub], g["Kw"][idx][sub])
-    assert rel_err(full[sub], st) < 3e-5
+    assert max_abs(full[sub], st) < 3 * TOL  # 3 free-running sub-steps
 
 
 def test_device_rng_reset_is_the_documented_philox_stream(orc):
@@ -344,7 +364,7 @@ def test_device_disturbance_stream(orc):
                     disturb=d, disturb_max=g["disturb_max"])
     H.substeps(g["action"][0], K)
     assert occ_total > 10
-    assert rel_err(H.get("state"), st) < 3e-5
+    assert max_abs(H.get("state"), st) < 4 * TOL  # 4 free-running sub-steps
     # and it really was applied: without disturbance the result differs
     H2 = DynHarness(pd, n)
     H2.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"], state=g["state"][0], thrust=g["thrust_in"][0])

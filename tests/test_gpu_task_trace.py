@@ -44,13 +44,20 @@ class ReplaySource:
         return mean
 
 
-@pytest.mark.parametrize("tag,controller", [("position", "lee_position_control"), ("attitude", "lee_attitude_control")])
+@pytest.mark.parametrize("tag,controller", [("position", "lee_position_control"), ("attitude", "lee_attitude_control"),
+                                            ("position_long", "lee_position_control")])
 def test_task_api_reproduces_config1_trace(tag, controller):
+    """task_registry.make_task -> reset / step, free-running, vs the reference trace (tests/trace_util.py states the
+    gates): flags bit-exact and reward <= 1e-4 absolute over the gated segment (500 steps for `position_long`, SURVEY
+    8d), first-divergence step reported for the rest."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from conftest import max_abs
+    from trace_util import TRACES, run_trace_against
 
-    g = load_golden(f"trace_{tag}_64")
+    name, gate_steps, tail_gate = TRACES[tag]
+    g = load_golden(name)
     n = g["init_state"].shape[0]
     rs = ReplaySource(DEV)
     zeros3 = np.zeros((n, 3), np.float32)
@@ -73,24 +80,19 @@ def test_task_api_reproduces_config1_trace(tag, controller):
     cfg.args = {"strict_rng": True, "random_source": rs}
     task = task_registry.make_task("position_setpoint_task", seed=1, num_envs=n, headless=True)
     try:
-        obs, rew, term, trunc, info = task.reset()
+        task.reset()
         st = task.obs_dict["robot_state_tensor"].cpu().numpy()
-        assert rel_err(st, g["init_state"]) < 1e-6
-        T = g["action"].shape[0]
-        worst_r = worst_o = early = 0.0
-        for t in range(T):
-            if g["reset_mask"][t].any():
-                push_reset(g["u_state"][t], g["u_tau_inc"][t], g["u_tau_dec"][t], g["u_thrust"][t], g["u_kT"][t])
-            obs, rew, term, trunc, info = task.step(torch.from_numpy(g["action"][t]).to(DEV))
-            assert np.array_equal(trunc.cpu().numpy(), g["truncations"][t]), t
-            assert np.array_equal(term.cpu().numpy(), g["crashes"][t]), t
-            worst_r = max(worst_r, rel_err(rew.cpu().numpy(), g["reward"][t]))
-            worst_o = max(worst_o, rel_err(obs["observations"].cpu().numpy(), g["obs"][t]))
-            if t == 19:
-                early = max(worst_r, worst_o)
-        assert early < 5e-5, early            # ~1e-6 per step
-        assert worst_r < 1e-3 and worst_o < 1e-3, (worst_r, worst_o)  # free-running fp32 drift
-        assert all(len(v) == 0 for v in rs.q.values()), {k: len(v) for k, v in rs.q.items()}  # every draw consumed
+        assert max_abs(st, g["init_state"]) < 1e-6
+
+        def step(t, action, draws):
+            if draws is not None:
+                push_reset(*draws)
+            obs, rew, term, trunc, info = task.step(torch.from_numpy(np.ascontiguousarray(action)).to(DEV))
+            return obs["observations"].cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy()
+
+        first_div = run_trace_against(step, g, gate_steps, tail_gate, f"gpu_task_vs_reference_trace[{tag}]")
+        if first_div is None or tail_gate is not None:
+            assert all(len(v) == 0 for v in rs.q.values()), {k: len(v) for k, v in rs.q.items()}  # every draw consumed
     finally:
         cfg.args = {}
         cfg.episode_len_steps = 500

@@ -5,7 +5,7 @@ import pytest
 from conftest import golden_params, load_golden, rel_err
 
 STEP_CASES = ["quad_position", "quad_velocity", "quad_attitude", "quad_acceleration", "quad_no_control",
-              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated"]
+              "octarotor_position", "octarotor_velocity", "octarotor_fully_actuated", "quad_rates", "quad_velocity_steering"]
 
 
 def test_math_helpers(orc):
@@ -110,14 +110,21 @@ def test_navigation_reward(orc):
     assert rel_err(r, g["reward"]) < 3e-6
 
 
-@pytest.mark.parametrize("tag", ["position", "attitude"])
+from trace_util import TRACES, run_trace_against  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", list(TRACES))
 def test_trace_config1(orc, tag):
-    """BASELINE config 1 (64 envs, empty_env): oracle loop vs the trace assembled from the
-    reference's control / reward / reset code (+ oracle integrator).  Chaotic divergence is
-    bounded by comparing teacher-forced one-step predictions AND the free-running trace."""
+    """BASELINE config 1 (64 envs, empty_env): oracle loop vs the trace assembled from the reference's control /
+    reward / reset code (+ oracle integrator).  `position_long` is SURVEY 8d's 1000-step trace with the task's real
+    episode length: 500 steps at the zero set-point (gated at 1e-4), the truncation reset of all envs, then 500 steps
+    of U(-1, 1) set-points held for 25 steps each, where fp32 rounding differences (~1e-6 per step in the body rates)
+    are amplified by the manoeuvres: that half reports its first-divergence step."""
+    from conftest import max_abs
     from oracle_env import OraclePositionEnv
 
-    g = load_golden(f"trace_{tag}_64")
+    name, gate_steps, tail_gate = TRACES[tag]
+    g = load_golden(name)
     pd = golden_params(g)
     n = g["init_state"].shape[0]
     ranges = dict(tau_inc=(0.04, 0.04), tau_dec=(0.04, 0.04), thrust=(0.0, 2.0), kT=(0.00000926312, 0.00001826312))
@@ -125,24 +132,21 @@ def test_trace_config1(orc, tag):
                             g["min_init_state"], g["max_init_state"], ranges)
     env.reset_masked(np.ones(n, np.uint8), g["init_u_state"], g["init_u_tau_inc"], g["init_u_tau_dec"],
                      g["init_u_thrust"], g["init_u_kT"])
-    assert rel_err(env.state, g["init_state"]) < 1e-6
+    assert max_abs(env.state, g["init_state"]) < 1e-6
     assert rel_err(env.thrust, g["init_thrust"]) < 1e-6
     assert rel_err(env.kT, g["init_kT"]) < 1e-6
-    T = g["action"].shape[0]
-    worst_r = worst_s = early_s = 0.0
-    for t in range(T):
-        draws = (g["u_state"][t], g["u_tau_inc"][t], g["u_tau_dec"][t], g["u_thrust"][t], g["u_kT"][t])
-        obs, rew, crashes, trunc, reset_mask, state_after = env.step(g["action"][t], draws)
-        assert np.array_equal(reset_mask.astype(bool), g["reset_mask"][t]), t
-        assert np.array_equal(trunc.astype(bool), g["truncations"][t]), t
-        worst_s = max(worst_s, rel_err(state_after, g["state_after_step"][t]))
-        if t < 20:
-            early_s = worst_s
-        worst_r = max(worst_r, rel_err(rew, g["reward"][t]))
-        assert rel_err(obs, g["obs"][t]) < 5e-4, t
-    # fp32 noise grows along the free-running (closed-loop but chaotic under random actions) trace
-    assert early_s < 5e-5, early_s  # ~1e-6 per step
-    assert worst_s < 1e-3 and worst_r < 1e-3, (worst_s, worst_r)
+    first_state = []
+
+    def step(t, action, draws):
+        obs, rew, crashes, trunc, reset_mask, state_after = env.step(action, draws)
+        if t == 0:
+            first_state.append(state_after)
+        assert t >= gate_steps or np.array_equal(reset_mask.astype(bool), g["reset_mask"][t]), t
+        return obs, rew, crashes, trunc
+
+    run_trace_against(step, g, gate_steps, tail_gate, f"oracle_vs_reference_trace[{tag}]")
+    if "action_q8" not in g.files:  # one step from the identical initial state: the per-step bound
+        assert max_abs(first_state[0], g["state_after_step"][0]) < 1e-5
 
 
 # ---------------------------------------------------------------- LiDAR navigation task
