@@ -93,6 +93,32 @@ class navigation_task_config:
         return out
 
 
+class fully_actuated_lidar_navigation_task_config(navigation_task_config):
+    """BASELINE configs[3] as written: "fully-actuated octarotor + 32-beam x 512 LiDAR depth+seg".  Assembled from
+    reference pieces only: NavigationTask (reward / obs / curriculum), `base_octarotor` (base_octarotor_config.py)
+    with a 32 x 512 range + segmentation LiDAR (base_lidar_config.py), and FullyActuatedController
+    (fully_actuated_control.py:14-32, registered as `rov_fully_actuated_control`, control/__init__.py:98-100), whose
+    command is 7-D: world-frame position set-point + orientation set-point (xyzw).  The policy's 4-D action maps to
+    that command the way the reference's tasks map theirs (a static function of the action alone)."""
+
+    robot_name = "base_octarotor_with_lidar_32x512"
+    controller_name = "rov_fully_actuated_control"
+    action_space_dim = 4
+
+    @staticmethod
+    def action_transformation_function(action):
+        """(x, y, z, yaw) in [-1, 1] -> position set-point within +-(5, 5, 2.5) m, level attitude at yaw * pi."""
+        a = torch.clamp(action, -1.0, 1.0)
+        out = torch.zeros((a.shape[0], 7), device=a.device)
+        out[:, 0] = 5.0 * a[:, 0]
+        out[:, 1] = 5.0 * a[:, 1]
+        out[:, 2] = 2.5 * a[:, 2]
+        half = 0.5 * torch.pi * a[:, 3]
+        out[:, 5] = torch.sin(half)
+        out[:, 6] = torch.cos(half)
+        return out
+
+
 class lidar_navigation_task_config:  # lidar_navigation_task_config.py:5-108
     seed = -1
     sim_name = "base_sim"

@@ -38,8 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--num-envs", type=int, default=8192, help="envs per GPU")
-    ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar", "lidar_nav"])
+    ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default: 8192; 4096 for the LiDAR workloads, BASELINE configs[3])")
+    ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar", "lidar_velocity", "lidar_nav"])
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step")
@@ -47,7 +47,10 @@ def parse():
                     help="N > 1: who enqueues the per-step all-gather. auto = time both (torch's process group first, then the "
                          "library's RCCL worker thread under a watchdog) and report the faster one as `value`")
     ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.num_envs is None:
+        args.num_envs = 4096 if args.workload in ("lidar", "lidar_velocity") else 8192
+    return args
 
 
 def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all"):
@@ -69,15 +72,22 @@ def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all"):
         lcfg.device = device
         lcfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
         return task_registry.make_task("lidar_navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
-    cfg = navigation_task_config
+    if workload == "lidar":  # BASELINE configs[3] as written: FULLY-ACTUATED octarotor (7-D command) + 32 x 512 LiDAR
+        from aerial_gym_simulator_amd.config.task_config import fully_actuated_lidar_navigation_task_config as cfg
+    else:
+        cfg = navigation_task_config
     if not hasattr(cfg, "_reference_curriculum"):
         cfg._reference_curriculum = (cfg.curriculum.min_level, cfg.curriculum.max_level)
     cfg.curriculum.min_level, cfg.curriculum.max_level = (106, 107) if obstacles == "all" else cfg._reference_curriculum
     cfg.device = device
     cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}  # rank: own scenes, RNG stream and semantic-id range
     if workload == "lidar":
+        return task_registry.make_task("navigation_task_fully_actuated_lidar", seed=1 + rank, num_envs=num_envs, headless=True)
+    if workload == "lidar_velocity":  # the same robot and sensor under the Lee velocity controller (4-D command)
         cfg.robot_name = "base_octarotor_with_lidar_32x512"
         cfg.controller_name = "octarotor_velocity_control"
+    else:
+        cfg.robot_name, cfg.controller_name = "base_quadrotor_with_camera_64x48", "lee_velocity_control"
     return task_registry.make_task("navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
 
 
@@ -425,7 +435,7 @@ def main():
     value = n_gpus * N * args.steps / dt
     exchange = exchange_diagnostics(task, actions, args, world, gather_buf, dt) if use_dist else None
     out = {
-        "metric": "env-steps/sec at N_envs=8192 per GPU (" + ("dynamics-only" if args.workload == "dynamics" else "+" + args.workload + " sensor") + ")",
+        "metric": f"env-steps/sec at N_envs={N} per GPU (" + ("dynamics-only" if args.workload == "dynamics" else "+" + args.workload + " sensor") + ")",
         "value": value,
         "unit": "env-steps/s",
         "n_gpus": n_gpus,
@@ -440,7 +450,8 @@ def main():
         "config": {
             "workload": {"dynamics": "base_quadrotor position_setpoint_task, lee_position_control, empty_env, 1 sub-step/step (BASELINE configs[1])",
                          "depth": "base_quadrotor navigation_task, lee_velocity_control, 100 random boxes + 6 walls, 10 sub-steps/step, 64x48 depth+seg camera (BASELINE configs[2])",
-                         "lidar": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes, 32x512 LiDAR range+seg (BASELINE configs[3])",
+                         "lidar": "base_octarotor navigation_task, rov_fully_actuated_control (7-D position + attitude command), 100 boxes + 6 walls, 10 sub-steps/step, 32x512 LiDAR range+seg (BASELINE configs[3] as written)",
+                         "lidar_velocity": "base_octarotor navigation_task, octarotor_velocity_control, 100 boxes + 6 walls, 32x512 LiDAR range+seg",
                          "lidar_nav": "magpie lidar_navigation_task, magpie_acceleration_control, env_with_lidar_nav_obstacles (91 assets), 48x120 world-frame point-cloud LiDAR, 10 sub-steps/step (SURVEY 8 f2)"}[args.workload],
             "num_envs_per_gpu": N,
             "num_envs_total": n_gpus * N,
