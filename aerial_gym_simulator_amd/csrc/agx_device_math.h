@@ -108,12 +108,17 @@ AGX_DEV M33 quat_to_rotmat(Q4 q) {
   m.m22 = 1.0f - 2.0f * (xx + yy);
   return m;
 }
+// ---- elementary functions -------------------------------------------------------------------------
+// sincos_bounded / atan2_cw / asin_cw / exp_cw are explicit single-precision kernels (cephes-style range reduction +
+// minimax polynomial; S. Moshier's sinf.c, atanf.c, asinf.c, expf.c) written as individually rounded IEEE operations.
+// The CPU restatement the parity tests check against evaluates the SAME sequences, so with contraction off the dynamics path is
+// bit-reproducible there (ocml's and glibc's sinf / atan2f / expf agree only to ~1 ulp, like torch's own CPU and CUDA
+// kernels); accuracy vs libm is <= 2.5 ulp on the ranges used (DESIGN.md "numerics").
+//
 // sin and cos of the same angle.  Every angle on this path is bounded (|x| < 64: Euler angles,
 // half angles, yaw set-points clipped to +-10), so a 3-term Cody-Waite reduction by pi/2 is
 // exact enough and the Payne-Hanek slow path of the generic sinf/cosf (hundreds of
-// instructions and ~100 VGPRs of dead weight per call site) is not needed.  Polynomials are
-// the single-precision minimax kernels of cephes sinf/cosf on [-pi/4, pi/4]; max error
-// ~1.2e-7, well inside the 1e-5 state tolerance (DESIGN.md "numerics").
+// instructions and ~100 VGPRs of dead weight per call site) is not needed.
 AGX_DEV void sincos_bounded(float x, float &sn, float &cs) {
   const float kTwoOverPi = 0.636619772367581343f;
   float kf = rintf(x * kTwoOverPi);
@@ -127,6 +132,70 @@ AGX_DEV void sincos_bounded(float x, float &sn, float &cs) {
   float c0 = (k & 1) ? ps : pc;
   sn = (k & 2) ? -s0 : s0;
   cs = ((k + 1) & 2) ? -c0 : c0;
+}
+
+// cephes atanf: reduction at tan(3 pi / 8) and tan(pi / 8)
+AGX_DEV float atan_cw(float xx) {
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) {
+    y = 1.5707963267948966f;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) {
+    y = 0.7853981633974483f;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y = 0.0f;
+  }
+  float z = x * x;
+  float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+  y = y + p;
+  return (xx < 0.0f) ? -y : y;
+}
+// atan2 for finite arguments; atan2(0, 0) = 0 like torch (every consumer takes the angle modulo 2 pi)
+AGX_DEV float atan2_cw(float y, float x) {
+  const float half_pi = 1.5707963267948966f;
+  if (x == 0.0f) {
+    if (y == 0.0f) return 0.0f;
+    return (y > 0.0f) ? half_pi : -half_pi;
+  }
+  float z = atan_cw(y / x);
+  if (x < 0.0f) z = (y < 0.0f) ? z - kPi : z + kPi;
+  return z;
+}
+// cephes asinf, |x| <= 1
+AGX_DEV float asin_cw(float xx) {
+  float a = fabsf(xx), x, z;
+  bool flag = false;
+  if (a < 1.0e-4f) return xx;
+  if (a > 0.5f) {
+    z = 0.5f * (1.0f - a);
+    x = sqrtf(z);
+    flag = true;
+  } else {
+    x = a;
+    z = x * x;
+  }
+  z = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+  if (flag) {
+    z = z + z;
+    z = 1.5707963267948966f - z;
+  }
+  return (xx < 0.0f) ? -z : z;
+}
+AGX_DEV float pow2i(int n) { return __uint_as_float((uint32_t)(n + 127) << 23); }  // 2^n, -126 <= n <= 127
+// cephes expf; results below the smallest normal are flushed to 0
+AGX_DEV float exp_cw(float x) {
+  if (x > 88.7228317f) return INFINITY;
+  if (x < -87.3365402f) return 0.0f;
+  float z = floorf(1.44269504088896341f * x + 0.5f);
+  float r = x - z * 0.693359375f;
+  r = r - z * -2.12194440e-4f;
+  int n = (int)z;
+  float rr = r * r;
+  float p = (((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r + 1.6666665459e-1f) * r +
+             5.0000001201e-1f) * rr + r + 1.0f;
+  int n1 = n / 2, n2 = n - n1;
+  return p * pow2i(n1) * pow2i(n2);
 }
 
 // utils/math.py:156-172
@@ -146,18 +215,18 @@ AGX_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
 AGX_DEV V3 euler_xyz_0_2pi(Q4 q) {
   float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
   float cosr_cosp = q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z;
-  float roll = atan2f(sinr_cosp, cosr_cosp);
+  float roll = atan2_cw(sinr_cosp, cosr_cosp);
   float sinp = 2.0f * (q.w * q.y - q.z * q.x);
   float pitch;
   if (fabsf(sinp) >= 1.0f) {
     float sg = (sinp > 0.0f) ? 1.0f : ((sinp < 0.0f) ? -1.0f : 0.0f);
     pitch = (kPi / 2.0f) * sg;
   } else {
-    pitch = asinf(sinp);
+    pitch = asin_cw(sinp);
   }
   float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
   float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
-  float yaw = atan2f(siny_cosp, cosy_cosp);
+  float yaw = atan2_cw(siny_cosp, cosy_cosp);
   return V3{pymod(roll, kTwoPi), pymod(pitch, kTwoPi), pymod(yaw, kTwoPi)};
 }
 

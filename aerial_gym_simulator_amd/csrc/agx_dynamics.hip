@@ -11,15 +11,20 @@
 // No MFMA: there is no dense contraction in this path (the 6xM allocation products are
 // per-env matrix-vector products with constant matrices held in SGPRs).
 #include "agx_common.h"
-// The dynamics path is graded on a 1e-5 state tolerance, not on bits: let the compiler contract
-// a*b+c into v_fma_f32 in the hot device functions (fewer, and more accurate, operations).  The
-// predicates that must be bit-reproducible (collision, reset placement) switch it off again below.
+// Arithmetic of the state path (controller, motor model, integrator, rewards).  Default: every + - * / sqrt is one
+// correctly rounded IEEE operation (no fma contraction) and the elementary functions are the explicit kernels of
+// agx_device_math.h, i.e. exactly the sequence the CPU restatement of the parity tests evaluates: the whole env step is
+// BIT-IDENTICAL to that restatement (tests assert array_equal), which in turn is pinned to the reference's own outputs on the
+// CPU.  Measured cost of exactness on MI355X (profiles/r02_parity_variants.json): k_env_step 10.3 -> 11.2 us at 8192 envs,
+// 138 -> 154 us at 2^21 envs.  The two switches below re-enable the faster, ~1e-6-accurate arithmetic for A/B runs:
+//   AGX_DYN_CONTRACT=1  let the compiler contract a*b+c into v_fma_f32
+//   AGX_DYN_FAST_RCP=1  hardware v_rcp / v_rsq / v_sqrt (+ one Newton step) instead of correctly rounded division / sqrt
 #ifndef AGX_DYN_CONTRACT
-#define AGX_DYN_CONTRACT 1
+#define AGX_DYN_CONTRACT 0
 #endif
 #ifndef AGX_DYN_WAVES
-// waves per SIMD the env-step kernel is compiled for.  With the scalar-base SoA addressing (soa_at) it needs 160
-// VGPRs and fits 3; a limit of 4 (128 VGPRs) spills.  Measured (profiles/r01_soa_addressing.txt).
+// waves per SIMD the straight-line env-step kernels are compiled for.  With the scalar-base SoA addressing (soa_at) they
+// need <= 168 VGPRs and fit 3; a limit of 4 (128 VGPRs) spills.  Measured (profiles/r01_soa_addressing.txt).
 #define AGX_DYN_WAVES 3
 #endif
 #ifndef AGX_DYN_WAVES_LOOP
@@ -29,6 +34,8 @@
 #endif
 #if AGX_DYN_CONTRACT
 #pragma clang fp contract(fast)
+#else
+#pragma clang fp contract(off)
 #endif
 #include "agx_device_math.h"
 #include "agx_rng.h"
@@ -36,12 +43,8 @@
 
 #include <type_traits>
 
-// State path only (controller, motor model, integrator: graded on the 1e-5 per-step tolerance, like the fma
-// contraction above): 1-ulp hardware reciprocal / square root / reciprocal square root instead of the
-// correctly rounded sequences (11 / 9 vector instructions each; the env step is bound by instruction issue).
-// Never used below the `contract(off)` line.
 #ifndef AGX_DYN_FAST_RCP
-#define AGX_DYN_FAST_RCP 1
+#define AGX_DYN_FAST_RCP 0
 #endif
 namespace agx {
 #if AGX_DYN_FAST_RCP
@@ -50,17 +53,17 @@ AGX_DEV float srcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   return fmaf(r, fmaf(-x, r, 1.0f), r);
 }
-AGX_DEV float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-AGX_DEV float srsq(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  float h = 0.5f * y;
-  return fmaf(h, fmaf(-x * y, y, 1.0f), y);
-}
+AGX_DEV float fdiv(float a, float b) { return a * srcp(b); }
+AGX_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 #else
-AGX_DEV float srcp(float x) { return 1.0f / x; }
-AGX_DEV float ssqrt(float x) { return sqrtf(x); }
-AGX_DEV float srsq(float x) { return 1.0f / sqrtf(x); }
+AGX_DEV float fdiv(float a, float b) { return a / b; }
+AGX_DEV float fsqrt(float x) { return sqrtf(x); }
 #endif
+// v / |v| the way torch evaluates it: the norm first, then one division per component
+AGX_DEV V3 normalized(V3 v) {
+  float nv = fsqrt(dot(v, v));
+  return V3{fdiv(v.x, nv), fdiv(v.y, nv), fdiv(v.z, nv)};
+}
 }  // namespace agx
 
 namespace agx {
@@ -179,12 +182,11 @@ AGX_DEV V3 compute_body_torque(const AgxRobotParams &P, Q4 q, V3 wb, Q4 qd, V3 &
 
 // base_lee_controller.py:173-194
 AGX_DEV Q4 desired_orientation_pos_vel(V3 f, float yaw) {
-  V3 b3 = f * srsq(dot(f, f));
+  V3 b3 = normalized(f);
   float sy, cy;
   sincos_bounded(yaw, sy, cy);
   V3 tmp = V3{cy, sy, 0.0f};
-  V3 b2 = cross(b3, tmp);
-  b2 = b2 * srsq(dot(b2, b2));
+  V3 b2 = normalized(cross(b3, tmp));
   V3 b1 = cross(b2, b3);
   M33 R{b1.x, b2.x, b3.x, b1.y, b2.y, b3.y, b1.z, b2.z, b3.z};
   return rotmat_to_quat(R);
@@ -192,8 +194,8 @@ AGX_DEV Q4 desired_orientation_pos_vel(V3 f, float yaw) {
 
 // base_lee_controller.py:158-169
 AGX_DEV Q4 desired_orientation_forces_yaw(V3 f, float yaw) {
-  float pitch = atan2f(f.x, f.z);
-  float roll = atan2f(-f.y, sqrtf(f.z * f.z + f.x * f.x));
+  float pitch = atan2_cw(f.x, f.z);
+  float roll = atan2_cw(-f.y, sqrtf(f.z * f.z + f.x * f.x));
   return quat_from_euler(roll, pitch, yaw);
 }
 
@@ -294,11 +296,10 @@ AGX_DEV float motor_update(const AgxRobotParams &P, float ref, float cur, float 
   ref = fminf(fmaxf(ref, P.min_thrust), P.max_thrust);
   float err = ref - cur;
   float tc = (sgnf(cur) * sgnf(err) < 0.0f) ? tau_dec : tau_inc;
-  float mix = srcp(P.use_discrete_approximation ? dt + tc : tc);
+  float mix = fdiv(1.0f, P.use_discrete_approximation ? dt + tc : tc);
   if (P.use_rps) {
-    const float inv_kT = srcp(kT);
-    float cur_rpm = ssqrt(cur * inv_kT);
-    float des_rpm = ssqrt(ref * inv_kT);
+    float cur_rpm = fsqrt(fdiv(cur, kT));
+    float des_rpm = fsqrt(fdiv(ref, kT));
     if (P.integration_rk4)
       cur_rpm += rk4_delta(des_rpm, cur_rpm, mix, P.max_rate, dt);
     else
@@ -323,24 +324,23 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
               P.inertia_inv[6] * rhs.x + P.inertia_inv[7] * rhs.y + P.inertia_inv[8] * rhs.z};
   V3 wb_new = V3{wb.x + dt * dwb.x, wb.y + dt * dwb.y, wb.z + dt * dwb.z};
   V3 w_new = quat_rotate(s.q, wb_new);
-  const float inv_mass = srcp(P.mass);
-  V3 v_new = V3{s.v.x + dt * (Fw.x * inv_mass), s.v.y + dt * (Fw.y * inv_mass), s.v.z + dt * (Fw.z * inv_mass)};
+  V3 v_new = V3{s.v.x + dt * fdiv(Fw.x, P.mass), s.v.y + dt * fdiv(Fw.y, P.mass), s.v.z + dt * fdiv(Fw.z, P.mass)};
   v_new = V3{v_new.x + P.gravity[0] * dt, v_new.y + P.gravity[1] * dt, v_new.z + P.gravity[2] * dt};
   float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
   float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
   v_new = v_new * ml;
   w_new = w_new * ma;
   float v2 = dot(v_new, v_new), w2 = dot(w_new, w_new);
-  if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * (P.max_linear_velocity * srsq(v2));
-  if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * (P.max_angular_velocity * srsq(w2));
+  if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
+  if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
   s.p = V3{s.p.x + v_new.x * dt, s.p.y + v_new.y * dt, s.p.z + v_new.z * dt};
   float wm2 = dot(w_new, w_new);
   if (wm2 != 0.0f) {
-    float wm = ssqrt(wm2);
+    float wm = fsqrt(wm2);
     float half = dt * wm * 0.5f;
     float sn, cs;
     sincos_bounded(half, sn, cs);  // |half| = dt |w| / 2 <= 0.5 (|w| <= 100 rad/s)
-    float sc = sn * srcp(wm);
+    float sc = fdiv(sn, wm);
     float x1 = w_new.x * sc, y1 = w_new.y * sc, z1 = w_new.z * sc;
     Q4 q = s.q;
     float rx = x1 * q.w + y1 * q.z - z1 * q.y;
@@ -348,8 +348,8 @@ AGX_DEV void integrate(const AgxRobotParams &P, EnvState &s, V3 Fb, V3 Tb) {
     float rz = z1 * q.w + x1 * q.y - y1 * q.x;
     float rw = -(x1 * q.x) - y1 * q.y - z1 * q.z;
     rx += q.x * cs; ry += q.y * cs; rz += q.z * cs; rw += q.w * cs;
-    float inv_nn = srsq(rx * rx + ry * ry + rz * rz + rw * rw);
-    s.q = Q4{rx * inv_nn, ry * inv_nn, rz * inv_nn, rw * inv_nn};
+    float nn = fsqrt(rx * rx + ry * ry + rz * rz + rw * rw);
+    s.q = Q4{fdiv(rx, nn), fdiv(ry, nn), fdiv(rz, nn), fdiv(rw, nn)};
   }
   s.v = v_new;
   s.w = w_new;
@@ -411,14 +411,14 @@ AGX_DEV bool collide_trajectory(const float *__restrict__ boxes, int nb, int n, 
   return hit;
 }
 
-AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * expf(-(v * v) * ex); }
-AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (expf(-(v * v) * ex) - 1.0f); }
+AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * exp_cw(-(v * v) * ex); }
+AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (exp_cw(-(v * v) * ex) - 1.0f); }
 
 // position_setpoint_task.py:245-282 on registers; returns the reward, ORs the distance crash
 AGX_DEV float reward_position(const EnvState &s, Q4 qveh, V3 wb, V3 tgt, bool &crash) {
   V3 pe = quat_apply(conj(qveh), tgt - s.p);  // quat_apply_inverse
   float dist = norm(pe);
-  float pos_reward = 3.0f * expf(-8.0f * dist * dist) + 2.0f * expf(-4.0f * dist * dist);
+  float pos_reward = 3.0f * exp_cw(-8.0f * dist * dist) + 2.0f * exp_cw(-4.0f * dist * dist);
   float dist_reward = (20.0f - dist) / 40.0f;
   V3 up = quat_rotate(s.q, V3{0.0f, 0.0f, 1.0f});  // quat_axis(q, 2)
   float tilt = fabsf(1.0f - up.z);

@@ -15,8 +15,8 @@
 
 namespace agx {
 
-AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * expf(-(v * v) * ex); }
-AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (expf(-(v * v) * ex) - 1.0f); }
+AGX_DEV float exp_reward(float mag, float ex, float v) { return mag * exp_cw(-(v * v) * ex); }
+AGX_DEV float exp_penalty(float mag, float ex, float v) { return mag * (exp_cw(-(v * v) * ex) - 1.0f); }
 
 struct LidarNavParams {
   float rp[22];

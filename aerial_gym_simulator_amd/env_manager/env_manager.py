@@ -167,8 +167,10 @@ class EnvManager(BaseManager):
         per_env_gains = has_gains and (bool(getattr(ctrl.cfg, "randomize_params", False))
                                        or bool(self.env_args.get("per_env_gains", False)))
         if has_gains:
-            for i in range(12):
-                params.gains_uniform[i] = (ctrl.gains_min[i] + ctrl.gains_max[i]) / 2.0
+            import numpy as np
+
+            for i in range(12):  # (max + min) / 2 in fp32, like K_*_tensor_current (base_lee_controller.py:59-62)
+                params.gains_uniform[i] = float((np.float32(ctrl.gains_max[i]) + np.float32(ctrl.gains_min[i])) / np.float32(2.0))
             ctrl._per_env_gains_bound = per_env_gains
         B.gains = p(g["controller_gains_soa"]) if per_env_gains else None
         B.wrench_cmd = None  # only the stand-alone controller call stores the wrench

@@ -65,6 +65,17 @@ def _fill(dst, values):
         dst[i] = float(v)
 
 
+def allocation_pinv(A32):
+    """Moore-Penrose inverse of the fp32 allocation matrix (control_allocation.py:27: torch.linalg.pinv), evaluated in
+    float64 and rounded once.  The reference's fp32 SVD leaves machine-dependent noise in the result (entries that are
+    exactly 0 come out as +-2e-4, the 1 / (4 * 0.13) torque gains differ by 7e-7 between two hosts), which would make
+    every thrust depend on the BLAS of the box; from float64 the fp32 result is the correctly rounded one, and entries
+    below 1e-12 of the largest are the zeros they stand for."""
+    P = np.linalg.pinv(np.asarray(A32, dtype=np.float32).astype(np.float64))
+    P[np.abs(P) < 1e-12 * np.abs(P).max()] = 0.0
+    return P.astype(np.float32)
+
+
 def robot_params_dict(robot_cfg, controller_cfg, controller_kind, sim_cfg):
     """Plain-number description of the robot (the parity tests consume the same dict)."""
     ca = robot_cfg.control_allocator_config
@@ -77,7 +88,7 @@ def robot_params_dict(robot_cfg, controller_cfg, controller_kind, sim_cfg):
     A = np.asarray(ca.allocation_matrix, dtype=np.float32)
     if A.shape != (6, M):
         raise ValueError("Allocation matrix must have 6 rows and num_motors columns.")
-    A_pinv = torch.linalg.pinv(torch.tensor(ca.allocation_matrix, dtype=torch.float32)).numpy()
+    A_pinv = allocation_pinv(A)
     J32 = inertia.astype(np.float32)
     W = motor_wrench_map(model, ca.motor_directions, float(mm.thrust_to_torque_ratio), com)
     scheme = getattr(mm, "integration_scheme", "rk4")

@@ -66,7 +66,7 @@ class OrcRobotParams(C.Structure):
 
 def build(force=False):
     """Compile oracle/*.c with gcc (oracle/Makefile).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_dynamics.c", "oracle_raycast.c", "oracle_types.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_dynamics.c", "oracle_raycast.c", "oracle_types.h", "oracle_math.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -488,3 +488,13 @@ def obs_navigation(state, euler, qveh, vbody, wbody, actions, target, u_vec, u_e
                              actions.shape[1], _p(_f(target)), _p(_f(u_vec)), _p(_f(u_euler)), _p(pixels), ns, H, W, gh, gw,
                              obs_dim, _p(obs))
     return obs
+
+
+def math_eval(which, x, y=None):
+    """oracle_math.h kernels: which in ("sin", "cos", "atan2", "asin", "exp"); atan2(x, y) takes (y-arg, x-arg)."""
+    idx = ("sin", "cos", "atan2", "asin", "exp").index(which)
+    x = _f(x).ravel()
+    yy = _f(y).ravel() if y is not None else x
+    out = np.zeros_like(x)
+    lib().orc_math_eval(idx, x.shape[0], _p(x), _p(yy), _p(out))
+    return out

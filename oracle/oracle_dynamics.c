@@ -18,6 +18,7 @@
  * Build: see oracle/Makefile (-O2 -ffp-contract=off, no -ffast-math).
  */
 #include "oracle_types.h"
+#include "oracle_math.h" /* the elementary functions the HIP kernels evaluate too, bit for bit */
 
 #include <math.h>
 #include <stdlib.h>
@@ -127,9 +128,10 @@ static void quat_to_rotmat(const float q[4], float m[9]) {
 
 /* utils/math.py:156-172 */
 static void quat_from_euler_xyz(float roll, float pitch, float yaw, float q[4]) {
-  float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
-  float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
-  float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+  float cy, sy, cr, sr, cp, sp;
+  om_sincosf(yaw * 0.5f, &sy, &cy);
+  om_sincosf(roll * 0.5f, &sr, &cr);
+  om_sincosf(pitch * 0.5f, &sp, &cp);
   q[3] = cy * cr * cp + sy * sr * sp;
   q[0] = cy * sr * cp - sy * cr * sp;
   q[1] = cy * cr * sp + sy * sr * cp;
@@ -141,7 +143,7 @@ static void get_euler_xyz(const float q[4], float e[3]) {
   float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
   float sinr_cosp = 2.0f * (qw * qx + qy * qz);
   float cosr_cosp = qw * qw - qx * qx - qy * qy + qz * qz;
-  float roll = atan2f(sinr_cosp, cosr_cosp);
+  float roll = om_atan2f(sinr_cosp, cosr_cosp);
   float sinp = 2.0f * (qw * qy - qz * qx);
   float pitch;
   if (fabsf(sinp) >= 1.0f) {
@@ -149,11 +151,11 @@ static void get_euler_xyz(const float q[4], float e[3]) {
     float sg = (sinp > 0.0f) ? 1.0f : ((sinp < 0.0f) ? -1.0f : 0.0f);
     pitch = (ORC_PI_F / 2.0f) * sg;
   } else {
-    pitch = asinf(sinp);
+    pitch = om_asinf(sinp);
   }
   float siny_cosp = 2.0f * (qw * qz + qx * qy);
   float cosy_cosp = qw * qw + qx * qx - qy * qy - qz * qz;
-  float yaw = atan2f(siny_cosp, cosy_cosp);
+  float yaw = om_atan2f(siny_cosp, cosy_cosp);
   e[0] = py_mod(roll, ORC_2PI_F);
   e[1] = py_mod(pitch, ORC_2PI_F);
   e[2] = py_mod(yaw, ORC_2PI_F);
@@ -266,7 +268,9 @@ static void compute_body_torque(const OrcRobotParams *P, const float q[4], const
 static void desired_orientation_pos_vel(const float f[3], float yaw, float qd[4]) {
   float nf = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
   float b3[3] = {f[0] / nf, f[1] / nf, f[2] / nf};
-  float tmp[3] = {cosf(yaw), sinf(yaw), 0.0f};
+  float sy_, cy_;
+  om_sincosf(yaw, &sy_, &cy_);
+  float tmp[3] = {cy_, sy_, 0.0f};
   float b2[3], b1[3];
   cross3(b3, tmp, b2);
   float n2 = sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]);
@@ -281,15 +285,16 @@ static void desired_orientation_forces_yaw(const float f[3], float yaw, float qd
   float c_phi_s_theta = f[0];
   float s_phi = -f[1];
   float c_phi_c_theta = f[2];
-  float pitch = atan2f(c_phi_s_theta, c_phi_c_theta);
-  float roll = atan2f(s_phi, sqrtf(c_phi_c_theta * c_phi_c_theta + c_phi_s_theta * c_phi_s_theta));
+  float pitch = om_atan2f(c_phi_s_theta, c_phi_c_theta);
+  float roll = om_atan2f(s_phi, sqrtf(c_phi_c_theta * c_phi_c_theta + c_phi_s_theta * c_phi_s_theta));
   quat_from_euler_xyz(roll, pitch, yaw, qd);
 }
 
 /* base_lee_controller.py:201-215 with euler rates (0, 0, yaw_rate) */
 static void euler_rates_to_body_rates(const float euler[3], const float rates[3], float out[3]) {
-  float s_pitch = sinf(euler[1]), c_pitch = cosf(euler[1]);
-  float s_roll = sinf(euler[0]), c_roll = cosf(euler[0]);
+  float s_pitch, c_pitch, s_roll, c_roll;
+  om_sincosf(euler[1], &s_pitch, &c_pitch);
+  om_sincosf(euler[0], &s_roll, &c_roll);
   /* rows of the matrix; entries the reference leaves untouched only ever
      multiply the zero roll/pitch rates            */
   out[0] = 1.0f * rates[0] + 0.0f * rates[1] + (-s_pitch) * rates[2];
@@ -470,7 +475,8 @@ static void integrate_one(const OrcRobotParams *P, float *s, const float Fb[3], 
   if (wm2 != 0.0f) {
     float wm = sqrtf(wm2);
     float half = dt * wm * 0.5f;
-    float sn = sinf(half), cs = cosf(half);
+    float sn, cs;
+    om_sincosf(half, &sn, &cs);
     float sc = sn / wm;
     float qv[4] = {w_new[0] * sc, w_new[1] * sc, w_new[2] * sc, 0.0f};
     /* result = quatVel * q + q * cos ; Hamilton product written out */
@@ -615,7 +621,7 @@ void orc_reward_position(int n, const float *state, const float *qveh, const flo
     quat_conj(qveh + 4 * i, qi);
     quat_apply(qi, d, pe); /* quat_apply_inverse */
     float dist = sqrtf(pe[0] * pe[0] + pe[1] * pe[1] + pe[2] * pe[2]);
-    float pos_reward = 3.0f * expf(-8.0f * dist * dist) + 2.0f * expf(-4.0f * dist * dist);
+    float pos_reward = 3.0f * om_expf(-8.0f * dist * dist) + 2.0f * om_expf(-4.0f * dist * dist);
     float dist_reward = (20.0f - dist) / 40.0f;
     float ez[3] = {0.0f, 0.0f, 1.0f}, up[3];
     quat_rotate(q, ez, up); /* quat_axis(q, 2) */
@@ -650,8 +656,8 @@ void orc_obs_position(int n, const float *state, const float *vbody, const float
 /* rp: 17 reward parameters in the order of navigation_task_config.py  */
 /* pos_err / prev_pos_err [N,3] are in/out (prev <- cur, cur <- new)   */
 /* ------------------------------------------------------------------ */
-static float exp_reward(float mag, float ex, float v) { return mag * expf(-(v * v) * ex); }
-static float exp_penalty(float mag, float ex, float v) { return mag * (expf(-(v * v) * ex) - 1.0f); }
+static float exp_reward(float mag, float ex, float v) { return mag * om_expf(-(v * v) * ex); }
+static float exp_penalty(float mag, float ex, float v) { return mag * (om_expf(-(v * v) * ex) - 1.0f); }
 
 void orc_reward_navigation(int n, const float *state, const float *qveh, const float *target,
                            const float *action, const float *prev_action, int num_actions,
@@ -992,8 +998,8 @@ void orc_assets_integrate(int count, float *asset_state, const float *twist, flo
       float wm = sqrtf(wm2);
       float half = dt * wm * 0.5f;
       if (half > 60.0f) half = 60.0f;
-      float sn = sinf(half);
-      cs = cosf(half);
+      float sn;
+      om_sincosf(half, &sn, &cs);
       float sc = sn / wm;
       x1 = tw[3] * sc; y1 = tw[4] * sc; z1 = tw[5] * sc;
     }
@@ -1011,5 +1017,19 @@ void orc_assets_integrate(int count, float *asset_state, const float *twist, flo
       }
     }
     for (int c = 0; c < 6; ++c) st[7 + c] = tw[c];
+  }
+}
+
+/* test access to oracle_math.h (tests/test_oracle_math.py pins the kernels against libm in double):
+ * which = 0 sin, 1 cos, 2 atan2(x, y), 3 asin, 4 exp                                                  */
+void orc_math_eval(int which, int n, const float *x, const float *y, float *out) {
+  for (int i = 0; i < n; ++i) {
+    switch (which) {
+      case 0: out[i] = om_sinf(x[i]); break;
+      case 1: out[i] = om_cosf(x[i]); break;
+      case 2: out[i] = om_atan2f(x[i], y[i]); break;
+      case 3: out[i] = om_asinf(x[i]); break;
+      default: out[i] = om_expf(x[i]); break;
+    }
   }
 }

@@ -82,6 +82,14 @@ def max_abs(a, b):
     return float(np.abs(a - b).max()) if a.size else 0.0
 
 
+def elem_err(a, b):
+    """max over components of |a - b| / max(1, |b|): "fp32 within 1e-5" read element by element -- absolute for
+    magnitudes up to 1, relative above (a state component of 12 rad/s has an fp32 resolution of 1e-6 already).
+    Unlike `rel_err` nothing is blended across the array."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) if a.size else 0.0
+
+
 def max_rel(a, b, floor=0.0):
     """max over components of |a - b| / max(|b|, floor): for small-magnitude quantities (kT ~ 1e-5, thrusts)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
@@ -105,6 +113,8 @@ class ParityLog:
 
     def check(self, name, value, gate, unit="abs", ctx=None):
         self.record(name, value, gate, unit)
+        if os.environ.get("AGX_PARITY_SOFT") == "1":  # measurement runs (profiles/parity_variants.py): record everything
+            return
         assert value <= gate, (name, value, gate, ctx)
 
 
@@ -126,7 +136,7 @@ def pytest_terminal_summary(terminalreporter):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_report.json"), "w") as f:
+        with open(os.environ.get("AGX_PARITY_REPORT", os.path.join(out, "parity_report.json")), "w") as f:
             json.dump(PARITY.rows, f, indent=1, sort_keys=True)
     except OSError:
         pass

@@ -83,7 +83,7 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
         P = orc.make_params(env.robot_manager.robot.params_dict)
         pd = env.robot_manager.robot.params_dict
         ctrl = env.robot_manager.robot.controller
-        gains = [np.tile(((np.array(ctrl.gains_min) + np.array(ctrl.gains_max)) / 2)[3 * k:3 * k + 3].astype(np.float32), (n, 1))
+        gains = [np.tile(((np.array(ctrl.gains_max, np.float32) + np.array(ctrl.gains_min, np.float32)) / np.float32(2))[3 * k:3 * k + 3], (n, 1))
                  for k in range(4)]
         mm = env.robot_manager.robot.control_allocator.motor_model
         tri_local, tri_asset, tri_seg, half = npy(sc.tri_local), npy(sc.tri_asset), npy(sc.tri_seg), npy(sc.half_extents)
@@ -94,7 +94,10 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
         if sensor.is_lidar:
             rays = orc.lidar_ray_table(scfg.height, scfg.width, scfg.horizontal_fov_deg_min, scfg.horizontal_fov_deg_max,
                                        scfg.vertical_fov_deg_min, scfg.vertical_fov_deg_max)
-            assert np.array_equal(rays, npy(sensor.ray_vectors))
+            # torch's float64 cos / sin (product) and libm's (this table) may differ in the last bit of a few entries: the
+            # table itself is pinned to the reference's WarpLidar on the CPU (golden sensor_frontend); trace with the product's
+            assert np.abs(rays - npy(sensor.ray_vectors)).max() < 1.2e-7
+            rays = npy(sensor.ray_vectors)
         else:
             kinv, cx, cy = orc.camera_kinv(scfg.width, scfg.height, scfg.horizontal_fov_deg)
         frame = orc.quat_from_euler(np.deg2rad(np.array([scfg.euler_frame_rot_deg], np.float32)))[0]
@@ -106,7 +109,10 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
         assert A == (7 if "fully_actuated" in case else 4)
 
         def snapshot():
-            return dict(state=npy(g["robot_state_tensor"]), thrust=npy(mm.current_motor_thrust), kT=npy(mm.motor_thrust_constant),
+            per_env = getattr(ctrl, "_per_env_gains_bound", False)  # randomize_params: gains are re-drawn at every reset
+            return dict(gains=[npy(x) for x in (ctrl.K_pos_tensor_current, ctrl.K_linvel_tensor_current, ctrl.K_rot_tensor_current,
+                                                ctrl.K_angvel_tensor_current)] if per_env else gains,
+                        state=npy(g["robot_state_tensor"]), thrust=npy(mm.current_motor_thrust), kT=npy(mm.motor_thrust_constant),
                         tau_inc=npy(mm.motor_time_constants_increasing), tau_dec=npy(mm.motor_time_constants_decreasing),
                         asset=npy(sc.asset_state), target=npy(task.target_position), pos_err=npy(task.pos_error_vehicle_frame),
                         actions=npy(g["robot_actions"]), steps=npy(g["sim_steps"]), ep=npy(g["episode_count"]),
@@ -139,7 +145,7 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
                 if dcfg.enable_disturbance:  # apply_disturbance drawn in the kernel: stream RNG_DISTURB + sub-step
                     dist = orc.rng_fill(seed, np.full(n, step_no, np.int32), (1 << 20) + sub, 7)
                     dist[:, 0] = (dist[:, 0] < np.float32(dcfg.prob_apply_disturbance)).astype(np.float32)
-                o = orc.substep(P, st, a_tr.copy(), th, pre["kT"], pre["tau_inc"], pre["tau_dec"], *gains, disturb=dist, disturb_max=dmax)
+                o = orc.substep(P, st, a_tr.copy(), th, pre["kT"], pre["tau_inc"], pre["tau_dec"], *pre["gains"], disturb=dist, disturb_max=dmax)
                 orc.collide_sphere_boxes(pd["collision_radius"], st, boxes, crashes)
             pe, ppe = pre["pos_err"].copy(), np.zeros((n, 3), np.float32)
             r_ref = orc.reward_navigation(st, o.qveh, pre["target"], a_tr, a_tr, task.curriculum_progress_fraction, rp, pe, ppe, crashes)
@@ -148,11 +154,11 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             assert np.array_equal(npy(term), crashes.astype(bool)), t                     # crash flags: bit-exact
             assert np.array_equal(npy(trunc), trunc_ref), t
             assert np.array_equal(npy(g["reset_mask"]).astype(bool), reset_ref), t
-            parity.check(f"nav_task_reward[{case}]", max_rel(npy(rew), r_ref, 1.0), 2e-5, "rel(floor 1)", t)
+            parity.check(f"nav_task_reward[{case}]", max_abs(npy(rew), r_ref), 0.0, "abs (bit-exact)", t)
             keep = ~reset_ref
-            if keep.any():  # 10 fused free-running sub-steps: 10 x the per-step bound, absolute
-                parity.check(f"nav_task_state_10_substeps[{case}]", max_abs(post["state"][keep], st[keep]), 1e-4, "abs", t)
-                parity.check(f"nav_task_thrust_10_substeps[{case}]", max_rel(post["thrust"][keep], th[keep], 1e-2), 1e-4, "rel(floor 1e-2 N)", t)
+            if keep.any():  # 10 fused sub-steps (+ in-kernel disturbance draws): bit-exact
+                parity.check(f"nav_task_state_10_substeps[{case}]", max_abs(post["state"][keep], st[keep]), 0.0, "abs (bit-exact)", t)
+                parity.check(f"nav_task_thrust_10_substeps[{case}]", max_abs(post["thrust"][keep], th[keep]), 0.0, "abs (bit-exact)", t)
             n_resets += int(reset_ref.sum())
             n_crashes += int(crashes.sum())
             # ---------------- reset of the flagged envs (device Philox streams)
@@ -213,7 +219,7 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             u6 = orc.rng_fill(seed, np.full(n, env.step_counter - 1), 6, 6)  # RNG_OBS_NOISE of (env, this env step)
             obs_ref = orc.obs_navigation(post["state"], post["euler"], post["qveh"], post["vbody"], post["wbody"], post["actions"],
                                          post["target"], u6[:, 0:3], u6[:, 3:6], px_ref, cfg.observation_space_dim)
-            parity.check(f"nav_task_obs[{case}]", max_abs(npy(obs["observations"]), obs_ref), 1e-5, "abs", t)
+            parity.check(f"nav_task_obs[{case}]", max_abs(npy(obs["observations"]), obs_ref), 0.0, "abs (bit-exact)", t)
             if reset_ref.any():  # the reference refreshes EVERY env's derived tensors when any env resets
                 eu, qv, vv, vb, wb = orc.update_states(post["state"])
                 assert max_abs(post["vbody"], vb) < 1e-5 and max_abs(post["qveh"], qv) < 1e-5, t

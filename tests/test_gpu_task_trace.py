@@ -98,6 +98,78 @@ def test_task_api_reproduces_config1_trace(tag, controller):
         cfg.episode_len_steps = 500
 
 
+@pytest.mark.parametrize("tag,controller", [("position", "lee_position_control"), ("attitude", "lee_attitude_control"),
+                                            ("position_long", "lee_position_control")])
+def test_task_api_trace_is_bit_identical_to_the_oracle_loop(orc, tag, controller):
+    """The same traces, GPU Task API vs the CPU oracle's env loop (tests/oracle_env.py) fed the same actions and
+    reset draws: state, reward, observation and flags are BIT-IDENTICAL at every one of the 260 / 160 / 1000
+    free-running steps (the kernels evaluate the oracle's IEEE operation sequence; DESIGN.md "numerics").  Whatever
+    distance the trace keeps from the reference's torch arithmetic is therefore the oracle's, measured on the CPU
+    (tests/test_oracle_vs_reference.py::test_trace_config1)."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from conftest import TraceReader, golden_params
+    from oracle_env import OraclePositionEnv
+    from trace_util import TRACES
+
+    g = load_golden(TRACES[tag][0])
+    tr = TraceReader(g)
+    n = g["init_state"].shape[0]
+    rs = ReplaySource(DEV)
+    zeros3 = np.zeros((n, 3), np.float32)
+    for t in ("motor_init_thrust", "motor_init_tau_inc", "motor_init_tau_dec", "motor_init_kT"):
+        rs.push(t, np.zeros((n, 4), np.float32))
+
+    def push_reset(us, ti, td, th, kt):
+        for name, arr in (("bounds_lo", zeros3), ("bounds_hi", zeros3), ("robot_state", us), ("tau_inc", ti), ("tau_dec", td),
+                          ("thrust", th), ("kT", kt)):
+            rs.push(name, arr)
+
+    init = (g["init_u_state"], g["init_u_tau_inc"], g["init_u_tau_dec"], g["init_u_thrust"], g["init_u_kT"])
+    push_reset(*init)
+    cfg.device, cfg.controller_name = DEV, controller
+    cfg.episode_len_steps = int(g["episode_len"])
+    cfg.args = {"strict_rng": True, "random_source": rs}
+    task = task_registry.make_task("position_setpoint_task", seed=1, num_envs=n, headless=True)
+    ranges = dict(tau_inc=(0.04, 0.04), tau_dec=(0.04, 0.04), thrust=(0.0, 2.0), kT=(0.00000926312, 0.00001826312))
+    # the oracle runs on the PRODUCT's constants (its allocation pseudo-inverse is evaluated in float64; the goldens
+    # carry the reference's fp32 torch.linalg.pinv of the build container: same to 1e-6, not to the bit)
+    pd = dict(task.sim_env.robot_manager.robot.params_dict)
+    pd["controller"] = golden_params(g)["controller"]
+    env = OraclePositionEnv(pd, n, int(g["episode_len"]), (g["Kp"], g["Kv"], g["KR"], g["Kw"]),
+                            g["min_init_state"], g["max_init_state"], ranges)
+    try:
+        task.reset()
+        env.reset_masked(np.ones(n, np.uint8), *init)
+        gd = task.obs_dict
+        mm = task.sim_env.robot_manager.robot.control_allocator.motor_model
+        assert np.array_equal(gd["robot_state_tensor"].cpu().numpy(), env.state), "initial reset"
+        assert np.array_equal(mm.current_motor_thrust.cpu().numpy(), env.thrust)
+        assert np.array_equal(mm.motor_thrust_constant.cpu().numpy(), env.kT)
+        n_resets = 0
+        for t in range(tr.T):
+            draws = tr.draws(t)
+            if draws is not None:
+                push_reset(*draws)
+            obs, rew, term, trunc, info = task.step(torch.from_numpy(np.ascontiguousarray(tr.action(t))).to(DEV))
+            o_obs, o_rew, o_crash, o_trunc, o_mask, _ = env.step(tr.action(t), draws)
+            n_resets += int(o_mask.sum())
+            for name, got, ref in (("state", gd["robot_state_tensor"], env.state), ("thrust", mm.current_motor_thrust, env.thrust),
+                                   ("reward", rew, o_rew), ("obs", obs["observations"], o_obs),
+                                   ("body angvel", gd["robot_body_angvel"], env.wbody), ("euler", gd["robot_euler_angles"], env.euler)):
+                got = got.cpu().numpy()
+                if not np.array_equal(got, ref):
+                    bad = np.argwhere(got != ref)
+                    raise AssertionError(f"step {t}: {name} differs in {len(bad)} entries, first {bad[0]}: "
+                                         f"{got[tuple(bad[0])]!r} vs {ref[tuple(bad[0])]!r}; max abs {np.abs(got - ref).max():.3e}")
+            assert np.array_equal(term.cpu().numpy(), o_crash.astype(bool)) and np.array_equal(trunc.cpu().numpy(), o_trunc.astype(bool)), t
+        assert n_resets >= n  # resets were part of the comparison
+    finally:
+        cfg.args = {}
+        cfg.episode_len_steps = 500
+
+
 def test_sync_free_mode_runs_and_resets():
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
