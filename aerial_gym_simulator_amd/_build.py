@@ -23,6 +23,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-comment"]
 
 
+def source_hash():
+    """sha256 over the kernel sources, the C header and the compile flags: identifies the code a counter file under
+    profiles/ was measured on (bench.py marks `traffic` stale when it differs)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    for path in files + [os.path.join(INCLUDE, "aerial_gym_hip.h")]:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -142,16 +142,102 @@ def hbm_copy_gbs(device, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (start.elapsed_time(stop) * 1e-3) / 1e9
 
 
+_PMC = None
+
+
+def _pmc():
+    """The committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by profiles/collect_pmc.py): HBM bytes and
+    vector instructions per launch.  Counters cannot be collected inside a timed run, so they are read from the file --
+    together with the hash of the kernel sources they were measured on: when the sources changed since, every number taken
+    from the file is reported with "stale": true instead of silently."""
+    global _PMC
+    if _PMC is None:
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            _PMC = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            _PMC = {}
+        from aerial_gym_simulator_amd import _build
+
+        _PMC["_stale"] = _PMC.get("source_hash") != _build.source_hash()
+    return _PMC
+
+
 def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>_pmc_traffic.json, written by profiles/collect_pmc.py); None if absent."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    return _pmc().get(tag)
+
+
+def pmc_stale():
+    return bool(_pmc().get("_stale", True))
+
+
+def valu_peak():
+    """Plain (non-packed) fp32 VALU issue ceiling in wave64 instructions/s: measured on an MI355X by
+    profiles/src/valu_peak.hip (profiles/r02_valu_peak.json); fallback = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles."""
     try:
-        return json.load(open(path)).get(tag)
+        return float(json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))["wave_instr_per_s"]), "measured (profiles/r02_valu_peak.json)"
+    except Exception:  # noqa: BLE001
+        return 256 * 4 * 2.4e9 / 4.0, "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"
+
+
+def valu_roofline(kernel_key, launch_s):
+    """`bound: "valu"`: vector instructions the kernel issues per launch (SQ_INSTS_VALU, committed PMC pass) over the
+    launch duration measured live, against the VALU issue ceiling."""
+    n_valu = _pmc().get("valu_wave_instructions", {}).get(kernel_key)
+    if n_valu is None:
+        return None
+    peak, how = valu_peak()
+    ach = n_valu / launch_s
+    return {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave64-instr/s", "frac": ach / peak,
+            "valu_wave_instructions_per_launch": n_valu, "peak_source": how, "stale": pmc_stale()}
+
+
+def raycast_grid_threads(task):
+    """grid size (threads) of the frame's k_raycast launch: the key of its counters in the PMC file"""
+    cfg = task.sim_env.robot_manager.warp_sensor.cfg
+    n, ns = task.num_envs, cfg.num_sensors
+    tiles = ((cfg.width + 7) // 8) * ((cfg.height + 7) // 8)
+    split = max(1, min((16384 + n * ns * 4 - 1) // (n * ns * 4), (tiles + 3) // 4))
+    return n * ns * split * 256
+
+
+def cpu_baseline_reference():
+    """The reference's own torch CPU path (oracle/time_reference_cpu.py), timed where the reference tree exists."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_reference.json")))
+        return {k: d[k] for k in ("value", "unit", "cores", "kind", "sample", "host", "cpu_model", "what")}
     except Exception:  # noqa: BLE001
         return None
+
+
+def live_parity(device):
+    """One golden case through the C ABI right here, next to the timing: base_quadrotor + lee_position_control, the
+    reference's recorded inputs -> its recorded outputs (tests/golden/step_quad_position.npz, 6 sub-steps x 64 envs).
+    No CPU code is involved: the comparison is GPU vs the reference's own numbers."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from conftest import elem_err, golden_params, load_golden, max_abs
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_quad_position")
+    pd = golden_params(g)
+    n, K = g["state"].shape[1], g["state"].shape[0]
+    H = DynHarness(pd, n, dev=device)
+    H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"])
+    H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+    out = {"state_next": 0.0, "wrench": 0.0, "thrust_over_full_scale": 0.0, "body_rates": 0.0}
+    for k in range(K):
+        H.set(state=g["state"][k], thrust=g["thrust_in"][k])
+        H.substeps(g["action"][k], 1)
+        if k + 1 < K:
+            out["state_next"] = max(out["state_next"], elem_err(H.get("state"), g["state"][k + 1]))
+        out["wrench"] = max(out["wrench"], elem_err(H.get("wrench"), g["wrench_cmd"][k]))
+        out["thrust_over_full_scale"] = max(out["thrust_over_full_scale"], max_abs(H.get("thrust"), g["thrust_out"][k]) / pd["max_thrust"])
+        out["body_rates"] = max(out["body_rates"], elem_err(H.get("derived")[:, 10:16], np.concatenate([g["vbody"][k], g["wbody"][k]], axis=1)))
+    return {"case": "tests/golden/step_quad_position.npz (reference BaseMultirotor.step outputs, 6 sub-steps x 64 envs)",
+            "max_err_vs_reference": out, "unit": "|err| / max(1, |x|) per component (thrust: / 2 N full scale)",
+            "gates": "tests/ (pytest -m gpu): bit-exact vs the CPU oracle, <= 1e-5 (angvel 3e-5) vs the reference; "
+                     "measured maxima of the last full run: profiles/r02_parity_report.json"}
 
 
 def kernel_time_dynamics(task, actions, reps=400):
@@ -464,19 +550,18 @@ def main():
     if rank == 0 and args.workload == "dynamics":
         kt, k = kernel_time_dynamics(task, actions)
         achieved = BYTES_DYNAMICS_KERNEL * k * N / kt / 1e9
-        out["roofline"] = {
-            "bound": "hbm",
+        vr = valu_roofline("k_env_step_%d" % N, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9,
+                                                          "unit": "G wave64-instr/s", "frac": None}
+        out["roofline"] = dict(vr, **{
             "kernel": "k_env_step<4, position> (k sub-steps + reward epilogue)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("k_env_step_8192"),
             "launch_us": kt * 1e6,
-            "peak_measured_copy": hbm_copy_gbs(device),
-            "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N,
-            "note": "8192 envs move 1.2 MB per launch: launch-latency bound, see roofline_at_scale for the same kernel at 2^21 envs",
-        }
+            "traffic": pmc_traffic("k_env_step_%d" % N),
+            "traffic_stale": pmc_stale(),
+            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N, "peak_measured_copy": hbm_copy_gbs(device)},
+            "note": "8192 envs = 128 one-wave workgroups on 256 CUs (1 wave on 1 of every 8 SIMDs), 1.3 MB per launch: neither the vector "
+                    "ALUs nor HBM can be filled, the launch is latency bound; roofline_at_scale prices the same kernel at 2^21 envs",
+        })
     if exchange is not None:
         out["exchange"] = exchange
     if rank == 0 and args.workload != "dynamics":
@@ -484,12 +569,15 @@ def main():
         per_env = raycast_bytes_per_env(task)
         achieved = per_env * N / kt / 1e9
         cfgs = task.sim_env.robot_manager.warp_sensor.cfg
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_raycast (one frame, all envs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_raycast_%s_%d" % (args.workload, N)), "launch_us": kt * 1e6,
-            "algorithmic_bytes_per_launch": per_env * N, "rays_per_s": N * cfgs.num_sensors * cfgs.height * cfgs.width / kt,
-            "note": "ray traversal is latency / VALU bound, not HBM bound: the scene (127 KB/env) is read once per frame",
-        }
+        key = "k_raycast_%d" % raycast_grid_threads(task)
+        vr = valu_roofline(key, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9, "unit": "G wave64-instr/s", "frac": None}
+        out["roofline"] = dict(vr, **{
+            "kernel": "k_raycast (one frame, all envs)", "launch_us": kt * 1e6, "traffic": pmc_traffic(key), "traffic_stale": pmc_stale(),
+            "rays_per_s": N * cfgs.num_sensors * cfgs.height * cfgs.width / kt,
+            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": per_env * N},
+            "note": "packet traversal is bound by vector-instruction issue, not by HBM: the scene (127 KB/env) is read once per frame",
+        })
     if rank == 0 and args.workload == "dynamics" and world == 1:
         # same kernel where the roofline is meaningful (N = 2^21 envs, 319 MB per launch)
         try:
@@ -501,16 +589,30 @@ def main():
                 big.step(ab[0])
             kt2, k2 = kernel_time_dynamics(big, ab, reps=30)
             ach2 = BYTES_DYNAMICS_KERNEL * k2 * (1 << 21) / kt2 / 1e9
-            out["roofline_at_scale"] = {"num_envs": 1 << 21, "bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": ach2 / HBM_PEAK_GBS, "launch_us": kt2 * 1e6,
-                                        "env_steps_per_s_kernel_only": (1 << 21) / kt2,
-                                        "note": "instruction-issue / latency bound here, not HBM bound: 1766 VALU instructions per wave (SQ_INSTS_VALU) "
-                                                "x 4 cycles x 32 waves per SIMD = 94 us of vector issue at 2.4 GHz (DESIGN.md 3.1)"}
+            vr2 = valu_roofline("k_env_step_%d" % (1 << 21), kt2) or {"bound": "valu", "frac": None}
+            out["roofline_at_scale"] = dict(vr2, **{
+                "num_envs": 1 << 21, "launch_us": kt2 * 1e6, "env_steps_per_s_kernel_only": (1 << 21) / kt2,
+                "traffic": pmc_traffic("k_env_step_%d" % (1 << 21)), "traffic_stale": pmc_stale(),
+                "hbm": {"achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k2 * (1 << 21)},
+                "note": "the larger of the two fractions names the bound: vector issue (3 waves per SIMD cannot hide all latency), not HBM"})
             del big
         except Exception as e:  # noqa: BLE001
             out["roofline_at_scale"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
         out["cpu_baseline"] = cpu_baseline_dynamics(N)
+        ref = cpu_baseline_reference()
+        if ref is not None:
+            out["cpu_baseline_reference"] = ref
+    if rank == 0 and world == 1 and args.workload == "dynamics":
+        try:
+            out["parity"] = live_parity(device)
+        except Exception as e:  # noqa: BLE001
+            out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        from aerial_gym_simulator_amd import _build as _b
+
+        out["source_hash"] = _b.source_hash()
     if not args.no_depth and args.workload == "dynamics":
         # the "+depth sensor" half of the metric: BASELINE configs[2] on every GPU (= configs[4] when N > 1:
         # 8192 envs per rank + the per-step all-gather); fewer steps: ~2.5 ms each
@@ -535,9 +637,10 @@ def main():
             per_env = raycast_bytes_per_env(t2)
             out["plus_depth"].update({
                 "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                "raycast_roofline": {"bound": "hbm", "achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N,
-                                     "traffic": pmc_traffic("k_raycast_depth_%d" % N)}})
+                "raycast_roofline": dict(valu_roofline("k_raycast_%d" % raycast_grid_threads(t2), kt2) or {"bound": "valu", "frac": None}, **{
+                    "traffic": pmc_traffic("k_raycast_%d" % raycast_grid_threads(t2)), "traffic_stale": pmc_stale(),
+                    "hbm": {"achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N}})})
             if not args.no_cpu_baseline:
                 out["plus_depth"]["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
                 out["plus_depth"]["gpu_frames_per_s_kernel"] = N / kt2

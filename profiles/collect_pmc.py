@@ -31,11 +31,21 @@ def load(path, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def main(fetch_csv, write_csv):
+def main(fetch_csv, write_csv, sq_csv=None):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aerial_gym_simulator_amd import _build
+
     fetch, nf = load(fetch_csv, "FETCH_SIZE")
     write, nw = load(write_csv, "WRITE_SIZE")
     KB = 1024.0
-    out = {"unit": "bytes per launch", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), counters in KiB"}
+    out = {"unit": "bytes per launch", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), counters in KiB",
+           "source_hash": _build.source_hash()}
+    if sq_csv:  # third pass: vector instructions issued per launch (wave64 instructions), for the VALU-issue roofline
+        valu, nv = load(sq_csv, "SQ_INSTS_VALU")
+        waves, _ = load(sq_csv, "SQ_WAVES")
+        out["valu_wave_instructions"] = {"%s_%d" % k: v for k, v in valu.items()}
+        out["waves"] = {"%s_%d" % k: v for k, v in waves.items()}
+        out["valu_source"] = "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (own pass), average over %s launches" % sorted(set(nv.values()))
     n_cal = 1 << 21
     cal = ("k_update_states", n_cal)
     if cal in fetch and cal in write:
@@ -55,7 +65,7 @@ def main(fetch_csv, write_csv):
                                     "launches_averaged": [nf[(name, grid)], nw[(name, grid)]]}
     for (name, grid), v in fetch.items():
         if name == "k_raycast" and (name, grid) in write:
-            tag = "k_raycast_depth_%d" % (grid // 256)  # 256 threads per (env, sensor) workgroup
+            tag = "k_raycast_%d" % grid  # grid size in threads = envs x sensors x 256 (x tile split)
             # node / triangle reads are scalar (wave-uniform) loads: the coalesced-dword calibration does not
             # apply to them; report the raw counters and the FETCH x2 reading of the MI355X guide
             out[tag] = 2.0 * v * KB + write[(name, grid)] * KB
@@ -67,4 +77,4 @@ def main(fetch_csv, write_csv):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

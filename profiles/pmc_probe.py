@@ -34,4 +34,11 @@ if "--nav" in sys.argv:
     for _ in range(3):
         t.step(a)
     torch.cuda.synchronize()
+    del t
+    t = bench.make_task("lidar", 4096, dev, False)  # BASELINE configs[3]
+    t.reset()
+    a = torch.rand(4096, 4, device=dev) * 2 - 1
+    for _ in range(3):
+        t.step(a)
+    torch.cuda.synchronize()
 print("pmc probe done")
