@@ -788,6 +788,14 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
 // Reset.  Uniform draws come either from tensors (host RNG, reference-faithful stream) or
 // from Philox4x32-10 evaluated in place (sync-free mode).
 // ---------------------------------------------------------------------------------------
+AGX_DEV void bounds_from_draws(const AgxResetArgs &R, const float ub[6], float bmin[3], float bmax[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float ulo = ub[c], uhi = ub[3 + c];
+    bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
+    bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
+  }
+}
 AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin[3], float bmax[3]) {
   float ub[6];
   if (R.u_state) {
@@ -799,68 +807,126 @@ AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin
   } else {
     rng_fill<6>(R.seed, i, episode, RNG_BOUNDS, ub);
   }
+  bounds_from_draws(R, ub, bmin, bmax);
+}
+
+// The uniform draws one env's reset consumes: env bounds (6), robot state (13), controller gains (12), and per motor
+// (tau_inc, tau_dec, thrust, kT).
+template <int M>
+struct ResetDraws {
+  float ub[6], us[13], ug[12], um[M][4];
+};
+
+// strict mode: the tensors torch drew (AoS, the reference's order)
+template <int M>
+AGX_DEV void host_reset_draws(const AgxRobotParams &P, const AgxResetArgs &R, int i, ResetDraws<M> &D) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float ulo = ub[c], uhi = ub[3 + c];
-    bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
-    bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
+    D.ub[c] = R.u_bounds_lo[(size_t)i * 3 + c];
+    D.ub[3 + c] = R.u_bounds_hi[(size_t)i * 3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 13; ++c) D.us[c] = R.u_state[(size_t)i * 13 + c];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) D.ug[c] = R.randomize_gains ? R.u_gains[(size_t)i * 12 + c] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    size_t k = (size_t)i * M + j;
+    D.um[j][0] = R.u_tau_inc[k];
+    D.um[j][1] = R.u_tau_dec[k];
+    D.um[j][2] = R.u_thrust[k];
+    D.um[j][3] = P.use_rps ? R.u_kT[k] : 0.0f;
   }
 }
 
-// returns the (possibly new) state of env i; `with_flag`: the caller already checked the flag
+// sync-free mode: the Philox blocks of a resetting env are evaluated by the WAVE, one block per lane (2 bounds + 4 state
+// + 3 gains + M motor blocks of 4 draws), and handed to the env's own lane with v_readlane: a lane on its own would run
+// the 9 + M blocks (10 rounds each) back to back, and with a few of 8192 envs resetting on almost every step that
+// serial chain was the longest path of the reset / observation kernel.  Same (seed; env, episode, stream, block)
+// coordinates, hence the same draws as rng_fill / rng_block in any other arrangement.  Must be called by all 64 lanes.
 template <int M>
-AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int n, const AgxResetArgs &R, int i) {
+AGX_DEV void wave_reset_draws(const AgxResetArgs &R, int i, int ep, bool mine, ResetDraws<M> &D) {
+  constexpr int NB = 9 + M;
+  const int lane = threadIdx.x & 63;
+  int stream = RNG_MOTOR, blk = lane - 9;
+  if (lane < 2) { stream = RNG_BOUNDS; blk = lane; }
+  else if (lane < 6) { stream = RNG_STATE; blk = lane - 2; }
+  else if (lane < 9) { stream = RNG_GAINS; blk = lane - 6; }
+  unsigned long long todo = __ballot(mine);
+  if (__popcll(todo) > 8) {  // a full reset (task.reset(), short episodes): every lane for itself is the shorter path
+    if (mine) {
+      rng_fill<6>(R.seed, i, ep, RNG_BOUNDS, D.ub);
+      rng_fill<13>(R.seed, i, ep, RNG_STATE, D.us);
+      if (R.randomize_gains) rng_fill<12>(R.seed, i, ep, RNG_GAINS, D.ug);
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        F4 um = rng_block(R.seed, i, ep, RNG_MOTOR, j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) D.um[j][k] = um.v[k];
+      }
+    }
+    return;
+  }
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int iL = __builtin_amdgcn_readlane(i, L), epL = __builtin_amdgcn_readlane(ep, L);
+    F4 f{};
+    if (lane < NB) f = rng_block(R.seed, iL, epL, stream, blk);
+    const bool me = lane == L;
+#define AGX_TAKE(dst, b, k)                                                                   \
+  {                                                                                            \
+    float v_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.v[k]), (b)));          \
+    dst = me ? v_ : dst;                                                                       \
+  }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) AGX_TAKE(D.ub[c], c / 4, c % 4)
+#pragma unroll
+    for (int c = 0; c < 13; ++c) AGX_TAKE(D.us[c], 2 + c / 4, c % 4)
+    if (R.randomize_gains) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) AGX_TAKE(D.ug[c], 6 + c / 4, c % 4)
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) AGX_TAKE(D.um[j][k], 9 + j, k)
+    }
+#undef AGX_TAKE
+  }
+}
+
+// BaseMultirotor.reset_idx / MotorModel.reset_idx / IsaacGymEnv.reset_idx of ONE env from its draws; returns the new state
+template <int M>
+AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int n, const AgxResetArgs &R, int i, int ep,
+                           const ResetDraws<M> &D) {
   EnvState s;
-  if (B.reset_mask[i] == 0) return load_state(B.state, n, i);
-  const int ep = B.episode_count ? B.episode_count[i] : 0;
   // IsaacGymEnv.reset_idx: env bounds first, the robot spawn uses them
   float bmin[3], bmax[3];
-  sample_bounds(R, i, ep, bmin, bmax);
+  bounds_from_draws(R, D.ub, bmin, bmax);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     AGX_AT(B.bounds_min, c) = bmin[c];
     AGX_AT(B.bounds_max, c) = bmax[c];
   }
-  float r[13], us[13];
-  if (R.u_state) {
+  float r[13];
 #pragma unroll
-    for (int c = 0; c < 13; ++c) us[c] = R.u_state[(size_t)i * 13 + c];
-  } else {
-    rng_fill<13>(R.seed, i, ep, RNG_STATE, us);
-  }
-#pragma unroll
-  for (int c = 0; c < 13; ++c) r[c] = (R.max_state[c] - R.min_state[c]) * us[c] + R.min_state[c];
+  for (int c = 0; c < 13; ++c) r[c] = (R.max_state[c] - R.min_state[c]) * D.us[c] + R.min_state[c];
   s.p = V3{bmin[0] + (bmax[0] - bmin[0]) * r[0], bmin[1] + (bmax[1] - bmin[1]) * r[1], bmin[2] + (bmax[2] - bmin[2]) * r[2]};
   s.q = quat_from_euler(r[3], r[4], r[5]);
   s.v = V3{r[7], r[8], r[9]};
   s.w = V3{r[10], r[11], r[12]};
   store_state(B.state, n, i, s);
   if (R.randomize_gains) {
-    float ug[12];
-    if (R.u_state) {
 #pragma unroll
-      for (int c = 0; c < 12; ++c) ug[c] = R.u_gains[(size_t)i * 12 + c];
-    } else {
-      rng_fill<12>(R.seed, i, ep, RNG_GAINS, ug);
-    }
-#pragma unroll
-    for (int c = 0; c < 12; ++c) AGX_AT(B.gains, c) = (R.gains_max[c] - R.gains_min[c]) * ug[c] + R.gains_min[c];
+    for (int c = 0; c < 12; ++c) AGX_AT(B.gains, c) = (R.gains_max[c] - R.gains_min[c]) * D.ug[c] + R.gains_min[c];
   }
 #pragma unroll
   for (int j = 0; j < M; ++j) {
-    size_t k = (size_t)i * M + j;
-    F4 um{};
-    if (!R.u_state) um = rng_block(R.seed, i, ep, RNG_MOTOR, j);  // (tau_inc, tau_dec, thrust, kT) of motor j
-    float u0 = R.u_state ? R.u_tau_inc[k] : um.v[0];
-    float u1 = R.u_state ? R.u_tau_dec[k] : um.v[1];
-    float u2 = R.u_state ? R.u_thrust[k] : um.v[2];
-    if (B.motor_tau_inc) AGX_AT(B.motor_tau_inc, j) = (R.tau_inc_max - R.tau_inc_min) * u0 + R.tau_inc_min;
-    if (B.motor_tau_dec) AGX_AT(B.motor_tau_dec, j) = (R.tau_dec_max - R.tau_dec_min) * u1 + R.tau_dec_min;
-    AGX_AT(B.motor_thrust, j) = (P.max_thrust - P.min_thrust) * u2 + P.min_thrust;
-    if (P.use_rps) {
-      float u3 = R.u_state ? R.u_kT[k] : um.v[3];
-      AGX_AT(B.motor_kT, j) = (R.kT_max - R.kT_min) * u3 + R.kT_min;
-    }
+    if (B.motor_tau_inc) AGX_AT(B.motor_tau_inc, j) = (R.tau_inc_max - R.tau_inc_min) * D.um[j][0] + R.tau_inc_min;
+    if (B.motor_tau_dec) AGX_AT(B.motor_tau_dec, j) = (R.tau_dec_max - R.tau_dec_min) * D.um[j][1] + R.tau_dec_min;
+    AGX_AT(B.motor_thrust, j) = (P.max_thrust - P.min_thrust) * D.um[j][2] + P.min_thrust;
+    if (P.use_rps) AGX_AT(B.motor_kT, j) = (R.kT_max - R.kT_min) * D.um[j][3] + R.kT_min;
   }
   B.sim_steps[i] = 0;
   if (B.episode_count) B.episode_count[i] = ep + 1;
@@ -874,11 +940,20 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
                                                       const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
-  if (i < n) {
-    if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
-      if (WITH_OBS) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  const bool valid = i < n;
+  if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
+    if (WITH_OBS && valid) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  } else {  // (the flag is one word: the branch is taken by whole waves)
+    const bool mine = valid && B.reset_mask[i] != 0;
+    const int ep = (mine && B.episode_count) ? B.episode_count[i] : 0;
+    ResetDraws<M> D{};
+    if (R.u_state) {
+      if (mine) host_reset_draws<M>(P, R, i, D);
     } else {
-      EnvState s = reset_env<M>(P, B, n, R, i);
+      wave_reset_draws<M>(R, i, ep, mine, D);
+    }
+    if (valid) {
+      EnvState s = mine ? reset_env<M>(P, B, n, R, i, ep, D) : load_state(B.state, n, i);
       // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
       Derived d = update_states(s);
       store_derived(B.derived, n, i, d);
