@@ -175,7 +175,7 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 5  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 6  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -207,6 +207,7 @@ _SIGNATURES = {
     "agx_exchange_probe": (C.c_int, [_P, _P]),
     "agx_exchange_wait": (C.c_int, [_P, C.c_int, _P]),
     "agx_exchange_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_uint32, C.c_int, _P]),
+    "agx_exchange_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "agx_exchange_destroy": (C.c_int, [_P]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),

@@ -45,6 +45,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 // one binding per process (the path of the first call wins; later calls must agree or pass NULL)
@@ -67,6 +69,8 @@ int bind_rccl(const char *path, Rccl **out) {
     AGX_BIND(CommDestroy, "ncclCommDestroy")
     AGX_BIND(AllGather, "ncclAllGather")
     AGX_BIND(GetErrorString, "ncclGetErrorString")
+    AGX_BIND(CommCount, "ncclCommCount")
+    AGX_BIND(CommUserRank, "ncclCommUserRank")
 #undef AGX_BIND
     r.handle = h;
   }
@@ -318,6 +322,14 @@ extern "C" int agx_exchange_step(AgxExchange *x, int parity, const float *send, 
                                  const uint32_t *signal, uint32_t seq, int wait_parity, void *stream) {
   if (int e = agx_exchange_post(x, parity, send, recv, count_per_rank, signal, seq, stream)) return e;
   if (wait_parity == 0 || wait_parity == 1) return agx_exchange_wait(x, wait_parity, stream);
+  return AGX_OK;
+}
+
+extern "C" int agx_exchange_info(AgxExchange *x, int *rank, int *world) {
+  AGX_REQUIRE(x && rank && world, "agx_exchange_info: null argument");
+  ncclResult_t a = x->rccl->CommUserRank(x->comm, rank), b = x->rccl->CommCount(x->comm, world);
+  if (a != ncclSuccess || b != ncclSuccess)
+    return agx::fail(AGX_E_LAUNCH, "ncclCommUserRank / ncclCommCount: %s", x->rccl->GetErrorString(a != ncclSuccess ? a : b));
   return AGX_OK;
 }
 

@@ -14,7 +14,7 @@ latency bound on a fully connected xGMI node -- hence
     communicator of its own (csrc/agx_exchange.hip, `backend="rccl_thread"`): the stepping thread
     pays one event record + one stream wait per step.  Going through torch's process group
     (`backend="process_group"`, the only choice on CPU/gloo) costs 27 us of host time per step --
-    more than the 18 us dynamics-only step itself (profiles/r01_exchange_world1.json).
+    more than the 18 us dynamics-only step itself (profiles/r01_exchange_probe.txt).
 """
 import ctypes as C
 import os
@@ -24,7 +24,12 @@ import torch.distributed as dist
 
 
 def rccl_library_path():
-    """The librccl.so this process already uses (torch bundles its own); None = loader default."""
+    """The librccl.so this process already uses (torch bundles its own); None = loader default.
+    AGX_RCCL_PATH overrides it (the world-size-2 tests on a one-GPU box bind a test double: RCCL refuses two ranks
+    on one device)."""
+    override = os.environ.get("AGX_RCCL_PATH")
+    if override:
+        return override
     cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     return cand if os.path.exists(cand) else None
 
@@ -83,7 +88,7 @@ class StepGather:
         if backend == "rccl_thread" and not (self.collective and self.device.type == "cuda"):
             raise RuntimeError("backend='rccl_thread' needs an initialised process group and a HIP device")
         if self.collective and self.device.type == "cuda" and backend != "process_group" and (
-                backend == "rccl_thread" or "nccl" in str(dist.get_backend(group))):
+                backend == "rccl_thread" or "nccl" in str(dist.get_backend(group))):  # "auto" never picks it over gloo
             self._native = self._create_native(required=backend == "rccl_thread")
         self.backend = "rccl_thread" if self._native is not None else ("process_group" if self.collective else "none")
         if env is not None:
@@ -109,15 +114,18 @@ class StepGather:
         # BEFORE ncclCommInitRank, which blocks until all ranks have joined
         rc = lib.agx_exchange_unique_id(cpath, uid, 128)
         err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
-        ok = torch.tensor([1 if rc == 0 else 0], device=self.device, dtype=torch.int32)
+        # control traffic (one flag, the 128 id bytes) travels on whatever the process group runs on
+        ctl = self.device if "nccl" in str(dist.get_backend(self.group)) else torch.device("cpu")
+        ok = torch.tensor([1 if rc == 0 else 0], device=ctl, dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) == 0:
             if required:
                 raise RuntimeError(f"rccl_thread exchange unavailable on some rank ({err or 'see the other ranks'})")
             return None
-        idt = torch.tensor(list(uid.raw), dtype=torch.uint8, device=self.device)
+        idt = torch.tensor(list(uid.raw), dtype=torch.uint8, device=ctl)
         dist.broadcast(idt, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-        torch.cuda.synchronize(self.device)
+        if ctl.type == "cuda":
+            torch.cuda.synchronize(self.device)
         raw = bytes(idt.cpu().tolist())
         handle = C.c_void_p()
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -127,6 +135,19 @@ class StepGather:
         self._count = self.n * (self.obs_dim + 3)
         self._ptr = [(self.rows[p].data_ptr(), self.gathered[p].data_ptr()) for p in (0, 1)]  # tensor indexing costs microseconds
         return handle
+
+    def comm_info(self):
+        """(rank, world size) as the exchange's communicator reports them (ncclCommUserRank / ncclCommCount) for
+        `rccl_thread`, the process group's for `process_group`, (0, 1) without a collective."""
+        if self._native is not None:
+            from . import _lib
+
+            r, w = C.c_int(-1), C.c_int(-1)
+            _lib.check(self._lib.agx_exchange_info(self._native, C.byref(r), C.byref(w)), "agx_exchange_info")
+            return r.value, w.value
+        if self.collective:
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
 
     def close(self):
         """Drains and frees the library-side communicator (collective-free, but call it on every rank)."""

@@ -369,6 +369,9 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
         res["backend"] = gb.backend
         if gb.backend != "rccl_thread":
             raise RuntimeError("the library-side exchange could not be set up on every rank")
+        res["communicator"] = dict(zip(("rank", "ranks"), gb.comm_info()))  # as ncclCommUserRank / ncclCommCount report them
+        if res["communicator"]["ranks"] != max(world, 1):
+            raise RuntimeError(f"the exchange communicator spans {res['communicator']['ranks']} ranks, the job has {world}")
         if os.environ.get("AGX_BENCH_INJECT_EXCHANGE_FAILURE") == str(rank):  # exercises the abandon path below
             raise RuntimeError("injected failure")
         dt = timed_steps(task, actions, args.steps, args.warmup, world, gb, overlap=not args.sync_gather)
@@ -517,6 +520,10 @@ def main():
     if use_dist:
         gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards,
                                 backend=primary_backend)
+    if gather_buf is not None:
+        comm_rank, comm_ranks = gather_buf.comm_info()
+        if comm_ranks != max(world, 1) or comm_rank != rank:
+            raise SystemExit(f"the step exchange's communicator reports rank {comm_rank} of {comm_ranks}; the job is rank {rank} of {world}")
     dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf, overlap=not args.sync_gather)
     value = n_gpus * N * args.steps / dt
     exchange = exchange_diagnostics(task, actions, args, world, gather_buf, dt) if use_dist else None
@@ -563,6 +570,7 @@ def main():
                     "ALUs nor HBM can be filled, the launch is latency bound; roofline_at_scale prices the same kernel at 2^21 envs",
         })
     if exchange is not None:
+        exchange["communicator_ranks"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
         out["exchange"] = exchange
     if rank == 0 and args.workload != "dynamics":
         kt = kernel_time_raycast(task)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 5
+#define AGX_ABI_VERSION 6
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -496,7 +496,9 @@ int agx_image_min(int num_envs, int pixels_per_env, const float *pixels, float *
  *   agx_exchange_wait:      `stream` waits (no host block beyond the enqueue hand-off) for the
  *                           latest posted gather of `parity`: after it the stream may read that
  *                           recv buffer and overwrite that send buffer.
- *   agx_exchange_step:      post(parity) then wait(wait_parity) in one call (wait_parity < 0: none). */
+ *   agx_exchange_step:      post(parity) then wait(wait_parity) in one call (wait_parity < 0: none).
+ *   agx_exchange_info:      rank and size AS THE COMMUNICATOR REPORTS THEM (ncclCommUserRank / ncclCommCount):
+ *                           lets the caller assert that the collective really spans the ranks it was built for. */
 typedef struct AgxExchange AgxExchange;
 int agx_exchange_unique_id(const char *rccl_path, void *id_out, int id_bytes);
 int agx_exchange_create(const char *rccl_path, const void *id, int id_bytes, int rank, int world,
@@ -508,6 +510,7 @@ int agx_exchange_wait(AgxExchange *x, int parity, void *stream);
 int agx_exchange_step(AgxExchange *x, int parity, const float *send, float *recv,
                       size_t count_per_rank, const uint32_t *signal, uint32_t seq, int wait_parity,
                       void *stream);
+int agx_exchange_info(AgxExchange *x, int *rank, int *world);
 int agx_exchange_destroy(AgxExchange *x);
 
 #ifdef __cplusplus

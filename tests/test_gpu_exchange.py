@@ -1,7 +1,8 @@
 """The library-side step exchange (csrc/agx_exchange.hip) on one GPU: a world of one still goes
 through ncclCommInitRank / ncclAllGather, the worker thread, both streams and all four events.
-(World sizes > 1 need one GPU per rank: the host logic of the N > 1 path is covered by the gloo
-tests in test_abi_and_host.py, the RCCL leg by bench.py --gpus N.)"""
+World size 2 on the one-GPU box: two processes share the device and the exchange binds a test double of the five
+RCCL entry points (tests/fakerccl: a stream-ordered shared-memory all-gather; RCCL refuses two ranks on one device),
+see test_rccl_thread_exchange_world2."""
 import os
 import socket
 import time
@@ -195,3 +196,55 @@ def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
         cfg.episode_len_steps, cfg.args = old[0], old[1]
         if old[2] is not None:
             cfg.controller_name = old[2]
+
+
+def _run_world2(mode, steps, extra_env=None, timeout=240):
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fakerccl"))
+    import build as fake_build
+
+    lib = fake_build.build()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, AGX_RCCL_PATH=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_world2_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), mode, str(steps)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    t0 = time.time()
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, timeout - (time.time() - t0)))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError(f"world-2 exchange ({mode}) hung for {timeout} s")
+        outs.append(out)
+    return [p.returncode for p in procs], outs
+
+
+@pytest.mark.parametrize("mode", ["signal", "event", "sync", "close_skew"])
+def test_rccl_thread_exchange_world2(mode):
+    """StepGather(backend="rccl_thread") at WORLD SIZE 2 through agx_exchange_step: 2000 position-task steps per rank
+    (1536 envs each, episodes of 37 steps), overlapped (one gather in flight while the next step runs) and synchronous,
+    with the device-flag and the event hand-off.  Checked on every rank: the communicator reports 2 ranks; its own slice
+    of every gathered buffer is bit-identical to the rows it sent for that step; the checksums of what rank r SENT at
+    step t (exchanged over gloo afterwards) equal the checksums of rank r's slice in what EVERY rank RECEIVED for step
+    t -- ordering and double buffering over 2000 steps; teardown with the ranks a second apart."""
+    steps = 2000 if mode in ("signal", "event") else 400
+    codes, outs = _run_world2(mode, steps)
+    assert codes == [0, 0], "\n".join(o[-1500:] for o in outs)
+    assert all("ok %d steps" % steps in o for o in outs)
+
+
+def test_rccl_thread_exchange_world2_peer_failure_is_an_error_not_a_hang():
+    """Rank 1's 50th collective fails (injected): rank 1 raises from the exchange; rank 0's rendezvous ends with an
+    error as well (the double marks the segment failed; a silent peer would hit the 5 s bound) -- both processes end."""
+    codes, outs = _run_world2("fail", 400, extra_env={"AGX_FAKERCCL_FAIL_RANK": "1", "AGX_FAKERCCL_FAIL_AT": "50",
+                                                     "AGX_FAKERCCL_TIMEOUT_S": "5"}, timeout=120)
+    assert codes == [3, 3], "\n".join(o[-1500:] for o in outs)
+    assert all("exchange failed as expected" in o for o in outs)
