@@ -23,6 +23,7 @@ CTRL_IDS = {
     "acceleration": 5,
     "velocity_steering": 6,
     "fully_actuated": 7,
+    "wrench": 8,  # external controller (user class): the kernel takes its output
 }
 
 
@@ -96,6 +97,7 @@ class AgxEnvBuffers(C.Structure):
         ("step_reward", C.c_void_p),
         ("step_signal", C.c_void_p),
         ("body_force", C.c_void_p),
+        ("launch_flags", C.c_int32),
     ]
 
 

@@ -481,17 +481,21 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
       tdec[j] = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, j) : P.tau_dec_uniform;
     }
     Gains g{};
-    if (CTRL != AGX_CTRL_NONE) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
+    if (CTRL != AGX_CTRL_NONE && CTRL != AGX_CTRL_WRENCH) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
+    // EXTERNAL controller (a user class evaluated by the host between launches): actions_in is ITS OUTPUT, the body
+    // wrench [N][6]; robot_actions / robot_prev_actions (A columns) are maintained by the host and only read here
+    constexpr bool EXT = CTRL == AGX_CTRL_WRENCH;
     float a_in[AGX_MAX_ACTIONS], a_old[AGX_MAX_ACTIONS];
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
-      a_in[c] = (c < A) ? actions_in[(size_t)i * A + c] : 0.0f;
+      a_in[c] = EXT ? ((c < 6) ? actions_in[(size_t)i * 6 + c] : 0.0f) : ((c < A) ? actions_in[(size_t)i * A + c] : 0.0f);
       a_old[c] = (c < A) ? AGX_AT(B.actions, c) : 0.0f;
     }
     Derived d{};
     if (k == 0 && T.kind != AGX_TASK_NONE) d = load_derived(B.derived, n, i);
     Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
     const bool root_link = P.root_link_mode != 0;
+    const int sub_base = (B.launch_flags >> 8) & 0xFF;  // physics sub-step this launch starts at (split env steps)
     V3 tlo = s.p, thi = s.p;
     for (int sub = 0; sub < k; ++sub) {
       d = update_states(s);
@@ -502,7 +506,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 #pragma unroll
         for (int j = 0; j < M; ++j) u[j] = motor_update(P, a[j], u[j], kT[j], tinc[j], tdec[j]);
       } else {
-        wc = run_controller<CTRL>(P, s, d, a, g);
+        if (EXT) wc = Wrench{V3{a_in[0], a_in[1], a_in[2]}, V3{a_in[3], a_in[4], a_in[5]}};  // as handed in, not clipped
+      else wc = run_controller<CTRL>(P, s, d, a, g);
         const float w6[6] = {wc.f.x, wc.f.y, wc.f.z, wc.t.x, wc.t.y, wc.t.z};
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -531,7 +536,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         bw[5] += (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
       }
       if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234), draws supplied by the host
-        const float *dd = B.disturb + (size_t)sub * 7 * n + i;
+        const float *dd = B.disturb + (size_t)(sub_base + sub) * 7 * n + i;
         float occ = dd[0];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -540,7 +545,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         }
       } else if (B.disturb_prob > 0.0f) {  // same, drawn in place: 7 uniforms per env and sub-step
         float ud[7];
-        rng_fill<7>(B.rng_seed, i, B.step_counter, RNG_DISTURB + sub, ud);
+        rng_fill<7>(B.rng_seed, i, B.step_counter, RNG_DISTURB + sub_base + sub, ud);
         float occ = ud[0] < B.disturb_prob ? 1.0f : 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -562,8 +567,11 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
       }
     }
     // EnvManager.reset_tensors + compute_observations (env_manager.py:342-344, 358-362)
-    bool crashed = false;
-    if (B.boxes && k > 0) crashed = collide_trajectory(B.boxes, B.num_boxes, n, i, traj, k, bd, tid, tlo, thi, P.collision_radius);
+    // launch_flags (external controllers run ONE launch per physics sub-step): bit 0 = an earlier launch of this env
+    // step already ran: accumulate its crash flag; bit 1 = more launches follow: no step counter / truncation / task epilogue
+    const bool more_launches = (B.launch_flags & 2) != 0;
+    bool crashed = (B.launch_flags & 1) ? (B.crashes[i] != 0) : false;
+    if (B.boxes && k > 0) crashed = collide_trajectory(B.boxes, B.num_boxes, n, i, traj, k, bd, tid, tlo, thi, P.collision_radius) || crashed;
     store_state(B.state, n, i, s);
     if (k > 0) {
       store_derived(B.derived, n, i, d);
@@ -578,17 +586,17 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
     float a_cur[AGX_MAX_ACTIONS], a_prev[AGX_MAX_ACTIONS];
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
-      a_cur[c] = (k > 0) ? a_in[c] : a_old[c];
-      a_prev[c] = (k >= 2) ? a_in[c] : ((k == 1) ? a_old[c] : ((c < A) ? AGX_AT(B.prev_actions, c) : 0.0f));
-      if (c < A && k > 0) {
+      a_cur[c] = (k > 0 && !EXT) ? a_in[c] : a_old[c];
+      a_prev[c] = (k >= 2 && !EXT) ? a_in[c] : ((k == 1 && !EXT) ? a_old[c] : ((c < A) ? AGX_AT(B.prev_actions, c) : 0.0f));
+      if (c < A && k > 0 && !EXT) {
         AGX_AT(B.prev_actions, c) = a_prev[c];
         AGX_AT(B.actions, c) = a_cur[c];
       }
     }
-    const int steps = B.sim_steps[i] + 1;
-    B.sim_steps[i] = steps;
+    const int steps = B.sim_steps[i] + (more_launches ? 0 : 1);
+    if (!more_launches) B.sim_steps[i] = steps;
     bool trunc = false;
-    if (T.kind != AGX_TASK_NONE) {
+    if (T.kind != AGX_TASK_NONE && !more_launches) {
       V3 tgt = V3{AGX_AT(T.target, 0), AGX_AT(T.target, 1), AGX_AT(T.target, 2)};
       float rew;
       if (T.kind == AGX_TASK_POSITION) {
@@ -607,7 +615,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
       B.reset_mask[i] = reset ? 1 : 0;
     }
     B.crashes[i] = crashed ? 1 : 0;
-    B.truncations[i] = trunc ? 1 : 0;
+    if (!more_launches) B.truncations[i] = trunc ? 1 : 0;
   }
   if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
@@ -1027,6 +1035,7 @@ using namespace agx;
     case AGX_CTRL_ACCELERATION: { constexpr int kC = AGX_CTRL_ACCELERATION; __VA_ARGS__; } break; \
     case AGX_CTRL_VEL_STEERING: { constexpr int kC = AGX_CTRL_VEL_STEERING; __VA_ARGS__; } break; \
     case AGX_CTRL_FULLY_ACTUATED: { constexpr int kC = AGX_CTRL_FULLY_ACTUATED; __VA_ARGS__; } break; \
+    case AGX_CTRL_WRENCH: { constexpr int kC = AGX_CTRL_WRENCH; __VA_ARGS__; } break;      \
     default: return fail(AGX_E_ARG, "unknown controller id %d", C_);                       \
   }
 
@@ -1040,10 +1049,11 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   if (P) {
     AGX_REQUIRE(P->num_motors >= 1 && P->num_motors <= AGX_MAX_MOTORS, "num_motors out of range");
     AGX_REQUIRE(P->num_actions >= 1 && P->num_actions <= AGX_MAX_ACTIONS, "num_actions out of range");
-    AGX_REQUIRE(P->controller >= 0 && P->controller <= AGX_CTRL_FULLY_ACTUATED, "unknown controller id %d", P->controller);
+    AGX_REQUIRE(P->controller >= 0 && P->controller <= AGX_CTRL_WRENCH, "unknown controller id %d", P->controller);
     AGX_REQUIRE(P->controller != AGX_CTRL_FULLY_ACTUATED || P->num_actions == 7, "fully actuated controller needs 7 actions");
     AGX_REQUIRE(P->controller != AGX_CTRL_NONE || P->num_actions == P->num_motors, "no_control needs num_actions == num_motors");
-    AGX_REQUIRE(P->controller == AGX_CTRL_NONE || P->controller == AGX_CTRL_FULLY_ACTUATED || P->num_actions == 4,
+    AGX_REQUIRE(P->controller == AGX_CTRL_NONE || P->controller == AGX_CTRL_FULLY_ACTUATED || P->controller == AGX_CTRL_WRENCH ||
+                    P->num_actions == 4,
                 "Lee controllers take 4 actions");
   }
   return AGX_OK;
@@ -1064,6 +1074,9 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   AGX_REQUIRE(P != nullptr, "null params");
   AGX_REQUIRE(actions_in != nullptr, "null actions");
   AGX_REQUIRE(k >= 0 && k <= AGX_MAX_SUBSTEPS, "k_substeps out of range: %d", k);
+  AGX_REQUIRE(P->controller != AGX_CTRL_WRENCH || k <= 1,
+              "external controller (AGX_CTRL_WRENCH): one launch per physics sub-step, the host re-evaluates the controller in between");
+  AGX_REQUIRE((B->launch_flags & ~0xFF03) == 0, "launch_flags: bits 0, 1 and the sub-step index in bits 8-15");
   AGX_REQUIRE(B->state && B->derived && B->actions && B->prev_actions && B->motor_thrust && B->crashes && B->truncations &&
                   B->sim_steps,
               "null env buffer");

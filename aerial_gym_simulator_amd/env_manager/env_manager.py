@@ -394,14 +394,43 @@ class EnvManager(BaseManager):
         if a.shape != (self.num_envs, self.num_robot_actions):
             raise ValueError("Action tensor does not have the correct number of environments")
         self._draw_disturbance(num_substeps)
-        _lib.check(
-            self._lib.agx_env_step(self._params, self._buffers, self.num_envs, _lib.dptr(a), num_substeps, self.task_args,
-                                   self._stream()),
-            "agx_env_step",
-        )
+        if getattr(self.robot_manager.robot, "external_controller", False):
+            self._simulate_with_external_controller(a, num_substeps)
+        else:
+            _lib.check(
+                self._lib.agx_env_step(self._params, self._buffers, self.num_envs, _lib.dptr(a), num_substeps, self.task_args,
+                                       self._stream()),
+                "agx_env_step",
+            )
         self._reward_fresh = self.task_args is not None
         self._obs_fresh = False
         self.robot_manager.post_physics_step(num_substeps)
+
+    def _simulate_with_external_controller(self, a, k):
+        """A controller class the user registered (torch code, controller_registry.register_controller): per physics
+        sub-step, exactly the reference's order -- pre_physics_step copies the action (robot_manager.py:486-489),
+        BaseMultirotor.step refreshes the derived state tensors, clips the action to +-10 and calls the controller
+        (base_multirotor.py:296-307) -- then ONE launch takes the returned wrench through allocation, motor model, drag,
+        disturbance, integration and the collision test.  Crash flags accumulate over the launches; the step counter,
+        truncation and the task's fused reward run with the last one (AgxEnvBuffers.launch_flags)."""
+        g, B, robot = self.global_tensor_dict, self._buffers, self.robot_manager.robot
+        try:
+            for sub in range(max(k, 1)):
+                B.launch_flags = (1 if sub > 0 else 0) | (2 if sub < k - 1 else 0) | (sub << 8)
+                if k > 0:
+                    g["robot_prev_actions"][:] = g["robot_actions"]
+                    g["robot_actions"][:] = a
+                    self.update_states()
+                    wrench = robot.controller(torch.clamp(a, -10.0, 10.0))
+                    if wrench.shape != (self.num_envs, 6):
+                        raise ValueError(f"controller returned {tuple(wrench.shape)}, expected ({self.num_envs}, 6): [fx fy fz tx ty tz]")
+                    w = wrench.to(dtype=torch.float32).contiguous()
+                else:
+                    w = a
+                _lib.check(self._lib.agx_env_step(self._params, B, self.num_envs, _lib.dptr(w), min(k, 1), self.task_args, self._stream()),
+                           "agx_env_step")
+        finally:
+            B.launch_flags = 0
 
     def step(self, actions, env_actions=None):
         """env_actions: [N, num_assets, 6] obstacle twists (world-frame linear + angular velocity), the

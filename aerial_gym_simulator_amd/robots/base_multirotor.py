@@ -42,6 +42,12 @@ class BaseMultirotor(BaseRobot):
         g["robot_body_linvel"] = self.robot_body_linvel
         g["robot_body_angvel"] = self.robot_body_angvel
         g["num_robot_actions"] = self.controller_config.num_actions
+        # what the reference's controllers read in init_tensors (controllers/base_controller.py:11-24)
+        from .robot_model import composite_body
+
+        mass, _, inertia = composite_body(self.cfg.robot_model)
+        g.setdefault("robot_mass", torch.full((N,), float(mass), dtype=torch.float32, device=dev))
+        g.setdefault("robot_inertia", torch.tensor(inertia, dtype=torch.float32, device=dev).view(1, 3, 3).expand(N, 3, 3))
         self.controller.init_tensors(g)
         self.min_init_state = [float(x) for x in self.cfg.init_config.min_init_state]
         self.max_init_state = [float(x) for x in self.cfg.init_config.max_init_state]
@@ -51,10 +57,15 @@ class BaseMultirotor(BaseRobot):
             random_source=g["random_source"],
         )
         kind = getattr(self.controller, "KIND", None)
-        if kind is None:
-            raise NotImplementedError(
-                "custom controller classes must derive from aerial_gym_simulator_amd.control.controllers.BaseController"
-            )
+        # A class registered through controller_registry.register_controller that is not one of the built-in laws (no KIND):
+        # the reference's plug-in contract -- __init__(config, num_envs, device), init_tensors(global_tensor_dict),
+        # __call__(action) -> wrench [N, 6] (base_lee_controller.py:23-118).  It is evaluated by the host, in torch, once
+        # per physics sub-step on freshly updated state tensors; the kernel takes its output (AGX_CTRL_WRENCH).
+        self.external_controller = kind is None
+        if self.external_controller:
+            if self.output_mode != "wrench":
+                raise ValueError("an external controller must return a body wrench [N, 6]")
+            kind = "wrench"
         self.params_dict = robot_params_dict(self.cfg, self.controller_config, kind, g["sim_config"])
         self.params = pack_robot_params(self.params_dict)
 

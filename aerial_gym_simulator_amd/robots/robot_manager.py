@@ -36,8 +36,9 @@ class RobotManagerHIP:
         g["dof_control_mode"] = "none"
         self.robot.init_tensors(g)
         pd = self.robot.params_dict
-        g["robot_mass"] = torch.full((N,), pd["mass"], device=dev)
-        g["robot_inertia"] = torch.tensor(pd["inertia"], device=dev).view(1, 3, 3).expand(N, 3, 3)
+        # (allocated by the robot before its controller's init_tensors, which reads them like the reference's controllers do)
+        g["robot_mass"][:] = pd["mass"]
+        g["robot_inertia"] = g["robot_inertia"] if "robot_inertia" in g else torch.tensor(pd["inertia"], device=dev).view(1, 3, 3).expand(N, 3, 3)
         self.robot_masses, self.robot_inertias = g["robot_mass"], g["robot_inertia"]
         sc = self.cfg.sensor_config
         if self.use_warp and (sc.enable_camera or sc.enable_lidar):

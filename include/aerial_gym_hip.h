@@ -53,7 +53,14 @@ enum {
   AGX_CTRL_RATES = 4,         /* LeeRatesController        rates_control.py:16         */
   AGX_CTRL_ACCELERATION = 5,  /* LeeAccelerationController acceleration_control.py:16  */
   AGX_CTRL_VEL_STEERING = 6,  /* LeeVelocitySteeringAngleController  :15               */
-  AGX_CTRL_FULLY_ACTUATED = 7 /* FullyActuatedController   fully_actuated_control.py:14 */
+  AGX_CTRL_FULLY_ACTUATED = 7,/* FullyActuatedController   fully_actuated_control.py:14 */
+  AGX_CTRL_WRENCH = 8         /* EXTERNAL controller: any class registered through controller_registry.register_controller
+                                 (registry/controller_registry.py:12-52) whose __call__(action) returns the body wrench
+                                 [N, 6] (base_lee_controller.py:92-93).  The host evaluates it (torch) once per physics
+                                 sub-step on freshly updated state tensors and hands its OUTPUT to agx_env_step as
+                                 `actions_in` [N][6] with k_substeps = 1 and AgxEnvBuffers.launch_flags; allocation, motor
+                                 model, drag, disturbance, integration, collision run in the kernel as usual.  num_actions
+                                 stays the width of robot_actions (maintained by the host in this mode).               */
 };
 
 /* Constants shared by all envs.  Sources: config/robot_config/ *.py,
@@ -146,6 +153,10 @@ typedef struct AgxEnvBuffers {
   uint32_t *step_signal;
   float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
                             the body frame = allocator output + drag + disturbance; read by agx_imu_update */
+  int32_t launch_flags;  /* 0 for the fused step.  An env step split over several agx_env_step launches (AGX_CTRL_WRENCH:
+                            one per physics sub-step): bit 0 = not the first launch (crash flags accumulate, env_manager.py:
+                            426-428), bit 1 = not the last launch (no sim_steps += 1, truncation or task epilogue yet),
+                            bits 8-15 = index of the first physics sub-step of this launch (disturbance draws / rows).     */
 } AgxEnvBuffers;
 
 const char *agx_last_error(void);

@@ -36,7 +36,7 @@ def _env_step(meta):
 
 def test_env_step_instances_and_spills(meta):
     ks = _env_step(meta)
-    assert len(ks) == 3 * 8 * 2 * 2  # motors {4,6,8} x 8 controllers x {single, k-loop} x {wide, 256-thread}
+    assert len(ks) == 3 * 9 * 2 * 2  # motors {4,6,8} x 9 controller ids (8 laws + external wrench) x {single, k-loop} x {wide, 256-thread}
     report = []
     for (M, C, single, wide), r in sorted(ks.items()):
         if wide:
@@ -77,7 +77,7 @@ def test_wide_env_step_kernels_issue_no_scratch_instruction():
             scratch[cur] = scratch.get(cur, 0) + 1
         if cur and "k_env_step" in cur and "s_endpgm" in line:
             seen += 1
-    assert seen >= 96
+    assert seen >= 108
     wide = {k: v for k, v in scratch.items() if re.search(r"k_env_stepILi\dELi\dELb[01]ELb1E", k)}
     assert not wide, wide
     single_quad = {k: v for k, v in scratch.items() if re.search(r"k_env_stepILi4ELi\dELb1ELb0E", k)}
