@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         }
       } else if (B.disturb_prob > 0.0f) {  // same, drawn in place: 7 uniforms per env and sub-step
         float ud[7];
-        rng_fill<7>(B.rng_seed, i, B.step_counter, RNG_DISTURB + sub_base + sub, ud);
+        rng_fill<7>(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_DISTURB + sub_base + sub, ud);
         float occ = ud[0] < B.disturb_prob ? 1.0f : 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -750,7 +750,7 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
 #pragma unroll
       for (int c = 0; c < 3; ++c) { u6[c] = u_vec[(size_t)i * 3 + c]; u6[3 + c] = u_euler[(size_t)i * 3 + c]; }
     } else {
-      rng_fill<6>(B.rng_seed, i, B.step_counter, RNG_OBS_NOISE, u6);
+      rng_fill<6>(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_OBS_NOISE, u6);
     }
     // 0.1 * 2 * rand_like(vec - 0.5): the -0.5 sits inside rand_like in the reference (:374)
     V3 pv = V3{v.x + 0.1f * 2.0f * u6[0], v.y + 0.1f * 2.0f * u6[1], v.z + 0.1f * 2.0f * u6[2]};
@@ -804,7 +804,7 @@ AGX_DEV void bounds_from_draws(const AgxResetArgs &R, const float ub[6], float b
     bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
   }
 }
-AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin[3], float bmax[3]) {
+AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int rng_env, int episode, float bmin[3], float bmax[3]) {
   float ub[6];
   if (R.u_state) {
 #pragma unroll
@@ -813,7 +813,7 @@ AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int episode, float bmin
       ub[3 + c] = R.u_bounds_hi[(size_t)i * 3 + c];
     }
   } else {
-    rng_fill<6>(R.seed, i, episode, RNG_BOUNDS, ub);
+    rng_fill<6>(R.seed, rng_env, episode, RNG_BOUNDS, ub);
   }
   bounds_from_draws(R, ub, bmin, bmax);
 }
@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
     if (R.u_state) {
       if (mine) host_reset_draws<M>(P, R, i, D);
     } else {
-      wave_reset_draws<M>(R, i, ep, mine, D);
+      wave_reset_draws<M>(R, B.env_index_base + i, ep, mine, D);  // draws are keyed by the GLOBAL env index
     }
     if (valid) {
       EnvState s = mine ? reset_env<M>(P, B, n, R, i, ep, D) : load_state(B.state, n, i);
@@ -976,25 +976,27 @@ __global__ void __launch_bounds__(256) k_reset_assets(AgxEnvBuffers B, int n, in
                                                        const float *__restrict__ u2, const float *__restrict__ u_sel,
                                                        const float *__restrict__ min_ratio, const float *__restrict__ max_ratio,
                                                        int num_obstacles, int nk, float *__restrict__ asset_state) {
-  const int env = blockIdx.y;
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  // env on grid.x (2^31 blocks), asset chunk on grid.y: HIP caps grid.y at 65535, the env count has no such bound
+  const int env = blockIdx.x;
+  const int a = blockIdx.y * blockDim.x + threadIdx.x;
   if (a >= K) return;
   if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[env] == 0) return;
   const int ep = B.episode_count ? B.episode_count[env] : 0;
   const bool host_rng = u1 != nullptr;
-  float usel = host_rng ? u_sel[env] : rng_block(R.seed, env, ep, RNG_ASSET_SEL, 0).v[0];
+  const int genv = B.env_index_base + env;  // the device generator is keyed by the global env index
+  float usel = host_rng ? u_sel[env] : rng_block(R.seed, genv, ep, RNG_ASSET_SEL, 0).v[0];
   // strict mode hands over the bernoulli outcome (0/1); the device generator thresholds at 0.15
   const bool sel = host_rng ? (usel > 0.0f) : (usel < 0.15f);
   const int n_active = sel ? max(num_obstacles / 2, nk / 2) : max(num_obstacles, nk);
   float bmin[3], bmax[3];
-  sample_bounds(R, env, ep, bmin, bmax);
+  sample_bounds(R, env, genv, ep, bmin, bmax);
   const size_t base = ((size_t)env * K + a) * 13;
   float ratio[6], ua[6];
   if (host_rng) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) ua[c] = sel ? u2[base + c] : u1[base + c];
   } else {
-    rng_fill<6>(R.seed, env, ep, RNG_ASSETS + a, ua);
+    rng_fill<6>(R.seed, genv, ep, RNG_ASSETS + a, ua);
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * ua[c] + min_ratio[base + c];
@@ -1219,7 +1221,8 @@ extern "C" int agx_reset_assets(const AgxEnvBuffers *B, int n, int K, const AgxR
   AGX_REQUIRE((u1 && u2 && u_sel && R->u_state) || (!u1 && !u2 && !u_sel && !R->u_state),
               "asset draws and robot draws must both come from tensors or both from the device generator");
   AGX_REQUIRE(u1 || B->episode_count, "device RNG needs buf->episode_count");
-  dim3 grid(blocks_for(K, 64), n);
+  AGX_REQUIRE(blocks_for(K, 64) <= 65535, "too many assets per env");
+  dim3 grid(n, blocks_for(K, 64));
   hipLaunchKernelGGL(k_reset_assets, grid, dim3(64), 0, (hipStream_t)stream, *B, n, K, *R, u1, u2, u_sel, min_ratio, max_ratio,
                      num_obstacles, num_keep, asset_state);
   return check_launch("agx_reset_assets");

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_imu_update(AgxEnvBuffers B, int n, int 
 #pragma unroll
       for (int c = 0; c < 6; ++c) zb[c] = z_bias[((size_t)s * n + i) * 6 + c];
     } else {
-      normals6(B.rng_seed, i, B.step_counter, 2 * s + 1, zb);
+      normals6(B.rng_seed, B.env_index_base + i, B.step_counter, 2 * s + 1, zb);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] += zb[c] * A.bias_std[c] * A.sqrt_dt;
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_imu_update(AgxEnvBuffers B, int n, int 
 #pragma unroll
     for (int c = 0; c < 6; ++c) zn[c] = z_noise[(size_t)i * 6 + c];
   } else {
-    normals6(B.rng_seed, i, B.step_counter, 2 * (k > 0 ? k - 1 : 0), zn);
+    normals6(B.rng_seed, B.env_index_base + i, B.step_counter, 2 * (k > 0 ? k - 1 : 0), zn);
   }
   const float v[6] = {acc.x, acc.y, acc.z, ang.x, ang.y, ang.z};
 #pragma unroll
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) k_imu_reset(AgxEnvBuffers B, int n, AgxIm
 #pragma unroll
     for (int c = 0; c < 3; ++c) u[6 + c] = u_rot[(size_t)i * 3 + c];
   } else {
-    rng_fill<9>(B.rng_seed, i, B.episode_count ? B.episode_count[i] : 0, RNG_IMU_RESET, u);
+    rng_fill<9>(B.rng_seed, B.env_index_base + i, B.episode_count ? B.episode_count[i] : 0, RNG_IMU_RESET, u);
   }
 #pragma unroll
   for (int c = 0; c < 6; ++c) bias[(size_t)i * 6 + c] = A.max_bias_init[c] * (2.0f * (u[c] - 0.5f));

@@ -37,6 +37,19 @@ __global__ void __launch_bounds__(256) k_nav_bookkeeping(AgxEnvBuffers B, int n,
   }
 }
 
+// EnvManager.reset_terminated_and_truncated_envs (env_manager.py:364-371) for callers that did not go through one of
+// the task reward kernels (stand-alone EnvManager use, user tasks that set `truncations` in torch like every reference
+// task does): reset set = crashes * reset_on_collision + truncations, and the step's device flag.
+__global__ void __launch_bounds__(256) k_reset_set(AgxEnvBuffers B, int n, int reset_on_collision) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool reset = false;
+  if (i < n) {
+    reset = (B.crashes[i] != 0 && reset_on_collision != 0) || B.truncations[i] != 0;
+    B.reset_mask[i] = reset ? 1 : 0;
+  }
+  if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+}
+
 // reset_idx of the navigation tasks (navigation_task.py:166-175, lidar_navigation_task.py:164-181) for the envs of
 // reset_mask: target = bounds_min + (bounds_max - bounds_min) * U(min_ratio, max_ratio); optional target_yaw =
 // U(-pi, pi); optional robot_prev_actions = 0.
@@ -50,7 +63,7 @@ __global__ void __launch_bounds__(256) k_nav_target_reset(AgxEnvBuffers B, int n
 #pragma unroll
     for (int c = 0; c < 4; ++c) uu[c] = u[(size_t)i * 4 + c];
   } else {
-    rng_fill<4>(B.rng_seed, i, B.episode_count ? B.episode_count[i] : 0, RNG_TARGET, uu);
+    rng_fill<4>(B.rng_seed, B.env_index_base + i, B.episode_count ? B.episode_count[i] : 0, RNG_TARGET, uu);
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -76,7 +89,7 @@ __global__ void __launch_bounds__(256) k_sensor_mount_reset(AgxEnvBuffers B, int
 #pragma unroll
     for (int c = 0; c < 3; ++c) { uu[c] = u_pos[(size_t)idx * 3 + c]; uu[3 + c] = u_rot[(size_t)idx * 3 + c]; }
   } else {
-    rng_fill<6>(B.rng_seed, i, B.episode_count ? B.episode_count[i] : 0, RNG_SENSOR_MOUNT + s, uu);
+    rng_fill<6>(B.rng_seed, B.env_index_base + i, B.episode_count ? B.episode_count[i] : 0, RNG_SENSOR_MOUNT + s, uu);
   }
   float e[3];
 #pragma unroll
@@ -97,6 +110,13 @@ static Ratio3 ratio3(const float *lo, const float *hi) {
   Ratio3 r;
   for (int c = 0; c < 3; ++c) { r.lo[c] = lo[c]; r.hi[c] = hi[c]; }
   return r;
+}
+
+extern "C" int agx_reset_set(const AgxEnvBuffers *B, int n, int reset_on_collision, void *stream) {
+  AGX_REQUIRE(B && n > 0 && B->crashes && B->truncations && B->reset_mask && B->reset_flag, "agx_reset_set: null buffer");
+  AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
+  hipLaunchKernelGGL(k_reset_set, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, reset_on_collision);
+  return check_launch("agx_reset_set");
 }
 
 extern "C" int agx_nav_bookkeeping(const AgxEnvBuffers *B, int n, const float *target, float radius, uint8_t *successes,

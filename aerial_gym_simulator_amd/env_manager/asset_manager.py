@@ -41,7 +41,7 @@ class AssetManager:
     def draw_reset_randoms(self, env_ids):
         """strict_rng order (env_manager.py:283-295): rand_like [N,K,13]; bernoulli(0.15) over the
         reset envs; if any selected a second rand_like [N,K,13]."""
-        if self.scene.num_assets == 0:
+        if self.scene.num_assets == 0 or int(self.g["num_obstacles_in_env"]) == 0:
             return
         rs = self.env.random_source
         rs.rand_into(self._u1, tag="assets")
@@ -69,7 +69,9 @@ class AssetManager:
         self._refresh_geometry(env, None)
 
     def reset_masked(self, env):
-        if self.scene.num_assets == 0:
+        # no assets, or none of them in the env at this curriculum level: the reference skips the asset reset
+        # (env_manager.py:283-284: `if num_obstacles > 0:`), its draws included
+        if self.scene.num_assets == 0 or int(self.g["num_obstacles_in_env"]) == 0:
             return
         self._apply(env, num_obstacles=int(self.g["num_obstacles_in_env"]))
 

@@ -126,7 +126,12 @@ class EnvManager(BaseManager):
         g["gravity"] = torch.tensor(sim_cfg.sim.gravity, device=dev).expand(N, -1)
         g["dt"] = sim_cfg.sim.dt
         # obstacles: which boxes live in which env (asset_loader.py:148-194 semantics)
-        self.scene = SceneManager(env_cfg, N, dev, self.random_source, shard_rank=int(self.env_args.get("shard_rank", 0)))
+        # sharded runs: global index of this process's first env (sharding.shard_range()[0]).  `shard_rank` alone is enough
+        # only when every rank holds the same number of envs; with remainders (10 envs on 3 ranks: 4, 3, 3) rank * N_local
+        # would make neighbouring ranks share scene seeds, segmentation ids and device-RNG streams.
+        rank = int(self.env_args.get("shard_rank", 0))
+        self.env_offset = int(self.env_args.get("env_offset", rank * N))
+        self.scene = SceneManager(env_cfg, N, dev, self.random_source, shard_rank=rank, env_offset=self.env_offset)
         self.keep_in_env = self.scene.keep_in_env_num
         g["num_obstacles_in_env"] = self.scene.num_assets
         self.robot_manager = RobotManagerHIP(self.global_tensor_dict, self.cfg, self.robot_name, self.controller_name, dev)
@@ -184,6 +189,7 @@ class EnvManager(BaseManager):
             B.disturb_max[i] = v
         B.disturb_prob = 0.0
         B.rng_seed = self.rng_seed
+        B.env_index_base = self.env_offset
         B.step_counter = 0
         B.boxes = p(self.scene.boxes_soa) if self.scene.num_assets > 0 else None
         B.num_boxes = self.scene.num_prims  # collision boxes: one per primitive (= per asset for box scenes)
@@ -195,7 +201,7 @@ class EnvManager(BaseManager):
         robot.controller._env_binding = self
         self._make_reset_args()
         self._disturb_buf = None
-        self._reward_fresh = self._obs_fresh = False
+        self._reward_fresh = self._obs_fresh = self._mask_fresh = False
 
     def _make_reset_args(self):
         N, dev = self.num_envs, self.device
@@ -346,6 +352,13 @@ class EnvManager(BaseManager):
 
     def reset_terminated_and_truncated_envs(self):
         g = self.global_tensor_dict
+        if not self._mask_fresh:
+            # nobody produced this step's reset set on the device (no fused task epilogue, no agx_reward_* call): derive
+            # it from the flags as they stand, like the reference does right here (env_manager.py:364-371) -- stand-alone
+            # EnvManager loops (examples/benchmark.py) and user tasks that set `truncations[:]` in torch depend on it
+            _lib.check(self._lib.agx_reset_set(self._buffers, self.num_envs, int(self.cfg.env.reset_on_collision), self._stream()),
+                       "agx_reset_set")
+            self._mask_fresh = True
         if self.strict_rng and int(g["reset_flag"][self._parity].item()) != 0:  # host sync, like the reference's nonzero()/len()
             env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1)
             self._draw_reset_randoms(env_ids)
@@ -402,7 +415,7 @@ class EnvManager(BaseManager):
                                        self._stream()),
                 "agx_env_step",
             )
-        self._reward_fresh = self.task_args is not None
+        self._reward_fresh = self._mask_fresh = self.task_args is not None
         self._obs_fresh = False
         self.robot_manager.post_physics_step(num_substeps)
 

@@ -28,9 +28,11 @@ _BOX_FACES = np.array(
 
 
 class SceneManager:
-    def __init__(self, env_cfg, num_envs, device, random_source, shard_rank=0, scene_seed_base=1000):
+    def __init__(self, env_cfg, num_envs, device, random_source, shard_rank=0, scene_seed_base=1000, env_offset=None):
         self.cfg, self.num_envs, self.device = env_cfg, num_envs, device
-        self.shard_rank = shard_rank  # this process owns global envs [rank * N, (rank + 1) * N)  
+        self.shard_rank = shard_rank
+        # this process owns global envs [env_offset, env_offset + N)  (SURVEY 8e); equal shards: rank * N
+        self.env_offset = env_offset = shard_rank * num_envs if env_offset is None else int(env_offset)
         N = num_envs
         types = []
         for name, acfg in env_cfg.env_config.asset_type_to_dict_map.items():
@@ -47,7 +49,7 @@ class SceneManager:
         self.num_tris = 12 * K
         self.num_prims, self.has_prims = K, False  # collision / scene pieces: one per asset unless a URDF has several links
         # sharding: start of this rank's slice of the global asset counter
-        semantic_offset = self.semantic_offset = semantic_id_offset(shard_rank, N, K)
+        semantic_offset = self.semantic_offset = env_offset * K  # this shard's slice of the global id counter
         if K == 0:
             return
         size = np.zeros((N, K, 3), np.float32)
@@ -66,7 +68,7 @@ class SceneManager:
         # geometry per asset type: URDF folder when configured and present, else the restated box-size table
         variants = [self._variants(t) for t in slots]
         if any(len(v) != 1 or v[0].kind != "box" or not np.allclose(v[0].T, np.eye(4)) for vs in variants for v in vs):
-            self._init_general(slots, variants, nk, nf, N, scene_seed_base, shard_rank)
+            self._init_general(slots, variants, nk, nf, N, scene_seed_base, env_offset)
             return
         choices = [[v[0].dims for v in vs] for vs in variants]
         max_choices = max(len(c) for c in choices)
@@ -76,7 +78,7 @@ class SceneManager:
             slot_choices[j, : len(c)] = c
         free_idx = list(range(nk, nk + nf))
         for i in range(N):
-            rng = np.random.default_rng(scene_seed_base + shard_rank * N + i)  # seeded by GLOBAL env index
+            rng = np.random.default_rng(scene_seed_base + env_offset + i)  # seeded by GLOBAL env index
             order = free_idx[:]
             random.shuffle(order)  # python `random`, like asset_loader.py:181
             perm = np.array(list(range(nk)) + order)
@@ -114,7 +116,7 @@ class SceneManager:
         sizes = list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
         return [[Prim("box", tuple(float(v) for v in sz), np.eye(4), "base_link", 0)] for sz in sizes]
 
-    def _init_general(self, slots, variants, nk, nf, N, scene_seed_base, shard_rank):
+    def _init_general(self, slots, variants, nk, nf, N, scene_seed_base, env_offset):
         """Scenes with multi-primitive assets (several links, cylinders): every primitive is its own rigid piece
         (own triangles in its own frame, own collision box) tied to its asset by agx_prims_from_assets.  The
         primitive layout is fixed by the canonical slot order; which asset INDEX owns a slot differs per env
@@ -133,7 +135,7 @@ class SceneManager:
         T = self.num_tris = int(tri_base[-1])
         ids_per_slot = np.array([max(len(v) for v in vs) if getattr(t, "per_link_semantic", False) and t.semantic_id < 0 else 1
                                  for t, vs in zip(slots, variants)])
-        semantic_offset = self.semantic_offset = semantic_id_offset(shard_rank, N, int(ids_per_slot.sum()))
+        semantic_offset = self.semantic_offset = env_offset * int(ids_per_slot.sum())
         lo, hi = np.zeros((N, K, 13), np.float32), np.zeros((N, K, 13), np.float32)
         prim_asset = np.zeros((N, KP), np.int32)
         prim_half, prim_lpos = np.zeros((N, KP, 3), np.float32), np.zeros((N, KP, 3), np.float32)
@@ -144,7 +146,7 @@ class SceneManager:
         counter = 100 + semantic_offset
         free_idx = list(range(nk, nk + nf))
         for i in range(N):
-            rng = np.random.default_rng(scene_seed_base + shard_rank * N + i)
+            rng = np.random.default_rng(scene_seed_base + env_offset + i)
             order = free_idx[:]
             random.shuffle(order)
             perm = list(range(nk)) + order

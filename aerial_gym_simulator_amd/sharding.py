@@ -92,6 +92,10 @@ class StepGather:
             self._native = self._create_native(required=backend == "rccl_thread")
         self.backend = "rccl_thread" if self._native is not None else ("process_group" if self.collective else "none")
         if env is not None:
+            if getattr(env, "rows_written_twice_per_step", False):
+                # return_state_before_reset: the observation kernel runs before AND after the reset, each publishing the
+                # step's flag -- the gather could start between the two and read torn rows: order by an event instead
+                ready = "event"
             if self._native is not None and ready == "signal":
                 rc = self._lib.agx_exchange_probe(self._native, torch.cuda.current_stream(self.device).cuda_stream)
                 if rc < 0:

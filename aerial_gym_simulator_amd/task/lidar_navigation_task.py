@@ -115,6 +115,7 @@ class LiDARNavigationTask(NavigationTask):
                                                  int(env.cfg.env.reset_on_collision), p(self.rewards), env._stream()),
             "agx_reward_lidar_navigation",
         )
+        env._mask_fresh = True  # the reward kernel wrote this step's reset set
         return self.rewards, self.terminations
 
     def _draw_lidar_noise(self):

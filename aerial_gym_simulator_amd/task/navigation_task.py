@@ -37,6 +37,7 @@ class NavigationTask(BaseTask):
         )
         N, dev = self.sim_env.num_envs, self.device
         self.num_envs = N
+        self.sim_env.rows_written_twice_per_step = bool(cfg.return_state_before_reset)  # see sharding.StepGather
         self.target_soa = soa(3, N, dev)
         self.target_position = aos_view(self.target_soa)
         self.target_min_ratio = torch.tensor(cfg.target_min_ratio, device=dev).expand(N, -1)
@@ -235,6 +236,7 @@ class NavigationTask(BaseTask):
                                            int(env.cfg.env.reset_on_collision), _lib.dptr(self.rewards), env._stream()),
             "agx_reward_navigation",
         )
+        env._mask_fresh = True  # the reward kernel wrote this step's reset set
         return self.rewards, self.terminations
 
     def get_return_tuple(self):

@@ -30,6 +30,7 @@ class PositionSetpointTask(BaseTask):
         )
         N, dev = self.sim_env.num_envs, self.device
         self.num_envs = N
+        self.sim_env.rows_written_twice_per_step = bool(cfg.return_state_before_reset)  # see sharding.StepGather
         self.actions = torch.zeros((N, cfg.action_space_dim), device=dev)
         self.prev_actions = torch.zeros_like(self.actions)
         self.counter = 0
@@ -83,6 +84,7 @@ class PositionSetpointTask(BaseTask):
             plan.num_envs, plan.k_substeps = env.num_envs, int(e.num_physics_steps_per_env_step_mean)
             self._plan = plan
             self._plan_fn = env._lib.agx_position_task_step
+            self._action_shape = (env.num_envs, env.num_robot_actions)
             self.task_obs["rewards"] = self.rewards
             self.task_obs["terminations"] = self.terminations
             self.task_obs["truncations"] = self.truncations
@@ -106,7 +108,8 @@ class PositionSetpointTask(BaseTask):
 
     def step(self, actions):
         self.counter += 1
-        if self._plan is not None and actions.dtype is torch.float32 and actions.is_contiguous() and actions.is_cuda:
+        if (self._plan is not None and actions.dtype is torch.float32 and actions.is_contiguous() and actions.is_cuda
+                and actions.shape == self._action_shape):  # anything else takes the general path, which raises like the reference
             # fast path: same two launches as the general path below, one host call
             self.prev_actions = self.actions  # previous step's tensor (no copy; the reward does not read it)
             self.actions = actions
@@ -114,10 +117,13 @@ class PositionSetpointTask(BaseTask):
             env._new_call()
             env._buffers.step_counter = env.step_counter & 0x7FFFFFFF  # as EnvManager.step (RNG streams, step_signal)
             self._plan.task.contents.episode_len = self.task_config.episode_len_steps
-            rc = self._plan_fn(self._plan, actions.data_ptr(), env._stream())
+            try:
+                rc = self._plan_fn(self._plan, actions.data_ptr(), env._stream())
+            finally:
+                env._parity = env._buffers.flag_parity  # the library toggles it first: stay in step on the error path too
             if rc != 0:
                 _lib.check(rc, "agx_position_task_step")
-            env._parity = env._buffers.flag_parity
+            env._mask_fresh = env._obs_fresh = False
             env.step_counter += 1
             return (self.task_obs, self.rewards, self.terminations, self.truncations, self.infos)
         self.prev_actions = self.actions
@@ -148,6 +154,7 @@ class PositionSetpointTask(BaseTask):
                                          _lib.dptr(self.rewards), env._stream()),
             "agx_reward_position",
         )
+        env._mask_fresh = True  # the reward kernel wrote this step's reset set
         return self.rewards, self.terminations
 
     def get_return_tuple(self):

@@ -153,6 +153,9 @@ typedef struct AgxEnvBuffers {
   uint32_t *step_signal;
   float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
                             the body frame = allocator output + drag + disturbance; read by agx_imu_update */
+  int32_t env_index_base;/* global index of env 0 of these buffers (sharded runs: this rank owns global envs
+                            [env_index_base, env_index_base + N)): first counter word of the device generator, so that
+                            a draw is a function of (seed, GLOBAL env, episode | step, stream) whatever the sharding   */
   int32_t launch_flags;  /* 0 for the fused step.  An env step split over several agx_env_step launches (AGX_CTRL_WRENCH:
                             one per physics sub-step): bit 0 = not the first launch (crash flags accumulate, env_manager.py:
                             426-428), bit 1 = not the last launch (no sim_steps += 1, truncation or task epilogue yet),
@@ -267,6 +270,11 @@ int agx_reward_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const fl
 int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
                              const float *target_yaw, const float *u_vec, const float *u_euler,
                              const float *downsampled, int cells, float *obs, void *stream);
+
+/* The reset set of EnvManager.reset_terminated_and_truncated_envs (env_manager.py:364-371) from the flags as they are:
+ * reset_mask = crashes * reset_on_collision | truncations, reset_flag[flag_parity] |= any.  For callers that did not
+ * run one of the task reward kernels above this step (stand-alone EnvManager; tasks that set truncations in torch). */
+int agx_reset_set(const AgxEnvBuffers *buf, int num_envs, int reset_on_collision, void *stream);
 
 /* ---- task glue of the navigation-type tasks (sync-free mode: no torch launches per step) ----
  * successes / timeouts (navigation_task.py:311-326, lidar_navigation_task.py:405-418): u8 [N] each;
