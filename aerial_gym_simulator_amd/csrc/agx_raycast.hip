@@ -39,6 +39,21 @@ namespace agx {
 #define AGX_RAY_USE_LDS 0
 #endif
 constexpr int kRayThreads = AGX_RAY_THREADS;  // waves per workgroup = kRayThreads / 64
+// pixel tile of a 64-ray packet.  Measured (profiles/r02_raycast_variants.txt, bit-exact either way): the pinhole camera
+// wants the compact 8 x 8 tile (64 x 48 depth frame 2.65 ms; 16 x 4: 2.98 ms -- the wider frustum visits more nodes),
+// the 32 x 512 LiDAR the 16 x 4 one (5.57 -> 5.29 ms: its rows are azimuth sweeps of 0.7 degrees per ray, 4 rows of
+// elevation 2.9 degrees apart, so 16 x 4 is the more compact bundle there; also 64-byte row segments for the stores).
+#ifndef AGX_RAY_TILE_W_CAMERA
+#define AGX_RAY_TILE_W_CAMERA 8
+#endif
+#ifndef AGX_RAY_TILE_W_LIDAR
+#define AGX_RAY_TILE_W_LIDAR 16
+#endif
+template <bool LIDAR>
+struct Tile {
+  static constexpr int W = LIDAR ? AGX_RAY_TILE_W_LIDAR : AGX_RAY_TILE_W_CAMERA, H = 64 / W;
+  static_assert(W * H == 64 && (W & (W - 1)) == 0, "tile must hold one wave");
+};
 constexpr int kStackDepth = 64;
 constexpr float kNoHitRay = 1000.0f;  // warp_camera_kernels.py:3
 constexpr int kNoHitSeg = -2;         // warp_camera_kernels.py:4
@@ -266,10 +281,10 @@ enum { RAY_BASIC = 0, RAY_NORMAL = 1, RAY_STEREO = 2 };
 constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
 
 // Register budget: BASIC / NORMAL need 57-61 VGPRs (8 waves per SIMD); STEREO carries two rays' worth of state over the
-// second traversal: 67 VGPRs (7 waves per SIMD).  AGX_RAY_STEREO_WAVES=8 forces it under 64 at the price of 31 more
-// SGPR spills (v_readlane in the traversal loop); the default keeps the compiler's choice.
+// second traversal and would take 67 (7 waves per SIMD): it is compiled for 8 waves (64 VGPRs, a few more SGPR spills),
+// measured 1.26 -> 1.14 ms per 2048-env stereo frame (profiles/r02_raycast_variants.txt).
 #ifndef AGX_RAY_STEREO_WAVES
-#define AGX_RAY_STEREO_WAVES 1
+#define AGX_RAY_STEREO_WAVES 8
 #endif
 template <bool LIDAR, bool USE_LDS, int VARIANT>
 __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : 1) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
@@ -313,10 +328,11 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
   }
   V3 partner = ro;
   if (VARIANT == RAY_STEREO) partner = ro + wp_quat_rotate(sq, V3{-CA.baseline, 0.0f, 0.0f});
-  const int tiles_x = (width + 7) >> 3, tiles_y = (height + 7) >> 3;
+  constexpr int kTileW = Tile<LIDAR>::W, kTileH = Tile<LIDAR>::H;
+  const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
   // gridDim.z workgroups share the tiles of one (env, sensor): small batches still fill the GPU
   for (int tile = blockIdx.z * (kRayThreads / 64) + wave; tile < tiles_x * tiles_y; tile += gridDim.z * (kRayThreads / 64)) {
-    const int x = (tile % tiles_x) * 8 + (lane & 7), y = (tile / tiles_x) * 8 + (lane >> 3);
+    const int x = (tile % tiles_x) * kTileW + (lane % kTileW), y = (tile / tiles_x) * kTileH + (lane / kTileW);
     const bool active = x < width && y < height;
     V3 local = V3{0.0f, 0.0f, 1.0f};
     if (active) {
@@ -506,7 +522,8 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
   // 256 CUs x 32 waves = 8192 resident waves, and tails want ~2x that in the grid: split an image's 8x8 tiles over several workgroups when the
   // batch alone cannot provide them (256 envs: 199 -> see profiles/r01_small_batch.txt us per frame)
   const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
-  const int tiles = ((width + 7) / 8) * ((height + 7) / 8), waves_per_wg = kRayThreads / 64;
+  constexpr int kTileW = Tile<LIDAR>::W, kTileH = Tile<LIDAR>::H;
+  const int tiles = ((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH), waves_per_wg = kRayThreads / 64;
   int split = (16384 + n * ns * waves_per_wg - 1) / (n * ns * waves_per_wg);
   const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
   split = split < 1 ? 1 : (split > max_split ? max_split : split);

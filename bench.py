@@ -196,7 +196,8 @@ def raycast_grid_threads(task):
     """grid size (threads) of the frame's k_raycast launch: the key of its counters in the PMC file"""
     cfg = task.sim_env.robot_manager.warp_sensor.cfg
     n, ns = task.num_envs, cfg.num_sensors
-    tiles = ((cfg.width + 7) // 8) * ((cfg.height + 7) // 8)
+    tw = 16 if task.sim_env.robot_manager.warp_sensor.is_lidar else 8  # csrc/agx_raycast.hip: Tile<LIDAR>
+    tiles = ((cfg.width + tw - 1) // tw) * ((cfg.height + 64 // tw - 1) // (64 // tw))
     split = max(1, min((16384 + n * ns * 4 - 1) // (n * ns * 4), (tiles + 3) // 4))
     return n * ns * split * 256
 
