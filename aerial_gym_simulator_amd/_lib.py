@@ -97,6 +97,7 @@ class AgxEnvBuffers(C.Structure):
         ("step_reward", C.c_void_p),
         ("step_signal", C.c_void_p),
         ("body_force", C.c_void_p),
+        ("step_counter_dev", C.c_void_p),
         ("env_index_base", C.c_int32),
         ("launch_flags", C.c_int32),
     ]
@@ -240,6 +241,7 @@ _SIGNATURES = {
          C.c_float, C.c_int, C.c_int, _P],
     ),
     "agx_image_min": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
+    "agx_step_counter_advance": (C.c_int, [C.POINTER(AgxEnvBuffers), _P]),
     "agx_reset_set": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P]),
     "agx_nav_bookkeeping": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_float, _P, _P, _P, _P]),
     "agx_nav_target_reset": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P,

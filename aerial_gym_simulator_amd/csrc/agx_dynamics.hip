@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         }
       } else if (B.disturb_prob > 0.0f) {  // same, drawn in place: 7 uniforms per env and sub-step
         float ud[7];
-        rng_fill<7>(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_DISTURB + sub_base + sub, ud);
+        rng_fill<7>(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_DISTURB + sub_base + sub, ud);
         float occ = ud[0] < B.disturb_prob ? 1.0f : 0.0f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -750,7 +750,7 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
 #pragma unroll
       for (int c = 0; c < 3; ++c) { u6[c] = u_vec[(size_t)i * 3 + c]; u6[3 + c] = u_euler[(size_t)i * 3 + c]; }
     } else {
-      rng_fill<6>(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_OBS_NOISE, u6);
+      rng_fill<6>(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_OBS_NOISE, u6);
     }
     // 0.1 * 2 * rand_like(vec - 0.5): the -0.5 sits inside rand_like in the reference (:374)
     V3 pv = V3{v.x + 0.1f * 2.0f * u6[0], v.y + 0.1f * 2.0f * u6[1], v.z + 0.1f * 2.0f * u6[2]};

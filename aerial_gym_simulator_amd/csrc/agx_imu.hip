@@ -4,6 +4,7 @@
 #include "agx_common.h"
 #include "agx_device_math.h"
 #include "agx_rng.h"
+#include "agx_step_signal.h"
 
 namespace agx {
 
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) k_imu_update(AgxEnvBuffers B, int n, int 
 #pragma unroll
       for (int c = 0; c < 6; ++c) zb[c] = z_bias[((size_t)s * n + i) * 6 + c];
     } else {
-      normals6(B.rng_seed, B.env_index_base + i, B.step_counter, 2 * s + 1, zb);
+      normals6(B.rng_seed, B.env_index_base + i, agx::step_index(B), 2 * s + 1, zb);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) b[c] += zb[c] * A.bias_std[c] * A.sqrt_dt;
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(256) k_imu_update(AgxEnvBuffers B, int n, int 
 #pragma unroll
     for (int c = 0; c < 6; ++c) zn[c] = z_noise[(size_t)i * 6 + c];
   } else {
-    normals6(B.rng_seed, B.env_index_base + i, B.step_counter, 2 * (k > 0 ? k - 1 : 0), zn);
+    normals6(B.rng_seed, B.env_index_base + i, agx::step_index(B), 2 * (k > 0 ? k - 1 : 0), zn);
   }
   const float v[6] = {acc.x, acc.y, acc.z, ang.x, ang.y, ang.z};
 #pragma unroll

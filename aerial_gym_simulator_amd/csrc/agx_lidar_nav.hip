@@ -70,8 +70,8 @@ __global__ void __launch_bounds__(256) k_lidar_image_obs(AgxEnvBuffers B, int n,
     const size_t g = (size_t)i * cells + c;
     if (device_noise) {
       // u0 < 0.03: += U(0.2, 10); u2 < 0.02: = 10; rows >= low_row0 and u3 < 0.02: = U(0.2, 1)
-      F4 a = rng_block(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_LIDAR_NOISE, 2 * c);
-      F4 b = rng_block(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_LIDAR_NOISE, 2 * c + 1);
+      F4 a = rng_block(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_LIDAR_NOISE, 2 * c);
+      F4 b = rng_block(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_LIDAR_NOISE, 2 * c + 1);
       if (a.v[0] < 0.03f) m += (10.0f - 0.2f) * a.v[1] + 0.2f;
       if (a.v[2] < 0.02f) m = 10.0f;
       if (cy >= low_row0 && a.v[3] < 0.02f) m = (1.0f - 0.2f) * b.v[0] + 0.2f;
@@ -163,7 +163,7 @@ AGX_DEV void obs_lidar_navigation_env(const AgxEnvBuffers &B, int n, int i, cons
       for (int c = 0; c < 3; ++c) { uv[c] = u_vec[(size_t)i * 3 + c]; ue[c] = u_euler[(size_t)i * 3 + c]; }
     } else {
       float u6[6];
-      rng_fill<6>(B.rng_seed, B.env_index_base + i, B.step_counter, RNG_OBS_NOISE, u6);
+      rng_fill<6>(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_OBS_NOISE, u6);
 #pragma unroll
       for (int c = 0; c < 3; ++c) { uv[c] = u6[c]; ue[c] = u6[3 + c]; }
     }

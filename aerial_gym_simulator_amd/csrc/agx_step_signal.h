@@ -21,6 +21,12 @@
 
 namespace agx {
 
+// the env-step index of this launch: a kernel argument (eager stepping) or, when the step is replayed from a hipGraph
+// whose kernel arguments are frozen, a word in device memory that the graph's last node advances
+__device__ __forceinline__ int step_index(const AgxEnvBuffers &B) {
+  return B.step_counter_dev ? *B.step_counter_dev : B.step_counter;
+}
+
 __device__ __forceinline__ void row_store(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -35,7 +41,7 @@ __device__ __forceinline__ void step_rows_signal(const AgxEnvBuffers &B) {
     const uint32_t arrived = __hip_atomic_fetch_add(B.step_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (arrived == groups) {
       __hip_atomic_store(B.step_signal + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (same stream)
-      __hip_atomic_store(B.step_signal + B.flag_parity, (uint32_t)B.step_counter + 1u, __ATOMIC_RELAXED,
+      __hip_atomic_store(B.step_signal + B.flag_parity, (uint32_t)agx::step_index(B) + 1u, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
   }

@@ -50,6 +50,11 @@ __global__ void __launch_bounds__(256) k_reset_set(AgxEnvBuffers B, int n, int r
   if (__ballot(reset) != 0ull && (threadIdx.x & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
 
+// last node of a captured env step: the step index the NEXT replay's kernels read (AgxEnvBuffers.step_counter_dev)
+__global__ void k_step_counter_advance(int32_t *counter) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *counter = (*counter + 1) & 0x7FFFFFFF;
+}
+
 // reset_idx of the navigation tasks (navigation_task.py:166-175, lidar_navigation_task.py:164-181) for the envs of
 // reset_mask: target = bounds_min + (bounds_max - bounds_min) * U(min_ratio, max_ratio); optional target_yaw =
 // U(-pi, pi); optional robot_prev_actions = 0.
@@ -110,6 +115,12 @@ static Ratio3 ratio3(const float *lo, const float *hi) {
   Ratio3 r;
   for (int c = 0; c < 3; ++c) { r.lo[c] = lo[c]; r.hi[c] = hi[c]; }
   return r;
+}
+
+extern "C" int agx_step_counter_advance(const AgxEnvBuffers *B, void *stream) {
+  AGX_REQUIRE(B && B->step_counter_dev, "agx_step_counter_advance: buf->step_counter_dev is not set");
+  hipLaunchKernelGGL(k_step_counter_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, const_cast<int32_t *>(B->step_counter_dev));
+  return check_launch("agx_step_counter_advance");
 }
 
 extern "C" int agx_reset_set(const AgxEnvBuffers *B, int n, int reset_on_collision, void *stream) {

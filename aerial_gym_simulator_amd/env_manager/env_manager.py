@@ -83,6 +83,7 @@ class EnvManager(BaseManager):
         self.keep_in_env = None
         self.step_counter = 0
         self._stream_cache = None
+        self._step_counter_dev = None
         self._lib = None
         self.populate_env(env_cfg=self.cfg, sim_cfg=self.sim_config)
         self.prepare_sim()
@@ -239,6 +240,15 @@ class EnvManager(BaseManager):
         R.tau_dec_min, R.tau_dec_max = rng["tau_dec"]
         R.kT_min, R.kT_max = rng["kT"]
         self._reset_args = R
+
+    def enable_device_step_counter(self):
+        """From now on the kernels read the env-step index from device memory (AgxEnvBuffers.step_counter_dev) instead of a
+        kernel argument: a captured step can be replayed.  The caller advances it with agx_step_counter_advance as the
+        last launch of every step (tasks do); the host copy `step_counter` keeps counting alongside."""
+        self._require_device()
+        if self._step_counter_dev is None:
+            self._step_counter_dev = torch.tensor([self.step_counter & 0x7FFFFFFF], dtype=torch.int32, device=self.device)
+            self._buffers.step_counter_dev = _lib.dptr(self._step_counter_dev)
 
     def bind_step_rows(self, rows, reward, signal=None):
         """Multi-GPU exchange rows (sharding.StepGather): `rows` [2, N, obs_dim + 3], one per step

@@ -85,23 +85,14 @@ class LiDARNavigationTask(NavigationTask):
             self.target_yaw[env_ids] = (2.0 * torch.pi) * rs.rand(n, tag="target_yaw") - torch.pi
             prev[env_ids] = 0.0
 
-    def step(self, actions):
-        env = self.sim_env
+    def _flip_host_state(self):
         self._cur ^= 1  # prev_action <- current_action without a copy
-        transformed_action = self.action_transformation_function(actions)
+
+    def _graph_key(self):
+        return super()._graph_key() + (self._cur,)
+
+    def _begin_step(self, transformed_action):
         self.current_action.copy_(transformed_action)
-        env.step(actions=transformed_action)
-        self.compute_rewards_and_crashes(self.obs_dict)
-        if self.task_config.return_state_before_reset:
-            return_tuple = self.get_return_tuple()
-        self._bookkeeping()
-        reset_envs = env.post_reward_calculation_step()
-        self._reset_targets(reset_envs)
-        self.num_task_steps += 1
-        self.process_image_observation()
-        if not self.task_config.return_state_before_reset:
-            return_tuple = self.get_return_tuple()
-        return return_tuple
 
     def compute_rewards_and_crashes(self, obs_dict):
         env = self.sim_env

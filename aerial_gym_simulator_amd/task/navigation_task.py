@@ -79,6 +79,11 @@ class NavigationTask(BaseTask):
         self._successes = torch.zeros(N, dtype=torch.bool, device=dev)
         self._timeouts = torch.zeros(N, dtype=torch.bool, device=dev)
         self._counters = torch.zeros(3, dtype=torch.int32, device=dev)
+        self._graphs, self._graph_action = None, None  # see _graph_mode()
+        import os
+
+        want = cfg.args.get("step_graph") if isinstance(cfg.args, dict) else None
+        self._graph_wanted = bool(want) if want is not None else os.environ.get("AGX_STEP_GRAPH", "0") == "1"
         self._min_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_min_ratio])
         self._max_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_max_ratio])
         self._fuse_with_env()
@@ -153,8 +158,8 @@ class NavigationTask(BaseTask):
         self.success_aggregate = self.crashes_aggregate = self.timeouts_aggregate = 0
         return True
 
-    def _bookkeeping(self):
-        """successes / timeouts / crashes of this step and the curriculum (navigation_task.py:311-330)."""
+    def _bookkeeping_device(self):
+        """successes / timeouts / crashes of this step (navigation_task.py:311-326) and the curriculum counters"""
         env = self.sim_env
         if env.strict_rng:  # reference-faithful: torch reductions and a host sync on the aggregates
             near = torch.norm(self.target_position - self.obs_dict["robot_position"], dim=1) < 1.0
@@ -168,8 +173,14 @@ class NavigationTask(BaseTask):
         _lib.check(env._lib.agx_nav_bookkeeping(env._buffers, env.num_envs, p(self.target_soa), 1.0, p(self._successes),
                                                 p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
         self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = self._successes, self._timeouts, self.terminations
-        if self.num_task_steps % self.curriculum_check_every == 0:
-            ns, nc, nt = self._counters.tolist()  # the only host sync of the task, every `curriculum_check_every` steps
+
+    def _bookkeeping_host(self):
+        """the curriculum (navigation_task.py:229-270): the only host synchronisation of the task, every
+        `curriculum_check_every` steps (the level applies from the next step on)"""
+        if self.sim_env.strict_rng:
+            return
+        if (self.num_task_steps - 1) % self.curriculum_check_every == 0:
+            ns, nc, nt = self._counters.tolist()
             if self._curriculum_decision(ns, nc, nt):
                 self._counters.zero_()
 
@@ -190,9 +201,25 @@ class NavigationTask(BaseTask):
     def _target_yaw_ptr(self):
         return None
 
+    # ------------------------------------------------------------------ stepping
     def step(self, actions):
-        env = self.sim_env
         transformed_action = self.action_transformation_function(actions)
+        if self._graph_mode():
+            return self._step_replayed(transformed_action)
+        self._flip_host_state()
+        ret = self._device_step(transformed_action)
+        self._finish_step_host()
+        return ret
+
+    def _flip_host_state(self):
+        """host-side state that alternates per step and decides which buffers the step's kernels are handed (none here;
+        the LiDAR task's action ring)"""
+
+    def _device_step(self, transformed_action):
+        """Everything task.step() puts on the device, in the reference's order (navigation_task.py:291-349), with no
+        host synchronisation in the sync-free mode: this is the region a hipGraph captures for small batches."""
+        env = self.sim_env
+        self._begin_step(transformed_action)
         if env.task_args is not None:
             env.task_args.curriculum_progress = float(self.curriculum_progress_fraction)
             env.task_args.episode_len = int(self.task_config.episode_len_steps)
@@ -200,15 +227,79 @@ class NavigationTask(BaseTask):
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
-        self._bookkeeping()
+        self._bookkeeping_device()
         reset_envs = env.post_reward_calculation_step()
         self._reset_targets(reset_envs)
-        self.num_task_steps += 1
         self.process_image_observation()
         self.post_image_reward_addition()
         if not self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
+        if env._step_counter_dev is not None:  # replayed steps read the step index from device memory
+            _lib.check(env._lib.agx_step_counter_advance(env._buffers, env._stream()), "agx_step_counter_advance")
         return return_tuple
+
+    def _begin_step(self, transformed_action):
+        pass
+
+    def _finish_step_host(self):
+        self.num_task_steps += 1
+        self._bookkeeping_host()
+
+    # ---- opt-in (args={"step_graph": True} / AGX_STEP_GRAPH=1): the step as a replayed hipGraph -----------------------
+    # In the sync-free mode the step has no host synchronisation and fixed buffers, so it can be captured once per
+    # (reset-flag parity, curriculum level[, action-ring slot]) and replayed: one launch per step instead of ~15.  What
+    # changes from step to step travels through memory: the action (a static buffer), the step index
+    # (AgxEnvBuffers.step_counter_dev).  Host-side curriculum logic runs between replays, exactly as in eager mode.
+    # Measured (profiles/r02_small_batch.txt): NO gain at 256 .. 1024 envs (319 vs 324 us per step at 256 envs) -- the step
+    # is bound by the GPU-side chain of small dependent kernels, not by their launches -- hence off by default; a caller
+    # who captures policy + step in one graph gets a capture-safe step either way.
+    GRAPH_WARMUP_STEPS = 3
+
+    def _graph_mode(self):
+        if self._graphs is None:  # decided once
+            env = self.sim_env
+            sensor = env.robot_manager.warp_sensor
+            ok = (self._graph_wanted and env._buffers is not None and not env.strict_rng and env.robot_manager.imu_sensor is None
+                  and (sensor is None or not sensor.cfg.sensor_noise.enable_sensor_noise)  # torch RNG ops in the step
+                  and env.cfg.env.num_physics_steps_per_env_step_std == 0)
+            self._graphs = {} if ok else False
+        if self._graphs is False:
+            return False
+        return self.num_task_steps >= self.GRAPH_WARMUP_STEPS  # the first steps run eagerly (lazy initialisation)
+
+    def _graph_key(self):
+        return (self.sim_env._parity ^ 1, self.curriculum_level)
+
+    def _step_replayed(self, transformed_action):
+        env = self.sim_env
+        if self._graph_action is None:
+            self._graph_action = torch.zeros_like(transformed_action)
+            env.enable_device_step_counter()
+        self._graph_action.copy_(transformed_action)
+        self._flip_host_state()
+        key = self._graph_key()
+        entry = self._graphs.get(key)
+        if entry is None:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):  # the capture performs the step's HOST effects (parity, counters), no device work
+                    ret = self._device_step(self._graph_action)
+                self._graphs[key] = (graph, ret)
+                graph.replay()
+            except Exception as e:  # noqa: BLE001  (capture is an optimisation: fall back to eager stepping for good)
+                logger.warning(f"hipGraph capture of the step failed ({type(e).__name__}: {e}); stepping eagerly")
+                self._graphs = False
+                ret = self._device_step(transformed_action)
+        else:
+            graph, ret = entry
+            env._new_call()
+            env._parity ^= 1  # what EnvManager.step does on the host (the kernels' copies are frozen in the graph)
+            env._buffers.flag_parity = env._parity
+            env.step_counter += 1
+            env._reward_fresh = env._obs_fresh = env._mask_fresh = False
+            graph.replay()
+        self._finish_step_host()
+        return ret
 
     def process_image_observation(self):
         pass  # the min-pooled latents are written by agx_obs_navigation

@@ -153,6 +153,9 @@ typedef struct AgxEnvBuffers {
   uint32_t *step_signal;
   float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
                             the body frame = allocator output + drag + disturbance; read by agx_imu_update */
+  const int32_t *step_counter_dev; /* optional, device memory: when set the kernels read the env-step index from here
+                            instead of `step_counter` (whose value is frozen in a captured hipGraph); advance it with
+                            agx_step_counter_advance as the last launch of the step                                    */
   int32_t env_index_base;/* global index of env 0 of these buffers (sharded runs: this rank owns global envs
                             [env_index_base, env_index_base + N)): first counter word of the device generator, so that
                             a draw is a function of (seed, GLOBAL env, episode | step, stream) whatever the sharding   */
@@ -270,6 +273,10 @@ int agx_reward_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const fl
 int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
                              const float *target_yaw, const float *u_vec, const float *u_euler,
                              const float *downsampled, int cells, float *obs, void *stream);
+
+/* *buf->step_counter_dev = (*buf->step_counter_dev + 1) mod 2^31, stream-ordered: the last node of an env step that is
+ * captured into a hipGraph and replayed (small batches are launch bound: ~15 launches per navigation step).           */
+int agx_step_counter_advance(const AgxEnvBuffers *buf, void *stream);
 
 /* The reset set of EnvManager.reset_terminated_and_truncated_envs (env_manager.py:364-371) from the flags as they are:
  * reset_mask = crashes * reset_on_collision | truncations, reset_flag[flag_parity] |= any.  For callers that did not

@@ -277,3 +277,45 @@ def test_bookkeeping_and_target_reset_kernels_vs_the_reference_task_glue():
                    "agx_nav_target_reset")
         assert np.array_equal(target.cpu().numpy().T, g["target_after"][t]), t
     assert want[0] > 100 and want[2] > 100
+
+
+@pytest.mark.parametrize("task_name,cfg_name", [("navigation_task", "navigation_task_config"),
+                                                ("lidar_navigation_task", "lidar_navigation_task_config")])
+def test_replayed_step_graph_equals_eager_stepping(task_name, cfg_name):
+    """Small batches replay the step as a hipGraph (one launch instead of ~15; task/navigation_task.py `_graph_mode`): same
+    seed, same actions, graph on vs off -> bit-identical observations, rewards, flags, images and states over 80 steps
+    that include resets (episodes of 9 steps), both reset-flag parities, the action ring of the LiDAR task and the
+    device-resident step counter behind the per-step noise streams."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import task_config as tc
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg = getattr(tc, cfg_name)
+    old = (cfg.episode_len_steps, cfg.args, cfg.device)
+    n = 48
+    tasks = []
+    try:
+        for use_graph in (False, True):
+            cfg.device, cfg.episode_len_steps = DEV, 9
+            cfg.args = {"rng_seed": 4242, "step_graph": use_graph}
+            t = task_registry.make_task(task_name, seed=6, num_envs=n, headless=True)
+            t.reset()
+            tasks.append(t)
+        eager, graphed = tasks
+        g = torch.Generator(device=DEV).manual_seed(1)
+        for step in range(80):
+            a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
+            outs = [t.step(a) for t in tasks]
+            torch.cuda.synchronize()
+            (o0, r0, te0, tr0, _), (o1, r1, te1, tr1, _) = outs
+            assert torch.equal(o0["observations"], o1["observations"]), step
+            assert torch.equal(r0, r1) and torch.equal(te0, te1) and torch.equal(tr0, tr1), step
+            assert torch.equal(eager.obs_dict["robot_state_tensor"], graphed.obs_dict["robot_state_tensor"]), step
+            assert torch.equal(eager.obs_dict["depth_range_pixels"], graphed.obs_dict["depth_range_pixels"]), step
+        assert graphed._graphs and len(graphed._graphs) >= 2  # both parities were captured and replayed
+        assert eager._graphs is False
+        assert int(graphed.sim_env.global_tensor_dict["episode_count"].sum()) >= 7 * n
+        assert graphed.sim_env.step_counter == eager.sim_env.step_counter == 80
+        assert int(graphed.sim_env._step_counter_dev[0]) == 80
+    finally:
+        cfg.episode_len_steps, cfg.args, cfg.device = old
