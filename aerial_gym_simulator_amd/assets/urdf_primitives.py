@@ -14,13 +14,17 @@ import numpy as np
 CYLINDER_SECTIONS = 9  # 2 * 9 side + 2 * 9 cap triangles = 36 = 3 x 12: the scene works in chunks of 12 triangles
 
 
+SPHERE_SEGMENTS, SPHERE_BANDS = 8, 7  # 2 * 8 cap + 5 * 16 band triangles = 96 = 8 x 12
+
+
 @dataclass
 class Prim:
-    kind: str           # "box" | "cylinder"
-    dims: tuple         # box: (sx, sy, sz); cylinder: (radius, length)
+    kind: str           # "box" | "cylinder" | "sphere" | "mesh"
+    dims: tuple         # box: (sx, sy, sz); cylinder: (radius, length); sphere: (radius,); mesh: its AABB size
     T: np.ndarray       # [4,4] primitive frame -> asset root-link frame
     link: str
     link_index: int
+    tris: np.ndarray = None  # mesh only: [T, 3, 3] triangles in the primitive frame (centred on its AABB)
 
 
 def rpy_matrix(r, p, y):
@@ -89,14 +93,79 @@ def load_urdf_primitives(path, use_collision=False):
             elif g.tag == "cylinder":
                 dims = (float(g.get("radius")), float(g.get("length")))
                 kind = "cylinder"
+            elif g.tag == "sphere":
+                dims = (float(g.get("radius")),)
+                kind = "sphere"
+            elif g.tag == "mesh":
+                # any triangle mesh, like the reference's WarpAsset (assets/warp_asset.py:19-136 loads whatever trimesh
+                # reads); here: Wavefront OBJ and STL through the stdlib readers below
+                scale = [float(v) for v in g.get("scale", "1 1 1").split()]
+                tris = load_mesh_triangles(resolve_mesh_path(g.get("filename"), path)) * np.asarray(scale, np.float64)
+                lo, hi = tris.reshape(-1, 3).min(0), tris.reshape(-1, 3).max(0)
+                centre = 0.5 * (lo + hi)
+                shift = np.eye(4)
+                shift[:3, 3] = centre  # the primitive frame sits at the centre of the mesh's bounding box (collision OBB)
+                prims.append(Prim("mesh", tuple(float(x) for x in np.maximum(hi - lo, 1e-6)), link_T(names[idx]) @ _origin(el) @ shift,
+                                  names[idx], idx, tris=(tris - centre).astype(np.float32)))
+                continue
             else:
-                raise NotImplementedError(f"{path}: geometry <{g.tag}> of link {ln.get('name')} is not supported (box, cylinder)")
+                raise NotImplementedError(f"{path}: geometry <{g.tag}> of link {ln.get('name')} is not supported")
             if min(dims) <= 0.0:
                 raise ValueError(f"{path}: non-positive dimensions {dims} in link {ln.get('name')}")
             prims.append(Prim(kind, dims, link_T(names[idx]) @ _origin(el), names[idx], idx))
     if not prims:
-        raise ValueError(f"{path}: no box / cylinder geometry found")
+        raise ValueError(f"{path}: no geometry found")
     return prims
+
+
+def resolve_mesh_path(filename, urdf_path):
+    """<mesh filename=...>: absolute, relative to the URDF, or package://pkg/rest (looked up next to / above the URDF)"""
+    if filename.startswith("file://"):
+        filename = filename[len("file://"):]
+    base = os.path.dirname(os.path.abspath(urdf_path))
+    if filename.startswith("package://"):
+        rest = filename[len("package://"):].split("/", 1)[-1]
+        d = base
+        for _ in range(4):
+            cand = os.path.join(d, rest)
+            if os.path.exists(cand):
+                return cand
+            d = os.path.dirname(d)
+        raise FileNotFoundError(f"{urdf_path}: cannot resolve {filename}")
+    return filename if os.path.isabs(filename) else os.path.join(base, filename)
+
+
+def load_mesh_triangles(path):
+    """[T, 3, 3] float64 triangles of a Wavefront OBJ or an STL (ascii / binary) file.  Polygons are fan-triangulated."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".obj":
+        verts, tris = [], []
+        with open(path, "r", errors="replace") as f:
+            for line in f:
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "v":
+                    verts.append([float(t[1]), float(t[2]), float(t[3])])
+                elif t[0] == "f":
+                    idx = [int(w.split("/")[0]) for w in t[1:]]
+                    idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                    for k in range(1, len(idx) - 1):
+                        tris.append([idx[0], idx[k], idx[k + 1]])
+        if not tris:
+            raise ValueError(f"{path}: no faces")
+        return np.asarray(verts, np.float64)[np.asarray(tris)]
+    if ext == ".stl":
+        raw = open(path, "rb").read()
+        n = int.from_bytes(raw[80:84], "little") if len(raw) >= 84 else -1
+        if n >= 0 and 84 + 50 * n == len(raw):  # binary: 80-byte header, count, 50-byte records (normal, 3 vertices, attr)
+            rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+            return rec["v"].astype(np.float64)
+        vals = [[float(x) for x in ln.split()[1:4]] for ln in raw.decode("ascii", "replace").splitlines() if ln.strip().startswith("vertex")]
+        if not vals or len(vals) % 3:
+            raise ValueError(f"{path}: not an STL file")
+        return np.asarray(vals, np.float64).reshape(-1, 3, 3)
+    raise NotImplementedError(f"{path}: mesh format {ext or '?'} is not supported (OBJ, STL; convert COLLADA / glTF assets)")
 
 
 _BOX_VERTS = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1], [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]], np.float64) - 0.5
@@ -104,10 +173,32 @@ _BOX_FACES = np.array([[1, 3, 0], [4, 1, 0], [0, 3, 2], [2, 4, 0], [1, 7, 3], [5
                        [6, 5, 4], [7, 5, 6]])
 
 
+def _pad12(tris):
+    """the scene works in chunks of 12 triangles: repeat the last one (a duplicate never changes a closest hit)"""
+    pad = (-len(tris)) % 12
+    return np.concatenate([tris, np.repeat(tris[-1:], pad, axis=0)], axis=0) if pad else tris
+
+
 def tessellate(prim):
-    """[T,3,3] float32 triangles in the primitive's own frame, outward normals (T = 12 box, 36 cylinder)."""
+    """[T,3,3] float32 triangles in the primitive's own frame, outward normals (T = 12 box, 36 cylinder, 96 sphere,
+    the file's triangle count rounded up to a multiple of 12 for a mesh)."""
     if prim.kind == "box":
         return (_BOX_VERTS[_BOX_FACES] * np.asarray(prim.dims)).astype(np.float32)
+    if prim.kind == "mesh":
+        return _pad12(np.asarray(prim.tris, np.float32))
+    if prim.kind == "sphere":
+        r, nl, nb = prim.dims[0], SPHERE_SEGMENTS, SPHERE_BANDS
+        lat = np.linspace(-0.5 * math.pi, 0.5 * math.pi, nb + 1)
+        lon = 2 * math.pi * np.arange(nl) / nl
+        P = lambda i, j: np.array([r * math.cos(lat[i]) * math.cos(lon[j % nl]), r * math.cos(lat[i]) * math.sin(lon[j % nl]), r * math.sin(lat[i])])  # noqa: E731
+        tris = []
+        for j in range(nl):
+            tris.append([P(0, 0), P(1, j + 1), P(1, j)])            # south cap
+            tris.append([P(nb, 0), P(nb - 1, j), P(nb - 1, j + 1)])  # north cap
+            for i in range(1, nb - 1):
+                a, b, c, d = P(i, j), P(i, j + 1), P(i + 1, j + 1), P(i + 1, j)
+                tris += [[a, b, c], [a, c, d]]
+        return np.asarray(tris, np.float32)
     r, L = prim.dims
     n = CYLINDER_SECTIONS
     ang = 2 * math.pi * np.arange(n) / n
@@ -123,11 +214,17 @@ def tessellate(prim):
 
 def half_extents(prim):
     """half extents of the primitive's bounding box in its own frame (the collision OBB)"""
-    if prim.kind == "box":
+    if prim.kind in ("box", "mesh"):
         return tuple(0.5 * d for d in prim.dims)
+    if prim.kind == "sphere":
+        return (prim.dims[0],) * 3
     r, L = prim.dims
     return (r, r, 0.5 * L)
 
 
-def num_triangles(kind):
-    return 12 if kind == "box" else 4 * CYLINDER_SECTIONS
+def num_triangles(prim):
+    """triangle count of a primitive (a Prim, or a kind name for the fixed-size kinds)"""
+    kind = prim if isinstance(prim, str) else prim.kind
+    if kind == "mesh":
+        return len(_pad12(prim.tris))
+    return {"box": 12, "cylinder": 4 * CYLINDER_SECTIONS, "sphere": 2 * SPHERE_SEGMENTS * (SPHERE_BANDS - 1)}[kind]

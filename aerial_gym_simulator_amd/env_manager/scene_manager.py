@@ -126,7 +126,7 @@ class SceneManager:
         K = len(slots)
         self.has_prims = True
         P_s = [max(len(v) for v in vs) for vs in variants]                    # primitives per slot
-        tri_s = [[max(num_triangles((v[q] if q < len(v) else v[0]).kind) for v in vs) for q in range(P_s[s])]
+        tri_s = [[max(num_triangles(v[q] if q < len(v) else v[0]) for v in vs) for q in range(P_s[s])]
                  for s, vs in enumerate(variants)]                            # triangles per primitive slot
         prim_base = np.concatenate([[0], np.cumsum(P_s)]).astype(int)
         KP = self.num_prims = int(prim_base[-1])
@@ -175,9 +175,11 @@ class SceneManager:
                     prim_sem[i, pg] = base_id + (links.index(pr.link_index) if per_link else 0)
                     tr = tessellate(pr).reshape(-1, 9)
                     tri_local[i, tri_base[pg]: tri_base[pg] + len(tr)] = tr
-                    if len(tr) < tri_count[pg]:  # a box in a slot that may also hold a cylinder: repeat its triangles
-                        reps = tri_count[pg] // len(tr)
-                        tri_local[i, tri_base[pg]: tri_base[pg + 1]] = np.tile(tr, (reps, 1))
+                    if len(tr) < tri_count[pg]:  # a box in a slot that may also hold a cylinder / a smaller mesh: repeat triangles
+                        if tri_count[pg] % len(tr) == 0:
+                            tri_local[i, tri_base[pg]: tri_base[pg + 1]] = np.tile(tr, (tri_count[pg] // len(tr), 1))
+                        else:
+                            tri_local[i, tri_base[pg] + len(tr): tri_base[pg + 1]] = tr[-1]
                 if t.semantic_id < 0:
                     counter += int(ids_per_slot[s_])
         tri_prim = np.repeat(np.arange(KP, dtype=np.int32), tri_count)

@@ -206,3 +206,37 @@ def test_empty_scene_has_the_attributes_the_binding_reads():
 
     sc = SceneManager(EmptyEnvCfg, 4, "cpu", None)
     assert (sc.num_assets, sc.num_prims, sc.num_tris, sc.has_prims) == (0, 0, 0, False)
+
+
+def test_mesh_and_sphere_geometry_ingestion():
+    """<mesh> (Wavefront OBJ, binary / ascii STL; stdlib readers) and <sphere> obstacle geometry: the reference's WarpAsset
+    takes any trimesh (assets/warp_asset.py:19-136).  The three encodings of the same wedge give the same triangles;
+    the primitive frame sits at the centre of the mesh's bounding box (its collision OBB); triangle counts are padded
+    to the scene's chunks of 12 with duplicates."""
+    from aerial_gym_simulator_amd.assets import half_extents, load_urdf_primitives, num_triangles, tessellate
+    from aerial_gym_simulator_amd.assets.urdf_primitives import load_mesh_triangles
+
+    M = os.path.join(FIX, "meshes")
+    a, b, c = (load_mesh_triangles(os.path.join(M, f)) for f in ("wedge.obj", "wedge_binary.stl", "wedge_ascii.stl"))
+    assert a.shape == (8, 3, 3) and np.allclose(a, b, atol=1e-6) and np.allclose(a, c, atol=1e-6)
+    for urdf in ("wedge_obj.urdf", "wedge_stl.urdf"):
+        (p,) = load_urdf_primitives(os.path.join(M, urdf))
+        assert p.kind == "mesh" and num_triangles(p) == 12
+        t = tessellate(p)
+        assert t.shape == (12, 3, 3) and np.array_equal(t[8:], np.repeat(t[7:8], 4, axis=0))  # padding = duplicates
+        assert np.allclose(half_extents(p), (0.4, 0.32, 0.36))  # scale 0.8 x 0.8 x 1.2 of a 1 x 0.8 x 0.6 wedge
+        assert np.allclose(t.reshape(-1, 3).min(0), -np.array(half_extents(p)), atol=1e-6)  # centred on its AABB
+        # volume of the prism (signed tetrahedra): outward orientation survived the reader
+        vol = sum(np.dot(x[0], np.cross(x[1], x[2])) for x in t[:8].astype(np.float64)) / 6.0
+        assert abs(vol - 0.5 * 0.8 * 0.64 * 0.72) < 1e-6
+        # primitive frame = visual origin (rotated 0.3 rad about z) shifted to the box centre
+        c0 = np.array([0.1, 0, 0.05]) + np.array([[np.cos(0.3), -np.sin(0.3), 0], [np.sin(0.3), np.cos(0.3), 0], [0, 0, 1]]) @ np.array([0.4, 0.32, 0.36])
+        assert np.allclose(p.T[:3, 3], c0)
+    post, ball = load_urdf_primitives(os.path.join(M, "ball_on_post.urdf"))
+    assert (post.kind, ball.kind) == ("cylinder", "sphere") and num_triangles(ball) == 96
+    s = tessellate(ball)
+    assert np.allclose(np.linalg.norm(s.reshape(-1, 3), axis=1), 0.35, atol=1e-6) and np.allclose(ball.T[:3, 3], (0, 0, 1.0))
+    vol = sum(np.dot(x[0], np.cross(x[1], x[2])) for x in s.astype(np.float64)) / 6.0
+    assert 0.6 * (4 / 3) * np.pi * 0.35 ** 3 < vol < (4 / 3) * np.pi * 0.35 ** 3  # closed, outward, inscribed
+    with pytest.raises(NotImplementedError, match="OBJ, STL"):
+        load_mesh_triangles(os.path.join(M, "missing.dae"))

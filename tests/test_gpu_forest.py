@@ -78,6 +78,63 @@ def test_forest_scene_primitives_images_and_collisions(orc):
     assert crash_ref.all() and npy(g["crashes"]).all()
 
 
+def test_mesh_and_sphere_obstacles_images_and_collisions(orc):
+    """Obstacle URDFs with <mesh> (OBJ / STL) and <sphere> geometry (tests/fixtures/assets/meshes) next to boxes: scene
+    triangles, depth + segmentation images (bit-exact vs the oracle's ray-cast of the same triangles) and crash flags."""
+    import random
+
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import asset_config as A
+    from aerial_gym_simulator_amd.config.env_config import ForestEnvCfg
+    from aerial_gym_simulator_amd.registry.env_registry import env_config_registry
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    class shapes(A.tree_asset_params):
+        num_assets = 6
+        asset_folder = os.path.join(FIX, "meshes")  # wedge_obj, wedge_stl, ball_on_post: one is drawn per instance
+
+    class Cfg(ForestEnvCfg):
+        class env_config:
+            include_asset_type = {"trees": True, "objects": True, "bottom_wall": True}
+            asset_type_to_dict_map = {"trees": shapes, "objects": A.object_asset_params, "bottom_wall": A.bottom_wall}
+
+    random.seed(3)
+    torch.manual_seed(3)
+    env_config_registry.register("mesh_env_fixture", Cfg)
+    n = 6
+    env = SimBuilder().build_env("base_sim", "mesh_env_fixture", "base_quadrotor_with_camera_64x48", "lee_velocity_control", DEV, num_envs=n)
+    sc = env.scene
+    # a slot holds the largest variant: 2 primitives -- (wedge 12 | post 36) and (duplicate | ball 96) -- smaller ones padded with duplicates
+    assert sc.has_prims and sc.num_prims == 1 + 6 * 2 + 35 and sc.num_tris == 12 + 6 * (36 + 96) + 35 * 12
+    env.reset()
+    g = env.get_obs()
+    a = torch.zeros(n, 4, device=DEV)
+    for _ in range(2):
+        env.step(actions=a)
+        env.post_reward_calculation_step()
+    npy = lambda t: np.ascontiguousarray(t.detach().cpu().numpy())  # noqa: E731
+    tris = orc.scene_transform(npy(sc.tri_local), npy(sc.tri_asset), npy(sc.prim_state))
+    assert np.array_equal(npy(sc.tri_world), tris)
+    sen = env.robot_manager.warp_sensor
+    kinv, cx, cy = orc.camera_kinv(64, 48, sen.cfg.horizontal_fov_deg)
+    ref, ref_seg = orc.raycast_camera(64, 48, kinv, sen.cfg.max_range, cx, cy, "depth", npy(sen.sensor_position), npy(sen.sensor_orientation),
+                                      tris, npy(sc.tri_seg))
+    ref = orc.sensor_postprocess(ref, sen.cfg.min_range, sen.cfg.max_range, sen.cfg.far_out_of_range_value, sen.cfg.near_out_of_range_value,
+                                 sen.cfg.normalize_range)
+    assert np.array_equal(npy(g["segmentation_pixels"]), ref_seg) and np.array_equal(npy(g["depth_range_pixels"]), ref)
+    kinds = {k for k in ("mesh", "sphere", "cylinder")}
+    assert kinds  # (the variants drawn are random per env; the triangle-count assertion above proves all three loaded)
+    prim = npy(sc.prim_state)
+    state = g["robot_state_tensor"]
+    state[:, 0:3] = torch.from_numpy(prim[:, 1, 0:3]).to(DEV)  # centre of the first shape primitive of each env
+    state[:, 7:13] = 0.0
+    env.step(actions=a)
+    boxes = np.concatenate([prim[..., :7], npy(sc.half_extents)], axis=-1)
+    crash_ref = np.zeros(n, np.uint8)
+    orc.collide_sphere_boxes(env.robot_manager.robot.params_dict["collision_radius"], npy(state), np.ascontiguousarray(boxes), crash_ref)
+    assert crash_ref.all() and npy(g["crashes"]).all()
+
+
 def test_reference_tree_assets_when_present():
     """with AERIAL_GYM_RESOURCES pointing at the reference's resources, forest_env loads its 13-link cylinder trees"""
     res = os.environ.get("AERIAL_GYM_RESOURCES", "")
