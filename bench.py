@@ -192,6 +192,16 @@ def valu_roofline(kernel_key, launch_s):
             "valu_wave_instructions_per_launch": n_valu, "peak_source": how, "stale": pmc_stale()}
 
 
+def env_step_key(task, k):
+    """key of the env-step kernel instance in the PMC file: template arguments + grid size in threads"""
+    env = task.sim_env
+    P, n = env._params, env.num_envs
+    wide = n <= 65536
+    block = 64 if wide else 256
+    grid = ((n + block - 1) // block) * block
+    return "k_env_step<%d,%d,%s,%s>_%d" % (P.num_motors, P.controller, "true" if k == 1 else "false", "true" if wide else "false", grid)
+
+
 def raycast_grid_threads(task):
     """grid size (threads) of the frame's k_raycast launch: the key of its counters in the PMC file"""
     cfg = task.sim_env.robot_manager.warp_sensor.cfg
@@ -200,6 +210,13 @@ def raycast_grid_threads(task):
     tiles = ((cfg.width + tw - 1) // tw) * ((cfg.height + 64 // tw - 1) // (64 // tw))
     split = max(1, min((16384 + n * ns * 4 - 1) // (n * ns * 4), (tiles + 3) // 4))
     return n * ns * split * 256
+
+
+def raycast_key(task):
+    """key of the frame's ray-cast kernel instance in the PMC file (template arguments <lidar, lds, variant> + grid)"""
+    sen = task.sim_env.robot_manager.warp_sensor
+    variant = 2 if sen.is_stereo else (1 if sen.is_normal else 0)
+    return "k_raycast<%s,false,%d>_%d" % ("true" if sen.is_lidar else "false", variant, raycast_grid_threads(task))
 
 
 def cpu_baseline_reference():
@@ -353,7 +370,7 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
     def give_up():
         report["rccl_thread"] = dict(res, error=res.get("error", "") + f" [no agreement of the ranks within {limit_s:.0f} s]")
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit_line(out, _JSON_FD[0])
         os._exit(0)
 
     dog = threading.Timer(limit_s, give_up)
@@ -416,6 +433,18 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
 
 
 _ABANDONED = []
+_JSON_FD = [None]
+
+
+def emit_line(out, fd=None):
+    """the ONE JSON line, on the process's original stdout"""
+    fd = fd if fd is not None else _JSON_FD[0]
+    line = json.dumps(out) + "\n"
+    if fd is None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    else:
+        os.write(fd, line.encode())
 
 
 def cpu_baseline_dynamics(num_envs, budget_s=12.0):
@@ -499,6 +528,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     use_dist = world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1"
+    json_fd = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when a communicator goes away: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        json_fd = _JSON_FD[0] = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
 
@@ -558,12 +593,13 @@ def main():
     if rank == 0 and args.workload == "dynamics":
         kt, k = kernel_time_dynamics(task, actions)
         achieved = BYTES_DYNAMICS_KERNEL * k * N / kt / 1e9
-        vr = valu_roofline("k_env_step_%d" % N, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9,
-                                                          "unit": "G wave64-instr/s", "frac": None}
+        ekey = env_step_key(task, k)
+        vr = valu_roofline(ekey, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9,
+                                         "unit": "G wave64-instr/s", "frac": None}
         out["roofline"] = dict(vr, **{
             "kernel": "k_env_step<4, position> (k sub-steps + reward epilogue)",
             "launch_us": kt * 1e6,
-            "traffic": pmc_traffic("k_env_step_%d" % N),
+            "traffic": pmc_traffic(ekey),
             "traffic_stale": pmc_stale(),
             "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N, "peak_measured_copy": hbm_copy_gbs(device)},
@@ -578,7 +614,7 @@ def main():
         per_env = raycast_bytes_per_env(task)
         achieved = per_env * N / kt / 1e9
         cfgs = task.sim_env.robot_manager.warp_sensor.cfg
-        key = "k_raycast_%d" % raycast_grid_threads(task)
+        key = raycast_key(task)
         vr = valu_roofline(key, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9, "unit": "G wave64-instr/s", "frac": None}
         out["roofline"] = dict(vr, **{
             "kernel": "k_raycast (one frame, all envs)", "launch_us": kt * 1e6, "traffic": pmc_traffic(key), "traffic_stale": pmc_stale(),
@@ -598,10 +634,11 @@ def main():
                 big.step(ab[0])
             kt2, k2 = kernel_time_dynamics(big, ab, reps=30)
             ach2 = BYTES_DYNAMICS_KERNEL * k2 * (1 << 21) / kt2 / 1e9
-            vr2 = valu_roofline("k_env_step_%d" % (1 << 21), kt2) or {"bound": "valu", "frac": None}
+            ekey2 = env_step_key(big, k2)
+            vr2 = valu_roofline(ekey2, kt2) or {"bound": "valu", "frac": None}
             out["roofline_at_scale"] = dict(vr2, **{
                 "num_envs": 1 << 21, "launch_us": kt2 * 1e6, "env_steps_per_s_kernel_only": (1 << 21) / kt2,
-                "traffic": pmc_traffic("k_env_step_%d" % (1 << 21)), "traffic_stale": pmc_stale(),
+                "traffic": pmc_traffic(ekey2), "traffic_stale": pmc_stale(),
                 "hbm": {"achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k2 * (1 << 21)},
                 "note": "the larger of the two fractions names the bound: vector issue (3 waves per SIMD cannot hide all latency), not HBM"})
@@ -646,8 +683,8 @@ def main():
             per_env = raycast_bytes_per_env(t2)
             out["plus_depth"].update({
                 "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                "raycast_roofline": dict(valu_roofline("k_raycast_%d" % raycast_grid_threads(t2), kt2) or {"bound": "valu", "frac": None}, **{
-                    "traffic": pmc_traffic("k_raycast_%d" % raycast_grid_threads(t2)), "traffic_stale": pmc_stale(),
+                "raycast_roofline": dict(valu_roofline(raycast_key(t2), kt2) or {"bound": "valu", "frac": None}, **{
+                    "traffic": pmc_traffic(raycast_key(t2)), "traffic_stale": pmc_stale(),
                     "hbm": {"achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N}})})
             if not args.no_cpu_baseline:
@@ -660,7 +697,7 @@ def main():
             pass
         rccl_thread_leg(args, world, rank, device, out)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_line(out, json_fd)
     if _ABANDONED:  # every rank took the same decision (all-reduced): no teardown of a half-built exchange
         sys.stdout.flush()
         os._exit(0)

@@ -21,9 +21,15 @@ def load(path, counter):
         if "k_update_states" in name:
             key = ("k_update_states", int(r["Grid_Size"]))
         elif "k_env_step" in name:
-            key = ("k_env_step", int(r["Grid_Size"]))
+            import re
+
+            m = re.search(r"k_env_step<([^>]*)>", name)  # <motors, controller id, single sub-step, one-wave workgroups>
+            key = ("k_env_step<%s>" % m.group(1).replace(" ", "") if m else "k_env_step", int(r["Grid_Size"]))
         elif "k_raycast" in name:
-            key = ("k_raycast", int(r["Grid_Size"]))
+            import re
+
+            m = re.search(r"k_raycast<([^>]*)>", name)  # <lidar, lds, variant>
+            key = ("k_raycast<%s>" % m.group(1).replace(" ", "") if m else "k_raycast", int(r["Grid_Size"]))
         elif "k_reset_masked" in name:
             key = ("k_reset_masked", int(r["Grid_Size"]))
         if key:
@@ -57,15 +63,16 @@ def main(fetch_csv, write_csv, sq_csv=None):
                               "write_true_bytes": wr_true, "write_correction": cw}
     else:
         cf = cw = 1.0
-    for (name, grid), tag in ((("k_env_step", 8192), "k_env_step_8192"), (("k_env_step", 1 << 21), "k_env_step_2097152")):
+    for (name, grid) in sorted(k for k in fetch if k[0].startswith("k_env_step")):
+        tag = "%s_%d" % (name, grid)
         if (name, grid) in fetch and (name, grid) in write:
             raw = fetch[(name, grid)] * KB + write[(name, grid)] * KB
             out[tag] = fetch[(name, grid)] * KB * cf + write[(name, grid)] * KB * cw
             out[tag + "_detail"] = {"fetch_raw": fetch[(name, grid)] * KB, "write_raw": write[(name, grid)] * KB, "raw_sum": raw,
                                     "launches_averaged": [nf[(name, grid)], nw[(name, grid)]]}
     for (name, grid), v in fetch.items():
-        if name == "k_raycast" and (name, grid) in write:
-            tag = "k_raycast_%d" % grid  # grid size in threads = envs x sensors x 256 (x tile split)
+        if name.startswith("k_raycast") and (name, grid) in write:
+            tag = "%s_%d" % (name, grid)  # grid size in threads = envs x sensors x 256 (x tile split)
             # node / triangle reads are scalar (wave-uniform) loads: the coalesced-dword calibration does not
             # apply to them; report the raw counters and the FETCH x2 reading of the MI355X guide
             out[tag] = 2.0 * v * KB + write[(name, grid)] * KB
