@@ -1,4 +1,5 @@
 """Moving obstacles through env_actions (reference: examples/dynamic_env_example.py:33-45)."""
+import os
 import torch
 
 import aerial_gym_simulator_amd  # noqa: F401
@@ -12,7 +13,7 @@ if __name__ == "__main__":
     env.reset()
     g = env.get_obs()
     twist = torch.zeros((n, K, 6), device="cuda:0")
-    for i in range(1000):
+    for i in range(int(os.environ.get("AGX_EXAMPLE_STEPS", 1000))):
         twist[:, :, 0] = torch.sin(torch.tensor(0.2 * i))
         twist[:, :, 1] = torch.cos(torch.tensor(0.2 * i))
         env.step(actions=actions, env_actions=twist)

@@ -1,4 +1,5 @@
 """IMU stream of a hovering quadrotor (reference: examples/imu_data_collection.py)."""
+import os
 import torch
 
 import aerial_gym_simulator_amd  # noqa: F401
@@ -11,7 +12,7 @@ if __name__ == "__main__":
     g = env.get_obs()
     target = torch.cat([g["robot_position"].clone(), torch.zeros(env.num_envs, 1, device="cuda:0")], dim=1)
     log = []
-    for i in range(2000):
+    for i in range(int(os.environ.get("AGX_EXAMPLE_STEPS", 2000))):
         env.step(actions=target)
         log.append(g["imu_measurement"][0].clone())
     data = torch.stack(log)[500:]

@@ -1,4 +1,5 @@
 """Depth-camera navigation task with random actions (reference: examples/navigation_task_example.py)."""
+import os
 import time
 
 import torch
@@ -11,7 +12,7 @@ if __name__ == "__main__":
     task.reset()
     n = task.num_envs
     t0 = time.time()
-    for i in range(1000):
+    for i in range(int(os.environ.get("AGX_EXAMPLE_STEPS", 1000))):
         actions = torch.rand((n, 4), device="cuda:0") * 2 - 1
         obs, reward, terminated, truncated, info = task.step(actions)
         if i % 200 == 199:

@@ -1,4 +1,5 @@
 """Lee position control of 64 quadrotors towards random set-points (reference: examples/position_control_example.py)."""
+import os
 import torch
 
 import aerial_gym_simulator_amd  # noqa: F401
@@ -10,7 +11,7 @@ if __name__ == "__main__":
     actions = torch.zeros((env.num_envs, 4), device="cuda:0")
     env.reset()
     g = env.get_obs()
-    for i in range(3000):
+    for i in range(int(os.environ.get("AGX_EXAMPLE_STEPS", 3000))):
         if i % 1000 == 0:
             actions[:, 0:3] = 0.6 * (torch.rand_like(actions[:, 0:3]) * 2 - 1)   # stay inside the +-1 m env
             actions[:, 3] = torch.pi * (torch.rand_like(actions[:, 3]) * 2 - 1)

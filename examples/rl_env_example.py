@@ -1,4 +1,5 @@
 """The task interface an RL library drives (reference: examples/rl_env_example.py)."""
+import os
 import time
 
 import torch
@@ -12,7 +13,7 @@ if __name__ == "__main__":
     actions = torch.zeros((task.num_envs, task.task_config.action_space_dim), device="cuda:0")
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(5000):
+    for i in range(int(os.environ.get("AGX_EXAMPLE_STEPS", 5000))):
         obs, reward, terminated, truncated, info = task.step(actions)
         if i % 1000 == 999:
             print(f"step {i + 1}: mean reward {float(reward.mean()):.3f}, resets so far "
