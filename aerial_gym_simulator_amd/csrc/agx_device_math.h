@@ -43,8 +43,17 @@ AGX_DEV V3 qvec(Q4 q) { return V3{q.x, q.y, q.z}; }
 AGX_DEV Q4 conj(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
 
 // torch `%` with a positive modulus (remainder, sign of divisor) -- utils/math.py:144-152
+// fmodf(a, m) is exact by definition; for |a| < 2m it is a, a - m or a + m -- and those subtractions are exact too
+// (Sterbenz: m <= |a| < 2m) -- so the angles of this path (|a| < 4 pi) take three instructions instead of ocml's
+// general remainder loop (~40): same bits.
+AGX_DEV float fmod_exact(float a, float m) {
+  const float aa = fabsf(a);
+  if (aa < m) return a;
+  if (aa < 2.0f * m) return a < 0.0f ? a + m : a - m;
+  return fmodf(a, m);
+}
 AGX_DEV float pymod(float a, float m) {
-  float r = fmodf(a, m);
+  float r = fmod_exact(a, m);
   if (r != 0.0f && (r < 0.0f)) r += m;
   return r;
 }
@@ -210,6 +219,14 @@ AGX_DEV Q4 quat_from_euler(float roll, float pitch, float yaw) {
   q.y = cy * cr * sp + sy * sr * cp;
   q.z = sy * cr * cp - cy * sr * sp;
   return q;
+}
+// vehicle_frame_quat_from_quat (utils/math.py:176-180): quat_from_euler(0 * roll, 0 * pitch, yaw).  With finite roll and
+// pitch the two half angles are +-0, their sines +-0 and cosines exactly 1, and every product / sum of the general formula
+// collapses to (0, 0, sin(yaw / 2), cos(yaw / 2)) up to the sign of a zero: one sincos instead of three, equal values.
+AGX_DEV Q4 quat_from_yaw(float yaw) {
+  float sy, cy;
+  sincos_bounded(yaw * 0.5f, sy, cy);
+  return Q4{0.0f, 0.0f, sy, cy};
 }
 // utils/math.py:124-146, angles in [0, 2 pi)
 AGX_DEV V3 euler_xyz_0_2pi(Q4 q) {

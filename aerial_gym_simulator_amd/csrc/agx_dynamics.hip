@@ -149,7 +149,7 @@ AGX_DEV Derived update_states(const EnvState &s) {
   V3 e = euler_xyz_0_2pi(s.q);
   d.euler = V3{ssa(e.x), ssa(e.y), ssa(e.z)};
   // vehicle_frame_quat_from_quat: euler * [0, 0, 1] (utils/math.py:176-180)
-  d.qveh = quat_from_euler(e.x * 0.0f, e.y * 0.0f, e.z * 1.0f);
+  d.qveh = quat_from_yaw(e.z * 1.0f);  // = quat_from_euler(e.x * 0, e.y * 0, e.z * 1), see agx_device_math.h
   d.vveh = quat_rotate_inverse(d.qveh, s.v);
   d.vbody = quat_rotate_inverse(s.q, s.v);
   d.wbody = quat_rotate_inverse(s.q, s.w);
@@ -157,20 +157,24 @@ AGX_DEV Derived update_states(const EnvState &s) {
 }
 
 // base_lee_controller.py:120-134
+// ZERO_VEL: the caller's velocity set-point is the constant 0 (position / fully actuated control): rotating it gives 0
+template <bool ZERO_VEL = false>
 AGX_DEV V3 compute_acceleration(const EnvState &s, Q4 qveh, V3 sp_pos, V3 sp_vel, const Gains &g) {
-  V3 sp_vel_w = quat_rotate(qveh, sp_vel);
+  V3 sp_vel_w = ZERO_VEL ? V3{0.0f, 0.0f, 0.0f} : quat_rotate(qveh, sp_vel);
   V3 pe = sp_pos - s.p;
   V3 ve = sp_vel_w - s.v;
   return V3{g.kp.x * pe.x + g.kv.x * ve.x, g.kp.y * pe.y + g.kv.y * ve.y, g.kp.z * pe.z + g.kv.z * ve.z};
 }
 
 // base_lee_controller.py:136-154 (sp_w.z is clamped in place by the caller-visible ref)
+// ZERO_RATE: the caller's angular-velocity set-point is the constant 0
+template <bool ZERO_RATE = false>
 AGX_DEV V3 compute_body_torque(const AgxRobotParams &P, Q4 q, V3 wb, Q4 qd, V3 &sp_w, const Gains &g) {
   sp_w.z = fminf(fmaxf(sp_w.z, -P.max_yaw_rate), P.max_yaw_rate);
   Q4 qe = quat_mul(conj(q), qd);
   M33 R = quat_to_rotmat(qe);
   V3 rot_err = V3{0.5f * (-(R.m21 - R.m12)), 0.5f * (R.m20 - R.m02), 0.5f * (-(R.m10 - R.m01))};
-  V3 wsp_b = quat_rotate(qe, sp_w);
+  V3 wsp_b = ZERO_RATE ? V3{0.0f, 0.0f, 0.0f} : quat_rotate(qe, sp_w);
   V3 Jw = V3{P.inertia[0] * wb.x + P.inertia[1] * wb.y + P.inertia[2] * wb.z,
              P.inertia[3] * wb.x + P.inertia[4] * wb.y + P.inertia[5] * wb.z,
              P.inertia[6] * wb.x + P.inertia[7] * wb.y + P.inertia[8] * wb.z};
@@ -219,13 +223,13 @@ AGX_DEV Wrench run_controller(const AgxRobotParams &P, const EnvState &s, const 
   const V3 zero = V3{0, 0, 0};
   switch (CTRL) {
     case AGX_CTRL_POSITION: {  // position_control.py:20-51
-      V3 acc = compute_acceleration(s, d.qveh, V3{a[0], a[1], a[2]}, zero, g);
+      V3 acc = compute_acceleration<true>(s, d.qveh, V3{a[0], a[1], a[2]}, zero, g);
       V3 f = (acc - grav) * m;
       M33 R = quat_to_rotmat(s.q);
       w.f.z = f.x * R.m02 + f.y * R.m12 + f.z * R.m22;
       Q4 qd = desired_orientation_pos_vel(f, a[3]);
       V3 wsp = zero;
-      w.t = compute_body_torque(P, s.q, d.wbody, qd, wsp, g);
+      w.t = compute_body_torque<true>(P, s.q, d.wbody, qd, wsp, g);
     } break;
     case AGX_CTRL_VELOCITY: {  // velocity_control.py:18-51
       V3 acc = compute_acceleration(s, d.qveh, s.p, V3{a[0], a[1], a[2]}, g);
@@ -269,11 +273,11 @@ AGX_DEV Wrench run_controller(const AgxRobotParams &P, const EnvState &s, const 
       float nq = sqrtf(a[3] * a[3] + a[4] * a[4] + a[5] * a[5] + a[6] * a[6]);
       nq = nq < 1e-9f ? 1e-9f : nq;
       a[3] = a[3] / nq; a[4] = a[4] / nq; a[5] = a[5] / nq; a[6] = a[6] / nq;
-      V3 acc = compute_acceleration(s, d.qveh, V3{a[0], a[1], a[2]}, zero, g);
+      V3 acc = compute_acceleration<true>(s, d.qveh, V3{a[0], a[1], a[2]}, zero, g);
       V3 f = (acc - grav) * m;
       w.f = quat_rotate_inverse(s.q, f);
       V3 wsp = zero;
-      w.t = compute_body_torque(P, s.q, d.wbody, Q4{a[3], a[4], a[5], a[6]}, wsp, g);
+      w.t = compute_body_torque<true>(P, s.q, d.wbody, Q4{a[3], a[4], a[5], a[6]}, wsp, g);
     } break;
     default: break;
   }
@@ -496,6 +500,11 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
     Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
     const bool root_link = P.root_link_mode != 0;
     const int sub_base = (B.launch_flags >> 8) & 0xFF;  // physics sub-step this launch starts at (split env steps)
+    bool has_drag = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      has_drag = has_drag || P.lin_drag_linear[c] != 0.0f || P.lin_drag_quadratic[c] != 0.0f || P.ang_drag_linear[c] != 0.0f ||
+                 P.ang_drag_quadratic[c] != 0.0f;
     V3 tlo = s.p, thi = s.p;
     for (int sub = 0; sub < k; ++sub) {
       d = update_states(s);
@@ -525,8 +534,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         for (int j = 0; j < M; ++j) acc += (root_link ? P.alloc[M * r + j] : P.wrench_map[M * r + j]) * u[j];
         bw[r] = acc;
       }
-      // simulate_drag (base_multirotor.py:260-285), pre-physics body velocities
-      {
+      // simulate_drag (base_multirotor.py:260-285), pre-physics body velocities; all-zero coefficients (base quadrotor)
+      // add +-0 to every component: skipped (a scalar test of kernel arguments)
+      if (has_drag) {
         float vbn = norm(d.vbody);
         bw[0] += (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
         bw[1] += (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
