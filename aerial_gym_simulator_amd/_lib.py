@@ -166,6 +166,11 @@ class AgxResetArgs(C.Structure):
     ]
 
 
+class AgxRangeLimits(C.Structure):
+    _fields_ = [("min_range", C.c_float), ("max_range", C.c_float), ("far_oor", C.c_float), ("near_oor", C.c_float),
+                ("normalize", C.c_int32)]
+
+
 class AgxPositionStepPlan(C.Structure):
     _fields_ = [
         ("params", C.POINTER(AgxRobotParams)),
@@ -179,7 +184,7 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 6  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 7  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -195,7 +200,7 @@ _SIGNATURES = {
         [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.POINTER(C.c_float), C.c_float, _P, _P, C.c_int, C.c_int, _P, _P],
     ),
     "agx_obs_navigation": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, _P, _P]),
+                                     C.c_int, C.c_int, _P, _P, _P]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
     "agx_post_step_position": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P]),
     "agx_position_task_step": (C.c_int, [C.POINTER(AgxPositionStepPlan), _P, _P]),
@@ -219,16 +224,16 @@ _SIGNATURES = {
     "agx_raycast_camera": (
         C.c_int,
         [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P,
-         C.c_int, _P, _P, _P],
+         C.c_int, _P, _P, C.POINTER(AgxRangeLimits), _P],
     ),
     "agx_raycast_stereo_camera": (
         C.c_int,
         [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _P, _P, _P,
-         _P, _P, C.c_int, _P, _P, _P],
+         _P, _P, C.c_int, _P, _P, C.POINTER(AgxRangeLimits), _P],
     ),
     "agx_raycast_lidar": (
         C.c_int,
-        [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P],
+        [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, C.POINTER(AgxRangeLimits), _P],
     ),
     "agx_sensor_postprocess": (
         C.c_int,

@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
 AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target,
                                 const float *__restrict__ u_vec, const float *__restrict__ u_euler,
                                 const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw, int obs_dim,
-                                float *__restrict__ obs) {
+                                float *__restrict__ obs, float *__restrict__ min_pixel) {
   const int lane = threadIdx.x & 63;
   float *o = obs + (size_t)i * obs_dim;
   float *row = B.step_rows[B.flag_parity] ? B.step_rows[B.flag_parity] + (size_t)i * (obs_dim + 3) : nullptr;
@@ -779,26 +779,60 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     }
   }
   if (pixels) {
+    // gh x gw min-pool of sensor 0's image as a COALESCED sweep: the wave reads 64 consecutive pixels of a row per load
+    // (each lane keeps the minimum of its column over the rows of the cell row), then the columns of one cell are
+    // reduced across lanes.  min is exact and order-free, so any arrangement gives the bits of the serial loop.
     const float *img = pixels + (size_t)i * ns * H * W;  // sensor 0
     const int ch = (H + gh - 1) / gh, cw = (W + gw - 1) / gw;
-    for (int cell = lane; cell < gh * gw; cell += 64) {
-      int cy = cell / gw, cx = cell % gw;
-      float m = INFINITY;
-      for (int y = cy * ch; y < min((cy + 1) * ch, H); ++y)
-        for (int x = cx * cw; x < min((cx + 1) * cw, W); ++x) m = fminf(m, img[(size_t)y * W + x]);
-      if (17 + cell < obs_dim) {
-        o[17 + cell] = m;
-        if (row) row_store(row + 17 + cell, m);
+    const bool pow2 = (cw & (cw - 1)) == 0 && cw < 64;
+    float imin = INFINITY;  // NavigationTask.post_image_reward_addition on the same sweep (min_pixel != NULL, ns == 1)
+    for (int cy = 0; cy < gh; ++cy) {
+      const int y0 = cy * ch, y1 = min(y0 + ch, H);
+      float cell = INFINITY;  // lane c < gw: cell (cy, c)
+      for (int x0 = 0; x0 < W && y0 < y1; x0 += 64) {
+        const int x = x0 + lane;
+        float m = INFINITY;
+        if (x < W) {
+          for (int y = y0; y < y1; ++y) {
+            const float v = img[(size_t)y * W + x];
+            m = fminf(m, v);
+            float v10 = 10.0f * v;
+            if (v10 < 0.0f) v10 = 10.0f;
+            imin = fminf(imin, v10);
+          }
+        }
+        if (pow2) {  // cells are aligned groups of cw lanes: butterfly inside the group, lane c fetches its group's value
+          for (int sft = 1; sft < cw; sft <<= 1) m = fminf(m, __shfl_xor(m, sft));
+          const int src = lane * cw - x0;
+          const float t = __shfl(m, src & 63);
+          if (src >= 0 && src < 64 && lane < gw) cell = fminf(cell, t);
+        } else {
+          const int c_lo = x0 / cw, c_hi = min(x0 + 63, W - 1) / cw;
+          for (int c = c_lo; c <= c_hi; ++c) {  // wave-uniform: the cells this 64-pixel chunk touches
+            float t = (x < W && x / cw == c) ? m : INFINITY;
+            for (int off = 32; off > 0; off >>= 1) t = fminf(t, __shfl_xor(t, off));
+            if (lane == c) cell = fminf(cell, t);
+          }
+        }
       }
+      const int k = 17 + cy * gw + lane;
+      if (lane < gw && k < obs_dim) {
+        o[k] = cell;
+        if (row) row_store(row + k, cell);
+      }
+    }
+    if (min_pixel) {
+      for (int off = 32; off > 0; off >>= 1) imin = fminf(imin, __shfl_xor(imin, off));
+      if (lane == 0) min_pixel[i] = imin;
     }
   }
 }
 __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
                                                          const float *__restrict__ u_vec, const float *__restrict__ u_euler,
                                                          const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
-                                                         int obs_dim, float *__restrict__ obs) {
+                                                         int obs_dim, float *__restrict__ obs, float *__restrict__ min_pixel) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per env
-  if (i < n) obs_navigation_env(B, n, i, target, u_vec, u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs);
+  if (i < n) obs_navigation_env(B, n, i, target, u_vec, u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel);
   step_rows_signal(B);
 }
 
@@ -1172,14 +1206,15 @@ extern "C" int agx_reward_navigation(const AgxEnvBuffers *B, int n, const float 
 
 extern "C" int agx_obs_navigation(const AgxEnvBuffers *B, int n, const float *target, const float *u_vec,
                                   const float *u_euler, const float *pixels, int ns, int H, int W, int gh, int gw,
-                                  int obs_dim, float *obs, void *stream) {
+                                  int obs_dim, float *obs, float *min_pixel, void *stream) {
   if (int e = check_common(nullptr, B, n)) return e;
+  AGX_REQUIRE(!min_pixel || (pixels && ns == 1), "min_pixel: needs the image, and covers it only with one sensor");
   AGX_REQUIRE(target && obs && B->state && B->derived && B->actions, "null buffer");
   AGX_REQUIRE((u_vec == nullptr) == (u_euler == nullptr), "u_vec and u_euler: both tensors or both NULL (device generator)");
   AGX_REQUIRE(obs_dim >= 17, "obs_dim must be >= 17");
   AGX_REQUIRE(!pixels || (ns > 0 && H > 0 && W > 0 && gh > 0 && gw > 0), "bad image sizes");
   hipLaunchKernelGGL(k_obs_navigation, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec,
-                     u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs);
+                     u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel);
   return check_launch("agx_obs_navigation");
 }
 

@@ -272,6 +272,20 @@ struct LidarArgs {
   int mode;
 };
 
+// WarpSensor.apply_range_limits + normalize_observation (warp_sensor.py:216-247) on the scalar pixel before it is stored:
+// the operations of k_sensor_postprocess without noise, in its order, so the image needs no second pass
+struct RangeEpilogue {
+  int enabled;
+  float min_range, max_range, far_oor, near_oor;
+  int normalize;
+};
+AGX_DEV float apply_range_limits(const RangeEpilogue &RL, float p) {
+  if (p > RL.max_range) p = RL.far_oor;
+  if (p < RL.min_range) p = RL.near_oor;
+  if (RL.normalize) p = p / RL.max_range;
+  return p;
+}
+
 // VARIANT: what happens after the closest hit is known
 //   RAY_BASIC   depth / range / point cloud (+ segmentation)             warp_camera_kernels.py:176-282, warp_lidar_kernels.py
 //   RAY_NORMAL  geometric normal + face index                           warp_camera_kernels.py:70-121, warp_lidar_kernels.py:90-126
@@ -287,7 +301,7 @@ constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
 #define AGX_RAY_STEREO_WAVES 8
 #endif
 template <bool LIDAR, bool USE_LDS, int VARIANT>
-__global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : 1) k_raycast(CamArgs CA, LidarArgs LA, const float *__restrict__ ray_vectors,
+__global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : 1) k_raycast(CamArgs CA, LidarArgs LA, RangeEpilogue RL, const float *__restrict__ ray_vectors,
                                                           const float *__restrict__ sensor_pos,
                                                           const float *__restrict__ sensor_quat,
                                                           const float *__restrict__ tri_world,
@@ -398,7 +412,7 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
         }
       }
       if (mode <= AGX_RAY_DEPTH) {
-        pixels[px] = dist;
+        pixels[px] = RL.enabled ? apply_range_limits(RL, dist) : dist;
       } else if (mode == AGX_RAY_POINTCLOUD_WORLD) {
         pixels[3 * px] = ro.x + dist * rd.x;
         pixels[3 * px + 1] = ro.y + dist * rd.y;
@@ -506,10 +520,15 @@ static size_t ray_lds_bytes(int nt) {
 }
 
 template <bool LIDAR, int VARIANT>
-static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *ray_vectors, const float *pos, const float *quat,
+static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const AgxRangeLimits *limits, const float *ray_vectors, const float *pos, const float *quat,
                           const float *tri_world, const int32_t *tri_seg, const float *nodes, int nt, float *pixels,
                           int32_t *seg, void *stream) {
   const int n = LIDAR ? LA.n : CA.n, ns = LIDAR ? LA.ns : CA.ns;
+  RangeEpilogue RL{};
+  if (limits) {
+    AGX_REQUIRE((LIDAR ? LA.mode : CA.mode) <= AGX_RAY_DEPTH, "range limits are fused for scalar images only (modes RANGE / DEPTH)");
+    RL = RangeEpilogue{1, limits->min_range, limits->max_range, limits->far_oor, limits->near_oor, limits->normalize};
+  }
   size_t lds = ray_lds_bytes(nt);
 #if AGX_RAY_USE_LDS
   static bool attr_set = false;
@@ -530,13 +549,13 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const float *r
   dim3 grid(n, ns, AGX_RAY_USE_LDS ? 1 : split);
 #if AGX_RAY_USE_LDS  // experimental builds only: the LDS-staged kernels are not instantiated otherwise
   if (lds <= 160 * 1024) {
-    hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, ray_vectors,
+    hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, RL, ray_vectors,
                        pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
     return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
   }
 #endif
   (void)lds;  // default: traverse from L2 with wave-uniform loads
-  hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, ray_vectors,
+  hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, RL, ray_vectors,
                      pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
   return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
 }
@@ -569,7 +588,7 @@ extern "C" int agx_sensor_pose(const AgxEnvBuffers *B, int n, int ns, const floa
 extern "C" int agx_raycast_camera(int n, int ns, int width, int height, const float *kinv, float far_plane, int c_x, int c_y,
                                   int mode, const float *cam_pos, const float *cam_quat, const float *tri_world,
                                   const int32_t *tri_seg, const float *nodes, int nt, float *pixels, int32_t *seg,
-                                  void *stream) {
+                                  const AgxRangeLimits *limits, void *stream) {
   AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
   AGX_REQUIRE(mode >= AGX_RAY_RANGE && mode <= AGX_RAY_NORMAL_WORLD, "bad mode %d", mode);
   AGX_REQUIRE(kinv && cam_pos && cam_quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
@@ -577,26 +596,27 @@ extern "C" int agx_raycast_camera(int n, int ns, int width, int height, const fl
   CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode, 0.0f};  // kinv: HOST pointer
   LidarArgs LA{};
   if (mode >= AGX_RAY_NORMAL)
-    return launch_raycast<false, RAY_NORMAL>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
-  return launch_raycast<false, RAY_BASIC>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+    return launch_raycast<false, RAY_NORMAL>(CA, LA, limits, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<false, RAY_BASIC>(CA, LA, limits, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
 }
 
 extern "C" int agx_raycast_stereo_camera(int n, int ns, int width, int height, const float *kinv, float far_plane, float baseline,
                                          int c_x, int c_y, int mode, const float *cam_pos, const float *cam_quat,
                                          const float *tri_world, const int32_t *tri_seg, const float *nodes, int nt,
-                                         float *pixels, int32_t *seg, void *stream) {
+                                         float *pixels, int32_t *seg, const AgxRangeLimits *limits, void *stream) {
   AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
   AGX_REQUIRE(mode >= AGX_RAY_RANGE && mode <= AGX_RAY_POINTCLOUD_WORLD, "bad mode %d", mode);
   AGX_REQUIRE(kinv && cam_pos && cam_quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
   AGX_REQUIRE(!seg || tri_seg, "segmentation output needs tri_seg");
   CamArgs CA{n, ns, width, height, kinv[0], kinv[1], kinv[2], kinv[3], far_plane, c_x, c_y, mode, baseline};
   LidarArgs LA{};
-  return launch_raycast<false, RAY_STEREO>(CA, LA, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<false, RAY_STEREO>(CA, LA, limits, nullptr, cam_pos, cam_quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
 }
 
 extern "C" int agx_raycast_lidar(int n, int ns, int width, int height, const float *ray_vectors, float far_plane, int mode,
                                  const float *pos, const float *quat, const float *tri_world, const int32_t *tri_seg,
-                                 const float *nodes, int nt, float *pixels, int32_t *seg, void *stream) {
+                                 const float *nodes, int nt, float *pixels, int32_t *seg, const AgxRangeLimits *limits,
+                                 void *stream) {
   AGX_REQUIRE(n > 0 && ns > 0 && width > 0 && height > 0 && nt >= 1, "bad sizes");
   AGX_REQUIRE(mode == AGX_RAY_RANGE || (mode >= AGX_RAY_POINTCLOUD && mode <= AGX_RAY_NORMAL_WORLD), "bad mode %d", mode);
   AGX_REQUIRE(ray_vectors && pos && quat && tri_world && pixels && (nt == 1 || nodes), "null buffer");
@@ -604,8 +624,8 @@ extern "C" int agx_raycast_lidar(int n, int ns, int width, int height, const flo
   CamArgs CA{};
   LidarArgs LA{n, ns, width, height, far_plane, mode};
   if (mode >= AGX_RAY_NORMAL)
-    return launch_raycast<true, RAY_NORMAL>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
-  return launch_raycast<true, RAY_BASIC>(CA, LA, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+    return launch_raycast<true, RAY_NORMAL>(CA, LA, limits, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
+  return launch_raycast<true, RAY_BASIC>(CA, LA, limits, ray_vectors, pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg, stream);
 }
 
 extern "C" int agx_sensor_postprocess(size_t count, float *pixels, const float *z_normal, const float *u_dropout, float std_a,

@@ -127,8 +127,21 @@ class HipSensor:
     def update(self):
         """WarpSensor.update (warp_sensor.py:177-200): pose -> ray-cast -> noise / range limits / normalise."""
         self.compose_pose()
-        self.raycast()
-        self.postprocess()
+        fused = self.limits_fusable()
+        self.raycast(fuse_limits=fused)
+        if not fused:
+            self.postprocess()
+
+    def limits_fusable(self):
+        """Scalar images without sensor noise: the range limits and the normalisation are applied by the ray-cast kernel
+        to the pixel it is about to store (AgxRangeLimits), the image is not read and written a second time."""
+        cfg = self.cfg
+        return not cfg.sensor_noise.enable_sensor_noise and not self.is_normal and not cfg.return_pointcloud
+
+    def _limits(self):
+        cfg = self.cfg
+        return _lib.AgxRangeLimits(float(cfg.min_range), float(cfg.max_range), float(cfg.far_out_of_range_value),
+                                   float(cfg.near_out_of_range_value), int(bool(cfg.normalize_range)))
 
     def compose_pose(self):
         env = self.g["env_manager"]
@@ -140,8 +153,10 @@ class HipSensor:
             "agx_sensor_pose",
         )
 
-    def raycast(self, stream=None):
+    def raycast(self, stream=None, fuse_limits=False):
+        """fuse_limits=False leaves the raw distances of the reference's warp kernels in `pixels` (postprocess() follows)."""
         env = self.g["env_manager"]
+        lim = C.byref(self._limits()) if fuse_limits else None
         lib, p, cfg, sc = env._lib, _lib.dptr, self.cfg, self.scene
         stream = stream if stream is not None else env._stream()
         N, S = self.num_envs, self.num_sensors
@@ -150,7 +165,7 @@ class HipSensor:
             return _lib.check(
                 lib.agx_raycast_lidar(N, S, cfg.width, cfg.height, p(self.ray_vectors), float(cfg.max_range), self.mode,
                                       p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
-                                      p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
+                                      p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, lim, stream),
                 "agx_raycast_lidar",
             )
         if self.is_stereo:
@@ -158,13 +173,13 @@ class HipSensor:
                 lib.agx_raycast_stereo_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), float(cfg.baseline),
                                               self.c_x, self.c_y, self.mode, p(self.sensor_position), p(self.sensor_orientation),
                                               p(sc.tri_world), p(sc.tri_seg), p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg,
-                                              stream),
+                                              lim, stream),
                 "agx_raycast_stereo_camera",
             )
         return _lib.check(
             lib.agx_raycast_camera(N, S, cfg.width, cfg.height, self.kinv, float(cfg.max_range), self.c_x, self.c_y, self.mode,
                                    p(self.sensor_position), p(self.sensor_orientation), p(sc.tri_world), p(sc.tri_seg),
-                                   p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, stream),
+                                   p(sc.bvh_nodes), sc.num_tris, p(self.pixels), seg, lim, stream),
             "agx_raycast_camera",
         )
 

@@ -231,9 +231,14 @@ class NavigationTask(BaseTask):
         reset_envs = env.post_reward_calculation_step()
         self._reset_targets(reset_envs)
         self.process_image_observation()
-        self.post_image_reward_addition()
+        # one sensor and the observation taken from the same frame: the observation kernel's sweep over the image also
+        # produces post_image_reward_addition's minimum (one read of the image instead of two)
+        self._min_pixel_in_obs = self._image_min_fusable()
+        if not self._min_pixel_in_obs:
+            self.post_image_reward_addition()
         if not self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
+        self._min_pixel_in_obs = False
         if env._step_counter_dev is not None:  # replayed steps read the step index from device memory
             _lib.check(env._lib.agx_step_counter_advance(env._buffers, env._stream()), "agx_step_counter_advance")
         return return_tuple
@@ -304,6 +309,13 @@ class NavigationTask(BaseTask):
     def process_image_observation(self):
         pass  # the min-pooled latents are written by agx_obs_navigation
 
+    _min_pixel_in_obs = False
+
+    def _image_min_fusable(self):
+        px = self.obs_dict.get("depth_range_pixels")
+        return (px is not None and px.dim() == 4 and px.shape[1] == 1 and self.task_config.observation_space_dim > 17
+                and not self.task_config.return_state_before_reset)
+
     def post_image_reward_addition(self):
         """navigation_task.py:351-357.  `rewards[terminations < 0] += ...` never selects anything
         for a bool tensor, so only min_pixel_dist is produced (reference quirk, kept)."""
@@ -348,6 +360,8 @@ class NavigationTask(BaseTask):
             env._lib.agx_obs_navigation(env._buffers, env.num_envs, _lib.dptr(self.target_soa), uv, ue,
                                         _lib.dptr(px) if use_px else None, S, H, W, 8, 8,
                                         int(self.task_config.observation_space_dim),
-                                        _lib.dptr(self.task_obs["observations"]), env._stream()),
+                                        _lib.dptr(self.task_obs["observations"]),
+                                        _lib.dptr(self.min_pixel_dist) if (use_px and self._min_pixel_in_obs) else None,
+                                        env._stream()),
             "agx_obs_navigation",
         )

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 6
+#define AGX_ABI_VERSION 7
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -236,11 +236,14 @@ int agx_reward_navigation(const AgxEnvBuffers *buf, int num_envs, const float *t
  * NULL = device generator (stream of (env, buf->step_counter)).
  * The reference fills the latents with a VAE encoding of the depth image (a conv net outside
  * the simulation hot path); here latents = grid_h x grid_w min-pooled depth image
- * (pixels [N][S][H][W], sensor 0), or left untouched when pixels == NULL.                  */
+ * (pixels [N][S][H][W], sensor 0), or left untouched when pixels == NULL.
+ * min_pixel [N] (optional, num_sensors == 1 only): what agx_image_min would write
+ * (post_image_reward_addition, navigation_task.py:351-357), produced by the same sweep over the
+ * image.                                                                                    */
 int agx_obs_navigation(const AgxEnvBuffers *buf, int num_envs, const float *target,
                        const float *u_vec, const float *u_euler, const float *pixels,
                        int num_sensors, int height, int width, int grid_h, int grid_w,
-                       int obs_dim, float *obs, void *stream);
+                       int obs_dim, float *obs, float *min_pixel, void *stream);
 
 /* ---- LiDAR navigation task (task/lidar_navigation_task/lidar_navigation_task.py) -----------
  * process_image_observation (:313-363) + add_noise_to_downsampled_lidar_data (:281-310):
@@ -450,6 +453,17 @@ enum {
   AGX_RAY_NORMAL = 4, AGX_RAY_NORMAL_WORLD = 5
 };
 
+/* WarpSensor.apply_range_limits + normalize_observation (warp_sensor.py:216-247) as the epilogue of the
+ * ray-cast itself.  With `limits` != NULL (scalar images only: modes RANGE / DEPTH) a pixel is stored
+ * already limited and normalised -- bit for bit what agx_sensor_postprocess(count, pixels, NULL, NULL,
+ * ...) leaves -- and the image needs no second pass over HBM.  NULL = raw distances (and the only
+ * choice with sensor noise, which the reference applies BEFORE the limits).                          */
+typedef struct AgxRangeLimits {
+  float min_range, max_range;
+  float far_oor, near_oor; /* cfg.far_out_of_range_value, cfg.near_out_of_range_value */
+  int32_t normalize;       /* cfg.normalize_range: p / max_range                     */
+} AgxRangeLimits;
+
 /* DepthCameraWarpKernels.draw_optimized_kernel_{depth_range,depth_range_segmentation,
  * pointcloud,pointcloud_segmentation} (warp_camera_kernels.py:176-282, 13-66, 125-172).
  * kinv = {K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]} (warp_cam.py:31-64).
@@ -458,7 +472,7 @@ int agx_raycast_camera(int num_envs, int num_sensors, int width, int height, con
                        float far_plane, int c_x, int c_y, int mode, const float *cam_pos,
                        const float *cam_quat, const float *tri_world, const int32_t *tri_seg,
                        const float *nodes, int num_tris, float *pixels, int32_t *seg,
-                       void *stream);
+                       const AgxRangeLimits *limits, void *stream);
 
 /* StereoCameraWarpKernels.* (warp_stereo_camera_kernels.py:13-299): as agx_raycast_camera
  * (modes 0..3), but a pixel is valid only if the stereo partner at cam_pos + R(cam_quat)
@@ -468,7 +482,8 @@ int agx_raycast_stereo_camera(int num_envs, int num_sensors, int width, int heig
                               const float *kinv, float far_plane, float baseline, int c_x, int c_y,
                               int mode, const float *cam_pos, const float *cam_quat,
                               const float *tri_world, const int32_t *tri_seg, const float *nodes,
-                              int num_tris, float *pixels, int32_t *seg, void *stream);
+                              int num_tris, float *pixels, int32_t *seg,
+                              const AgxRangeLimits *limits, void *stream);
 
 /* LidarWarpKernels.draw_optimized_kernel_{range,range_segmentation,pointcloud,
  * pointcloud_segmentation} (warp_lidar_kernels.py:167-194,130-163,13-86).
@@ -476,7 +491,8 @@ int agx_raycast_stereo_camera(int num_envs, int num_sensors, int width, int heig
 int agx_raycast_lidar(int num_envs, int num_sensors, int width, int height,
                       const float *ray_vectors, float far_plane, int mode, const float *pos,
                       const float *quat, const float *tri_world, const int32_t *tri_seg,
-                      const float *nodes, int num_tris, float *pixels, int32_t *seg, void *stream);
+                      const float *nodes, int num_tris, float *pixels, int32_t *seg,
+                      const AgxRangeLimits *limits, void *stream);
 
 /* WarpSensor.apply_noise / apply_range_limits / normalize_observation
  * (warp_sensor.py:202-247), scalar images, in place.  z_normal/u_dropout optional.     */

@@ -45,7 +45,7 @@ def timeit(name, fn, rays, reps=10):
 
 common = (p(sen.sensor_position), p(sen.sensor_orientation), p(sc.tri_world), p(sc.tri_seg), p(sc.bvh_nodes), sc.num_tris)
 rays = N * S * H * W
-timeit("camera depth + seg (BASIC)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 1, *common, p(px1), p(seg), st), rays)
-timeit("camera pointcloud world + seg (BASIC)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 3, *common, p(px3), p(seg), st), rays)
-timeit("camera normal world + faceID (NORMAL)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 5, *common, p(px3), p(seg), st), rays)
-timeit("stereo depth + seg, baseline 0.095 (STEREO)", lambda st: lib.agx_raycast_stereo_camera(N, S, W, H, sen.kinv, 10.0, 0.095, sen.c_x, sen.c_y, 1, *common, p(px1), p(seg), st), rays)
+timeit("camera depth + seg (BASIC)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 1, *common, p(px1), p(seg), None, st), rays)
+timeit("camera pointcloud world + seg (BASIC)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 3, *common, p(px3), p(seg), None, st), rays)
+timeit("camera normal world + faceID (NORMAL)", lambda st: lib.agx_raycast_camera(N, S, W, H, sen.kinv, 10.0, sen.c_x, sen.c_y, 5, *common, p(px3), p(seg), None, st), rays)
+timeit("stereo depth + seg, baseline 0.095 (STEREO)", lambda st: lib.agx_raycast_stereo_camera(N, S, W, H, sen.kinv, 10.0, 0.095, sen.c_x, sen.c_y, 1, *common, p(px1), p(seg), None, st), rays)

@@ -27,7 +27,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.agx_bvh_build(4, 5000, 0, C.c_void_p(16), None, C.c_void_p(16), None, None) == -1  # LDS-resident build limit
     assert b"num_tris" in lib.agx_last_error()
     assert lib.agx_bvh_build(4, 24, 0, C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None, None) == -1  # masked rebuild needs the work list
-    assert lib.agx_raycast_camera(1, 1, 8, 8, (C.c_float * 4)(), 10.0, 4, 4, 9, None, None, None, None, None, 12, None, None, None) == -1
+    assert lib.agx_raycast_camera(1, 1, 8, 8, (C.c_float * 4)(), 10.0, 4, 4, 9, None, None, None, None, None, 12, None, None, None, None) == -1
     assert lib.agx_bvh_nodes_bytes(3, 1272) == 3 * 1271 * 64
 
 

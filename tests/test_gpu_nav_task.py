@@ -220,12 +220,57 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             obs_ref = orc.obs_navigation(post["state"], post["euler"], post["qveh"], post["vbody"], post["wbody"], post["actions"],
                                          post["target"], u6[:, 0:3], u6[:, 3:6], px_ref, cfg.observation_space_dim)
             parity.check(f"nav_task_obs[{case}]", max_abs(npy(obs["observations"]), obs_ref), 0.0, "abs (bit-exact)", t)
+            # post_image_reward_addition's minimum (navigation_task.py:351-357), produced by the observation kernel's sweep
+            v10 = 10.0 * px_ref.reshape(n, -1)
+            v10[v10 < 0] = 10.0
+            assert np.array_equal(npy(task.min_pixel_dist), v10.min(axis=1)), t
             if reset_ref.any():  # the reference refreshes EVERY env's derived tensors when any env resets
                 eu, qv, vv, vb, wb = orc.update_states(post["state"])
                 assert max_abs(post["vbody"], vb) < 1e-5 and max_abs(post["qveh"], qv) < 1e-5, t
         assert n_resets >= 2 * n and (n_crashes >= 1 or "lidar" in case), (n_resets, n_crashes)  # truncations and collisions seen
     finally:
         cfg.episode_len_steps, cfg.args, cfg.device = old_cfg
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (32, 512), (30, 50), (270, 480), (5, 7), (64, 1024), (17, 200)])
+def test_observation_min_pool_any_image_shape(orc, shape):
+    """agx_obs_navigation's 8 x 8 min-pool is a coalesced sweep (64 consecutive pixels per load, cells reduced across
+    lanes): every arrangement -- cell width a power of two below 64, 64 and above, not a power of two, cells that
+    straddle a 64-pixel chunk, empty cells, several sensors -- gives the bits of the serial loop; min_pixel (one sensor)
+    == agx_image_min."""
+    from aerial_gym_simulator_amd import _lib
+
+    lib = _lib.load()
+    H, W = shape
+    n, obs_dim = 5, 81
+    rng = np.random.default_rng(H * 1000 + W)
+    f32 = np.float32
+    state = rng.normal(size=(n, 13)).astype(f32)
+    state[:, 3:7] /= np.linalg.norm(state[:, 3:7], axis=1, keepdims=True)
+    euler, qveh, vveh, vbody, wbody = orc.update_states(state)
+    actions, target = rng.normal(size=(n, 4)).astype(f32), rng.normal(size=(n, 3)).astype(f32)
+    u_vec, u_eul = rng.random((n, 3)).astype(f32), rng.random((n, 3)).astype(f32)
+    for S in (1, 2):
+        px = rng.uniform(-1.0, 1.0, (n, S, H, W)).astype(f32)
+        px[rng.random(px.shape) < 0.3] = -1.0
+        derived = np.concatenate([euler, qveh, vveh, vbody, wbody], axis=1).astype(f32)
+        t = {k: torch.from_numpy(np.ascontiguousarray(v.T)).to(DEV) for k, v in (("state", state), ("derived", derived),
+                                                                                 ("actions", actions), ("target", target))}
+        tu, te, tpx = torch.from_numpy(u_vec).to(DEV), torch.from_numpy(u_eul).to(DEV), torch.from_numpy(px).to(DEV)
+        obs, mp, mp_ref = torch.zeros(n, obs_dim, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        B = _lib.AgxEnvBuffers()
+        B.state, B.derived, B.actions, B.flag_parity = _lib.dptr(t["state"]), _lib.dptr(t["derived"]), _lib.dptr(t["actions"]), 0
+        st = _lib.current_stream(DEV)
+        _lib.check(lib.agx_obs_navigation(B, n, _lib.dptr(t["target"]), _lib.dptr(tu), _lib.dptr(te), _lib.dptr(tpx), S, H, W, 8, 8,
+                                          obs_dim, _lib.dptr(obs), _lib.dptr(mp) if S == 1 else None, st))
+        ref = orc.obs_navigation(state, euler, qveh, vbody, wbody, actions, target, u_vec, u_eul, px, obs_dim)
+        assert np.array_equal(obs.cpu().numpy(), ref), (shape, S)
+        if S == 1:
+            _lib.check(lib.agx_image_min(n, H * W, _lib.dptr(tpx), _lib.dptr(mp_ref), st))
+            assert np.array_equal(mp.cpu().numpy(), mp_ref.cpu().numpy())
+        else:  # several sensors: the observation covers sensor 0 only, the minimum all of them -> refused
+            assert lib.agx_obs_navigation(B, n, _lib.dptr(t["target"]), _lib.dptr(tu), _lib.dptr(te), _lib.dptr(tpx), S, H, W, 8, 8,
+                                          obs_dim, _lib.dptr(obs), _lib.dptr(mp), st) == -1
 
 
 def test_bookkeeping_and_target_reset_kernels_vs_the_reference_task_glue():

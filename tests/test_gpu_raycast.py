@@ -40,7 +40,14 @@ class Scene:
         L.check(self.lib.agx_bvh_build(self.n, self.nt, self.ppo, p(self.tri_world), mk, p(self.nodes), p(self.work), self.stream))
         torch.cuda.synchronize()
 
-    def camera(self, W, H, kinv, far, cx, cy, mode, pos, quat, seg=True):
+    def _lim(self, limits):
+        """limits = (min_range, max_range, far_oor, near_oor, normalize) -> AgxRangeLimits*, or NULL (raw distances)"""
+        if limits is None:
+            return None
+        self._limits_struct = self.L.AgxRangeLimits(*[float(x) for x in limits[:4]], int(limits[4]))
+        return C.byref(self._limits_struct)
+
+    def camera(self, W, H, kinv, far, cx, cy, mode, pos, quat, seg=True, limits=None):
         p, L = self.L.dptr, self.L
         S = pos.shape[1]
         shape = (self.n, S, H, W) if mode <= 1 else (self.n, S, H, W, 3)
@@ -49,11 +56,12 @@ class Scene:
         kin = (C.c_float * 4)(*[float(x) for x in kinv])
         tp, tq = T(pos), T(quat)
         L.check(self.lib.agx_raycast_camera(self.n, S, W, H, kin, float(far), cx, cy, mode, p(tp), p(tq), p(self.tri_world),
-                                            p(self.tri_seg), p(self.nodes), self.nt, p(px), p(sg) if seg else None, self.stream))
+                                            p(self.tri_seg), p(self.nodes), self.nt, p(px), p(sg) if seg else None,
+                                            self._lim(limits), self.stream))
         torch.cuda.synchronize()
         return px.cpu().numpy(), (sg.cpu().numpy() if seg else None)
 
-    def stereo(self, W, H, kinv, far, baseline, cx, cy, mode, pos, quat):
+    def stereo(self, W, H, kinv, far, baseline, cx, cy, mode, pos, quat, limits=None):
         p, L = self.L.dptr, self.L
         S = pos.shape[1]
         shape = (self.n, S, H, W) if mode <= 1 else (self.n, S, H, W, 3)
@@ -63,11 +71,11 @@ class Scene:
         tp, tq = T(pos), T(quat)
         L.check(self.lib.agx_raycast_stereo_camera(self.n, S, W, H, kin, float(far), float(baseline), cx, cy, mode, p(tp), p(tq),
                                                    p(self.tri_world), p(self.tri_seg), p(self.nodes), self.nt, p(px), p(sg),
-                                                   self.stream))
+                                                   self._lim(limits), self.stream))
         torch.cuda.synchronize()
         return px.cpu().numpy(), sg.cpu().numpy()
 
-    def lidar(self, rv, far, mode, pos, quat):
+    def lidar(self, rv, far, mode, pos, quat, limits=None):
         p, L = self.L.dptr, self.L
         S, H, W = pos.shape[1], rv.shape[0], rv.shape[1]
         shape = (self.n, S, H, W) if mode == 0 else (self.n, S, H, W, 3)
@@ -75,7 +83,7 @@ class Scene:
         sg = torch.zeros((self.n, S, H, W), dtype=torch.int32, device=DEV)
         trv, tp, tq = T(rv), T(pos), T(quat)
         L.check(self.lib.agx_raycast_lidar(self.n, S, W, H, p(trv), float(far), mode, p(tp), p(tq), p(self.tri_world),
-                                           p(self.tri_seg), p(self.nodes), self.nt, p(px), p(sg), self.stream))
+                                           p(self.tri_seg), p(self.nodes), self.nt, p(px), p(sg), self._lim(limits), self.stream))
         torch.cuda.synchronize()
         return px.cpu().numpy(), sg.cpu().numpy()
 
@@ -233,6 +241,51 @@ def test_rebuild_after_reset_is_idempotent_and_masked(orc):
     ref = orc.raycast_camera(64, 48, kinv, 10.0, cx, cy, "depth", pos, quat, tris, sc["tri_seg"])
     got = S.camera(64, 48, kinv, 10.0, cx, cy, 1, pos, quat)
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_range_limits_fused_into_the_raycast_equal_the_separate_pass(orc, normalize):
+    """AgxRangeLimits: the ray-cast kernel stores the limited / normalised pixel == raw ray-cast + agx_sensor_postprocess
+    (and == the restated warp kernel + WarpSensor.apply_range_limits / normalize_observation), camera depth, stereo, LiDAR."""
+    from aerial_gym_simulator_amd import _lib
+
+    n = 3
+    sc = random_box_scene(n, 60, seed=33)
+    S = Scene(sc)
+    S.build()
+    tris = orc.scene_transform(sc["tri_local"], sc["tri_asset"], sc["asset_state"])
+    lim = (1.5, 6.0, 6.0, -1.0, normalize)  # both limits bite in this scene
+
+    def separate(raw):
+        t = T(raw)
+        _lib.check(S.lib.agx_sensor_postprocess(t.numel(), _lib.dptr(t), None, None, 0.0, 0.0, 0.0, 0.0, 0.0, lim[0], lim[1],
+                                                lim[2], lim[3], int(normalize), S.stream))
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    _, _, _, _, pos, quat = _poses(orc, n, sc, 4)
+    kinv, cx, cy = orc.camera_kinv(53, 37, 87.0)
+    raw, seg0 = S.camera(53, 37, kinv, 10.0, cx, cy, 1, pos, quat)
+    fused, seg1 = S.camera(53, 37, kinv, 10.0, cx, cy, 1, pos, quat, limits=lim)
+    ref_raw, _ = orc.raycast_camera(53, 37, kinv, 10.0, cx, cy, "depth", pos, quat, tris, sc["tri_seg"])
+    ref = orc.sensor_postprocess(ref_raw.copy(), lim[0], lim[1], lim[2], lim[3], normalize)
+    assert np.array_equal(seg0, seg1) and np.array_equal(fused, separate(raw)) and np.array_equal(fused, ref)
+    assert (raw > lim[1]).any() and (raw < lim[0]).any() and ((raw >= lim[0]) & (raw <= lim[1])).any()
+
+    raw, _ = S.stereo(53, 37, kinv, 10.0, 0.095, cx, cy, 0, pos, quat)
+    fused, _ = S.stereo(53, 37, kinv, 10.0, 0.095, cx, cy, 0, pos, quat, limits=lim)
+    assert np.array_equal(fused, separate(raw))
+
+    _, _, _, _, pos, quat = _poses(orc, n, sc, 6, lidar=True)
+    rv = orc.lidar_ray_table(16, 130, -180, 180, -45, 45)
+    raw, _ = S.lidar(rv, 10.0, 0, pos, quat)
+    fused, _ = S.lidar(rv, 10.0, 0, pos, quat, limits=lim)
+    assert np.array_equal(fused, separate(raw))
+    # point clouds are limited on the point's norm by agx_sensor_postprocess_points: not fusable, refused
+    px = torch.zeros(n, 1, 16, 130, 3, device=DEV)
+    tp, tq, trv = T(pos), T(quat), T(rv)
+    assert S.lib.agx_raycast_lidar(n, 1, 130, 16, _lib.dptr(trv), 10.0, 2, _lib.dptr(tp), _lib.dptr(tq), _lib.dptr(S.tri_world),
+                                   _lib.dptr(S.tri_seg), _lib.dptr(S.nodes), S.nt, _lib.dptr(px), None, S._lim(lim), S.stream) == -1
 
 
 def test_postprocess_and_image_min(orc):
