@@ -692,9 +692,9 @@ AGX_DEV void write_step_row_tail(const AgxEnvBuffers &B, int i, float *__restric
   row_store(row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
   row_store(row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
 }
-AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target, float *__restrict__ obs,
-                                const EnvState &s, const Derived &d) {
-  float v[13] = {AGX_AT(target, 0) - s.p.x, AGX_AT(target, 1) - s.p.y, AGX_AT(target, 2) - s.p.z, s.q.x, s.q.y, s.q.z, s.q.w,
+AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, V3 tgt, float *__restrict__ obs, const EnvState &s,
+                                const Derived &d) {
+  float v[13] = {tgt.x - s.p.x, tgt.y - s.p.y, tgt.z - s.p.z, s.q.x, s.q.y, s.q.z, s.q.w,
                  d.vbody.x, d.vbody.y, d.vbody.z, d.wbody.x, d.wbody.y, d.wbody.z};
   float *o = obs + (size_t)i * 13;
 #pragma unroll
@@ -708,7 +708,9 @@ AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, const floa
 }
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
+  if (i < n)
+    write_obs_position(B, n, i, V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)}, obs, load_state(B.state, n, i),
+                       load_derived(B.derived, n, i));
   step_rows_signal(B);
 }
 
@@ -985,33 +987,56 @@ AGX_DEV EnvState reset_env(const AgxRobotParams &P, const AgxEnvBuffers &B, int 
   return s;
 }
 
-// Reset (base_multirotor.py:177-205, motor_model.py:140-154, env_manager.py:301) and,
-// when WITH_OBS, the position task's observation of the post-reset state.
+// What follows the reset decision of one env step, for one env: the masked reset (base_multirotor.py:177-205,
+// motor_model.py:140-154, env_manager.py:301) and, when WITH_OBS, the position task's observation of the post-reset state.
+// `any`: some env of the batch resets (wave-uniform); s / d: the env's state and derived tensors as the step left them.
+// Must be called by all 64 lanes (wave_reset_draws).
+template <int M, bool WITH_OBS>
+AGX_DEV void reset_and_observe(const AgxRobotParams &P, const AgxEnvBuffers &B, int n, const AgxResetArgs &R, int i, bool valid,
+                               bool any, bool mine, int ep, V3 tgt, float *__restrict__ obs, const EnvState &s, const Derived &d) {
+  if (!any) {  // nobody resets: the reference does not touch anything
+    if (WITH_OBS && valid) write_obs_position(B, n, i, tgt, obs, s, d);
+    return;
+  }
+  ResetDraws<M> D{};
+  if (R.u_state) {
+    if (mine) host_reset_draws<M>(P, R, i, D);
+  } else {
+    wave_reset_draws<M>(R, B.env_index_base + i, ep, mine, D);  // draws are keyed by the GLOBAL env index
+  }
+  if (valid) {
+    EnvState s2 = mine ? reset_env<M>(P, B, n, R, i, ep, D) : s;
+    // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
+    Derived d2 = update_states(s2);
+    store_derived(B.derived, n, i, d2);
+    if (WITH_OBS) write_obs_position(B, n, i, tgt, obs, s2, d2);
+  }
+}
+
+// The reset / observation half of the env step as its own launch.  Every load is issued before the flag is looked at (one
+// memory round trip instead of flag -> mask -> state in sequence).
 template <int M, bool WITH_OBS>
 __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
                                                       const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
   const bool valid = i < n;
-  if (B.reset_flag[B.flag_parity] == 0) {  // nobody resets: the reference does not touch anything
-    if (WITH_OBS && valid) write_obs_position(B, n, i, target, obs, load_state(B.state, n, i), load_derived(B.derived, n, i));
-  } else {  // (the flag is one word: the branch is taken by whole waves)
-    const bool mine = valid && B.reset_mask[i] != 0;
-    const int ep = (mine && B.episode_count) ? B.episode_count[i] : 0;
-    ResetDraws<M> D{};
-    if (R.u_state) {
-      if (mine) host_reset_draws<M>(P, R, i, D);
-    } else {
-      wave_reset_draws<M>(R, B.env_index_base + i, ep, mine, D);  // draws are keyed by the GLOBAL env index
+  EnvState s{};
+  Derived d{};
+  V3 tgt{};
+  bool mine = false;
+  int ep = 0;
+  if (valid) {
+    s = load_state(B.state, n, i);
+    if (WITH_OBS) {
+      d = load_derived(B.derived, n, i);
+      tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
     }
-    if (valid) {
-      EnvState s = mine ? reset_env<M>(P, B, n, R, i, ep, D) : load_state(B.state, n, i);
-      // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
-      Derived d = update_states(s);
-      store_derived(B.derived, n, i, d);
-      if (WITH_OBS) write_obs_position(B, n, i, target, obs, s, d);
-    }
+    mine = B.reset_mask[i] != 0;
+    if (B.episode_count) ep = B.episode_count[i];
   }
+  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  reset_and_observe<M, WITH_OBS>(P, B, n, R, i, valid, any, mine && any, ep, tgt, obs, s, d);
   if (WITH_OBS) step_rows_signal(B);
 }
 
