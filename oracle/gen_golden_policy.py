@@ -1,0 +1,39 @@
+"""TEST INFRASTRUCTURE.  Fixture: the actor of a policy the REFERENCE trained in its own simulator (Isaac Gym / PhysX),
+`aerial_gym/examples/rl_games_example/networks/attitude_policy.pth` -- the network the reference's closed-loop example
+flies (`examples/rl_games_example/rl_env_closed_loop_example.py:41-50`: position_setpoint_task, base_quadrotor,
+lee_attitude_control, 13-D observation -> 4-D attitude command).  tests/test_gpu_policy_transfer.py flies it on the HIP
+path: a behavioural cross-check of the rigid-body integration + controller stack against an artefact that only ever saw
+PhysX (the integrator row of SURVEY.md section 8 has no numeric fixture: PhysX is not in the reference tree).
+
+Stored: the actor MLP 13 -> 256 -> 128 -> 64 -> 4 (ELU; rl_games_inference.py:7-46), its log-std, and the mean episode
+return rl_games logged for it (`last_mean_rewards`).  Weights only -- no reference code.
+
+    python oracle/gen_golden_policy.py [/root/reference]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(ref="/root/reference"):
+    path = os.path.join(ref, "aerial_gym/examples/rl_games_example/networks/attitude_policy.pth")
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    m = ck["model"]
+    out = {}
+    for i, layer in enumerate(("actor_mlp.0", "actor_mlp.2", "actor_mlp.4", "mu")):
+        out[f"w{i}"] = m[f"a2c_network.{layer}.weight"].numpy().astype(np.float32)
+        out[f"b{i}"] = m[f"a2c_network.{layer}.bias"].numpy().astype(np.float32)
+    out["logstd"] = m["a2c_network.sigma"].numpy().astype(np.float32)
+    out["last_mean_rewards"] = np.float64(float(ck["last_mean_rewards"]))
+    out["epoch"], out["frame"] = np.int64(ck["epoch"]), np.int64(ck["frame"])
+    dst = os.path.join(ROOT, "tests", "golden", "policy_attitude_actor.npz")
+    np.savez_compressed(dst, **out)
+    print(dst, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

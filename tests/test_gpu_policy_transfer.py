@@ -1,0 +1,94 @@
+"""GPU: a policy the REFERENCE trained in Isaac Gym / PhysX flies the HIP simulator.
+
+`tests/golden/policy_attitude_actor.npz` (oracle/gen_golden_policy.py) is the actor of
+`examples/rl_games_example/networks/attitude_policy.pth`, the network of the reference's closed-loop example
+(`rl_env_closed_loop_example.py:22-66`: position_setpoint_task + base_quadrotor + lee_attitude_control).  It has only ever
+seen PhysX dynamics.  If this repository's restated rigid-body update, motor model, controller and observation differed
+from the reference's in a frame convention, a sign, a time constant or a gain, the closed loop would not hold a hover, let
+alone reach the set-point.  Checked: from spawns anywhere in the env every robot converges on the target and stays
+there (mean distance over the last second of the episode, its 95th percentile) and nobody crashes in 4096 episodes -- a
+behavioural cross-check of SURVEY.md section 8 rows a12 / a15 / a17, whose PhysX half has no numeric fixture.  The mean
+episode return is printed next to the one rl_games logged for this network (`last_mean_rewards`); it is not gated: which
+robot / reward revision the network was trained on is not recorded in the checkpoint.
+Measured (MI355X): 0 crashes, distance 0.155 m mean / 0.22 m p95 (deterministic), 0.16 / 0.24 (sampled actions)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "policy_attitude_actor.npz")
+
+
+class Actor(torch.nn.Module):
+    """rl_games_inference.py:7-46: 13 -> 256 -> 128 -> 64 -> 4, ELU"""
+
+    def __init__(self, g):
+        super().__init__()
+        self.layers = torch.nn.ModuleList()
+        for i in range(4):
+            w = torch.from_numpy(g[f"w{i}"])
+            lin = torch.nn.Linear(w.shape[1], w.shape[0])
+            lin.weight.data.copy_(w)
+            lin.bias.data.copy_(torch.from_numpy(g[f"b{i}"]))
+            self.layers.append(lin)
+        self.logstd = torch.nn.Parameter(torch.from_numpy(g["logstd"]), requires_grad=False)
+
+    def forward(self, x):
+        for lin in self.layers[:-1]:
+            x = torch.nn.functional.elu(lin(x))
+        return self.layers[-1](x)
+
+
+def fly(stochastic, n=2048, steps=1010):
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    old = (cfg.controller_name, cfg.episode_len_steps, cfg.args, cfg.robot_name)
+    cfg.device, cfg.controller_name, cfg.robot_name, cfg.episode_len_steps, cfg.args = DEV, "lee_attitude_control", "base_quadrotor", 500, {}
+    try:
+        g = np.load(GOLDEN)
+        actor = Actor(g).to(DEV).eval()
+        task = task_registry.make_task("position_setpoint_task", seed=42, num_envs=n, headless=True)
+        obs = task.reset()[0]
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        ret = torch.zeros(n, device=DEV)
+        finished, crashes = [], 0
+        dist_late, err_late = [], torch.zeros(3, device=DEV)
+        with torch.no_grad():
+            for t in range(steps):
+                a = actor(obs["observations"])
+                if stochastic:  # what rl_games' player samples while it logs `last_mean_rewards`
+                    a = a + torch.exp(actor.logstd) * torch.randn(a.shape, device=DEV, generator=gen)
+                a = a.clamp(-1.0, 1.0).contiguous()
+                obs, rew, term, trunc, _ = task.step(a)
+                ret += rew
+                done = term | trunc
+                if done.any():
+                    finished.append(ret[done].clone())
+                    ret[done] = 0.0
+                crashes += int(term.sum())
+                if 400 <= t < 500:  # the last second of the first episode: obs[:, 0:3] = target - position
+                    dist_late.append(obs["observations"][:, 0:3].norm(dim=1).clone())
+                    err_late = err_late + obs["observations"][:, 0:3].mean(dim=0) / 100.0
+        finished = torch.cat(finished) if finished else torch.zeros(0, device=DEV)
+        d = torch.stack(dist_late)
+        return {"episodes": int(finished.numel()), "mean_return": float(finished.mean()), "crashes": crashes,
+                "dist_late_mean": float(d.mean()), "dist_late_p95": float(d.flatten().quantile(0.95)),
+                "mean_error_xyz_late": [round(float(v), 4) for v in err_late],
+                "logged_return": float(g["last_mean_rewards"])}
+    finally:
+        cfg.controller_name, cfg.episode_len_steps, cfg.args, cfg.robot_name = old
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_reference_trained_attitude_policy_reaches_the_set_point(stochastic):
+    r = fly(stochastic)
+    print("policy transfer:", "stochastic" if stochastic else "deterministic", r)
+    assert r["episodes"] >= 2 * 2048 - 64
+    assert r["crashes"] <= 0.002 * r["episodes"]
+    assert r["dist_late_mean"] < 0.25 and r["dist_late_p95"] < 0.4
+    assert r["mean_return"] > 0.5 * r["logged_return"]
