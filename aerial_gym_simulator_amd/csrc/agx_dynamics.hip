@@ -38,9 +38,11 @@
 #pragma clang fp contract(off)
 #endif
 #include "agx_device_math.h"
+#include "agx_quad_math.h"
 #include "agx_rng.h"
 #include "agx_step_signal.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef AGX_DYN_FAST_RCP
@@ -630,6 +632,220 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
   if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
 }
 
+// ---------------------------------------------------------------------------------------
+// The one-sub-step env step of the Lee position controller on a quadrotor (BASELINE configs 1/2) with FOUR lanes per
+// env (agx_quad_math.h): a wave carries 16 envs, 8192 envs are 512 waves on the 1024 SIMDs instead of 128, and a wave
+// issues about half the vector instructions of the one-lane-per-env kernel.  Every value is produced by the same IEEE
+// operations in the same order as in k_env_step<4, AGX_CTRL_POSITION, true, .>; the GPU parity tests run against the
+// CPU restatement through this kernel.  Not covered (the launcher falls back to k_env_step): obstacles, drag, disturbances,
+// split launches, other controllers / motor counts.
+// ---------------------------------------------------------------------------------------
+namespace q4 = quad;
+
+// BaseMultirotor.update_states (base_multirotor.py:287-294) of one env on its lane quad
+struct QuadDerived {
+  float euler, qveh, vveh, vbody, wbody;
+};
+AGX_DEV QuadDerived update_states_quad(float q, float v, float w) {
+  const int l = q4::lane_in_quad();
+  QuadDerived d;
+  const float e = q4::euler_xyz_0_2pi(q);
+  d.euler = ssa(e);
+  float sy, cy;
+  sincos_bounded((q4::bc<2>(e) * 1.0f) * 0.5f, sy, cy);  // vehicle_frame_quat_from_quat: quat_from_yaw
+  d.qveh = l == 2 ? sy : (l == 3 ? cy : 0.0f);
+  d.vveh = q4::quat_rotate_inverse(d.qveh, v);
+  d.vbody = q4::quat_rotate_inverse(q, v);
+  d.wbody = q4::quat_rotate_inverse(q, w);
+  return d;
+}
+
+__global__ void __launch_bounds__(64, 1)
+    k_env_step_quad_position(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, AgxTaskArgs T) {
+  const int tid = threadIdx.x;
+  const int l = tid & 3, l3 = l < 3 ? l : 2;  // component of a 4-vector / of a 3-vector (lane 3 repeats z: don't care)
+  const int i = blockIdx.x * 16 + (tid >> 2);  // env
+  bool reset = false;
+  if (i < n) {
+    // ---- loads: one instruction per vector
+    float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
+    float u = AGX_AT(B.motor_thrust, l);  // motor l
+    const float kT = P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f;
+    const float tinc = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform;
+    const float tdec = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform;
+    const float a_in = actions_in[(size_t)i * 4 + l];
+    const float a_old = AGX_AT(B.actions, l);
+    const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
+    const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
+    const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
+    const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
+    // per-lane constants: component l of a vector, row l of a matrix (indexed kernel-argument loads)
+    const float grav = P.gravity[l3];
+    const float in0 = P.inertia[3 * l3 + 0], in1 = P.inertia[3 * l3 + 1], in2 = P.inertia[3 * l3 + 2];
+    const float ii0 = P.inertia_inv[3 * l3 + 0], ii1 = P.inertia_inv[3 * l3 + 1], ii2 = P.inertia_inv[3 * l3 + 2];
+    float pinv[6], mapf[4], mapt[4];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pinv[c] = P.alloc_pinv[6 * l + c];  // motor l
+    const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mapf[j] = wmap[4 * l3 + j];        // force row l
+      mapt[j] = wmap[4 * (3 + l3) + j];  // torque row l
+    }
+    const float mass = P.mass, dt = P.dt;
+
+    // ---- update_states + controller (position_control.py:20-51)
+    const QuadDerived d = update_states_quad(q, v, w);
+    const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions
+    // compute_acceleration (velocity set-point 0): kp (sp - p) + kv (0 - v)
+    const float pe = a - p;
+    const float ve = 0.0f - v;
+    const float acc = kp * pe + kv * ve;
+    const float f = (acc - grav) * mass;
+    // third column of quat_to_rotmat(q): (2 (xz + yw), 2 (yz - xw), 1 - 2 (xx + yy))
+    const float t1 = q * q4::bc<2>(q), t2 = q4::perm<1, 0, 2, 3>(q) * q4::bc<3>(q);
+    const float c2a = 2.0f * (l == 1 ? t1 - t2 : t1 + t2);
+    const float sqq = q * q;
+    const float m22 = 1.0f - 2.0f * (q4::bc<0>(sqq) + q4::bc<1>(sqq));
+    const float fz = q4::dot3(f, l == 2 ? m22 : c2a);
+    // desired_orientation_pos_vel(f, yaw set-point)
+    const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
+    float sy, cy;
+    sincos_bounded(q4::bc<3>(a), sy, cy);
+    const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
+    const float cb = q4::cross3(b3, tmp);
+    const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
+    const float b1 = q4::cross3(b2, b3);
+    const float qd = q4::rotmat_cols_to_quat(b1, b2, b3);
+    // compute_body_torque (rate set-point 0)
+    const float qe = q4::quat_mul(q4::conj(q), qd);
+    const float pp = q4::rot1(qe) * q4::rot2(qe);  // (yz, zx, xy)
+    const float pw = qe * q4::bc<3>(qe);           // (xw, yw, zw)
+    const float mp = 2.0f * (pp + pw);             // (m21, m02, m10)
+    const float mm = 2.0f * (pp - pw);             // (m12, m20, m01)
+    const float rot_err = 0.5f * (l == 1 ? mm - mp : -(mp - mm));
+    const float wb = d.wbody;
+    const float jw = (in0 * q4::bc<0>(wb) + in1 * q4::bc<1>(wb)) + in2 * q4::bc<2>(wb);
+    const float ff = q4::cross3(wb, jw);
+    const float torque = ((-kr) * rot_err - kw * wb) + ff;
+
+    // ---- allocation + motor model: lane l = motor l
+    float r = 0.0f;
+    r += pinv[0] * 0.0f;
+    r += pinv[1] * 0.0f;
+    r += pinv[2] * fz;
+    r += pinv[3] * q4::bc<0>(torque);
+    r += pinv[4] * q4::bc<1>(torque);
+    r += pinv[5] * q4::bc<2>(torque);
+    u = motor_update(P, r, u, kT, tinc, tdec);
+    // body wrench: lane l = row l
+    float fb = 0.0f, tb = 0.0f;
+    const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
+    fb += mapf[0] * u0; fb += mapf[1] * u1; fb += mapf[2] * u2; fb += mapf[3] * u3;
+    tb += mapt[0] * u0; tb += mapt[1] * u1; tb += mapt[2] * u2; tb += mapt[3] * u3;
+    if (B.body_force && l < 3) AGX_AT(B.body_force, l) = fb;
+
+    // ---- integrate (the rigid-body update)
+    const float fw = q4::quat_rotate(q, fb);
+    const float wbi = q4::quat_rotate_inverse(q, w);
+    const float jwi = (in0 * q4::bc<0>(wbi) + in1 * q4::bc<1>(wbi)) + in2 * q4::bc<2>(wbi);
+    const float rhs = tb - q4::cross3(wbi, jwi);
+    const float dwb = (ii0 * q4::bc<0>(rhs) + ii1 * q4::bc<1>(rhs)) + ii2 * q4::bc<2>(rhs);
+    const float wb_new = wbi + dt * dwb;
+    float w_new = q4::quat_rotate(q, wb_new);
+    float v_new = v + dt * fdiv(fw, mass);
+    v_new = v_new + grav * dt;
+    const float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
+    const float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
+    v_new = v_new * ml;
+    w_new = w_new * ma;
+    const float v2 = q4::dot3(v_new, v_new), w2 = q4::dot3(w_new, w_new);
+    if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
+    if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
+    p = p + v_new * dt;
+    const float wm2 = q4::dot3(w_new, w_new);
+    if (wm2 != 0.0f) {
+      const float wm = fsqrt(wm2);
+      const float half = dt * wm * 0.5f;
+      float sn, cs;
+      sincos_bounded(half, sn, cs);
+      const float sc = fdiv(sn, wm);
+      const float x1 = w_new * sc;  // (x1, y1, z1)
+      // (x1 w + y1 z - z1 y, y1 w + z1 x - x1 z, z1 w + x1 y - y1 x, -(x1 x) - y1 y - z1 z)
+      const float r3 = (x1 * q4::bc<3>(q) + q4::rot1(x1) * q4::rot2(q)) - q4::rot2(x1) * q4::rot1(q);
+      const float xq = x1 * q;
+      const float rw = (-q4::bc<0>(xq) - q4::bc<1>(xq)) - q4::bc<2>(xq);
+      float rq = l == 3 ? rw : r3;
+      rq += q * cs;
+      const float nn = fsqrt(q4::dot4(rq, rq));
+      q = fdiv(rq, nn);
+    }
+    v = v_new;
+    w = w_new;
+
+    // ---- stores: state, derived, motors, controller output, actions
+    if (l < 3) AGX_AT(B.state, 0 + l) = p;
+    AGX_AT(B.state, 3 + l) = q;
+    if (l < 3) {
+      AGX_AT(B.state, 7 + l) = v;
+      AGX_AT(B.state, 10 + l) = w;
+      AGX_AT(B.derived, 0 + l) = d.euler;
+      AGX_AT(B.derived, 7 + l) = d.vveh;
+      AGX_AT(B.derived, 10 + l) = d.vbody;
+      AGX_AT(B.derived, 13 + l) = d.wbody;
+    }
+    AGX_AT(B.derived, 3 + l) = d.qveh;
+    AGX_AT(B.motor_thrust, l) = u;
+    if (B.wrench_cmd) {
+      if (l < 3) {
+        AGX_AT(B.wrench_cmd, l) = l == 2 ? fz : 0.0f;
+        AGX_AT(B.wrench_cmd, 3 + l) = torque;
+      }
+    }
+    AGX_AT(B.prev_actions, l) = a_old;  // RobotManagerIGE.pre_physics_step: prev <- cur, cur <- action
+    AGX_AT(B.actions, l) = a_in;
+
+    // ---- EnvManager bookkeeping + the position task's reward / truncation / reset set (position_setpoint_task.py:245-282)
+    const int steps = B.sim_steps[i] + 1;
+    bool crashed = false, trunc = false;
+    float rew = 0.0f;
+    if (T.kind == AGX_TASK_POSITION) {
+      const float tgt = AGX_AT(T.target, l3);
+      const float pe_t = q4::quat_apply(q4::conj(d.qveh), tgt - p);  // quat_apply_inverse
+      const float dist = fsqrt(q4::dot3(pe_t, pe_t));
+      // 3 exp(-8 d^2) + 2 exp(-4 d^2): both exponentials in one evaluation (lanes 0 / 1)
+      const float ex = exp_cw((l == 0 ? -8.0f : -4.0f) * dist * dist);
+      const float pos_reward = 3.0f * q4::bc<0>(ex) + 2.0f * q4::bc<1>(ex);
+      const float dist_reward = (20.0f - dist) / 40.0f;
+      const float axis_z = l == 2 ? 1.0f : 0.0f;
+      const float up = q4::bc<2>(q4::quat_rotate(q, axis_z));  // quat_axis(q, 2).z
+      const float tilt = fabsf(1.0f - up);
+      const float spin = fsqrt(q4::dot3(d.wbody, d.wbody));
+      // 0.2 / (0.1 + tilt^2) and 1 / (1 + spin^2): one division (lanes 0 / 1)
+      const float quo = (l == 0 ? 0.2f : 1.0f) / (l == 0 ? 0.1f + tilt * tilt : 1.0f + spin * spin);
+      const float up_reward = q4::bc<0>(quo);
+      const float ang_reward = q4::bc<1>(quo) * 3.0f;
+      float total = pos_reward + dist_reward + pos_reward * (up_reward + ang_reward);
+      total = 1.0f * total;
+      if (dist > 8.0f) crashed = true;
+      if (crashed) total = -20.0f;
+      rew = total;
+      trunc = steps > T.episode_len;
+      reset = (crashed && T.reset_on_collision) || trunc;
+    }
+    if (l == 0) {
+      B.sim_steps[i] = steps;
+      if (T.kind == AGX_TASK_POSITION) {
+        T.reward[i] = rew;
+        B.reset_mask[i] = reset ? 1 : 0;
+      }
+      B.crashes[i] = crashed ? 1 : 0;
+      B.truncations[i] = trunc ? 1 : 0;
+    }
+  }
+  if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+}
+
 __global__ void __launch_bounds__(256) k_update_states(AgxEnvBuffers B, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1130,6 +1346,18 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   return AGX_OK;
 }
 
+// The four-lanes-per-env kernel covers the plain quadrotor position step; AGX_ENV_STEP_QUAD=0 keeps k_env_step (A/B runs).
+static bool quad_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, const AgxTaskArgs *T) {
+  const char *e = getenv("AGX_ENV_STEP_QUAD");  // looked up per launch: tests flip it inside one process
+  if ((e && e[0] == '0') || B->boxes || B->launch_flags != 0 || B->disturb || B->disturb_prob > 0.0f || P->num_actions != 4) return false;
+  if (T->kind != AGX_TASK_NONE && T->kind != AGX_TASK_POSITION) return false;
+  for (int c = 0; c < 3; ++c)
+    if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
+        P->ang_drag_quadratic[c] != 0.0f)
+      return false;
+  return true;
+}
+
 template <int M, int CTRL, bool WIDE>
 static void launch_env_step(int k, int n, int block, size_t lds, hipStream_t stream, const AgxRobotParams &P, const AgxEnvBuffers &B,
                             const float *actions_in, const AgxTaskArgs &T) {
@@ -1161,6 +1389,11 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   }
   const int block = pick_block(n);
   const size_t lds = B->boxes ? (size_t)k * 3 * block * sizeof(float) : 0;
+  if (k == 1 && block == 64 && P->num_motors == 4 && P->controller == AGX_CTRL_POSITION && quad_kernel_usable(P, B, &T)) {
+    hipLaunchKernelGGL(k_env_step_quad_position, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, actions_in,
+                       T);
+    return check_launch("agx_env_step");
+  }
   AGX_DISPATCH_M(P->num_motors,
                  AGX_DISPATCH_CTRL(P->controller, {
                    if (block == 64)

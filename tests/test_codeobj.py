@@ -53,6 +53,16 @@ def test_env_step_instances_and_spills(meta):
     print("k_env_step instances with spills or a private segment (M, ctrl, single, wide, vgpr spills, bytes):", report)
 
 
+def test_four_lanes_per_env_kernel(meta):
+    """k_env_step_quad_position (BASELINE configs 1/2): 16 envs per wave, compiled for one wave per SIMD; no spill, no scratch,
+    no LDS (components travel between the lanes of a quad as DPP operand modifiers)."""
+    ks = {n: r for n, r in meta.items() if "k_env_step_quad_position" in n}
+    assert len(ks) == 1
+    r = next(iter(ks.values()))
+    assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
+    assert r["group_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64 and r["vgpr_count"] <= 128, r
+
+
 def test_wide_env_step_kernels_issue_no_scratch_instruction():
     """`.private_segment_fixed_size` of some WIDE k-loop instances is non-zero (frame slots the SGPR spiller
     reserved and then did not need); what matters is that no scratch instruction is ever issued."""

@@ -239,6 +239,56 @@ def test_step_is_graph_capture_safe():
         cfg.episode_len_steps = 500
 
 
+@pytest.mark.parametrize("n,randomize", [(8192, False), (1000, True), (17, False)])
+def test_four_lanes_per_env_kernel_is_bit_identical_to_the_one_lane_kernel(n, randomize, monkeypatch):
+    """k_env_step_quad_position (agx_quad_math.h: a 3-vector / quaternion per register, components in the lanes of a quad)
+    against k_env_step<4, position>: the same IEEE operations in the same order, so every buffer the step touches is equal
+    bit for bit -- over several episodes, with per-env (randomised) gains / motor constants too, and with a partial last
+    wave.  AGX_ENV_STEP_QUAD=0 selects the one-lane kernel."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg.device, cfg.controller_name, cfg.episode_len_steps, cfg.args = DEV, "lee_position_control", 40, {}
+    ctl_cfg = None
+    try:
+        if randomize:  # per-env gains (B.gains bound) instead of the uniform kernel-argument constants
+            from aerial_gym_simulator_amd.config.controller_config import lee_controller_config as ctl_cfg
+
+            old_rand = ctl_cfg.randomize_params
+            ctl_cfg.randomize_params = True
+        one = task_registry.make_task("position_setpoint_task", seed=21, num_envs=n, headless=True)
+        four = task_registry.make_task("position_setpoint_task", seed=21, num_envs=n, headless=True)
+        one.reset()
+        four.reset()
+        g = torch.Generator(device=DEV).manual_seed(9)
+        for t in range(130):
+            a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
+            if t % 17 == 3:
+                a = a * 30.0  # beyond the +-10 clip
+            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "0")
+            one.step(a)
+            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "1")
+            four.step(a)
+            for k in ("robot_state_tensor", "robot_actions", "robot_prev_actions", "robot_euler_angles", "robot_body_linvel",
+                      "robot_body_angvel", "robot_vehicle_orientation", "robot_vehicle_linvel"):
+                assert torch.equal(one.obs_dict[k], four.obs_dict[k]), (t, k, (one.obs_dict[k] - four.obs_dict[k]).abs().max())
+            assert torch.equal(one.task_obs["observations"], four.task_obs["observations"]), t
+            assert torch.equal(one.rewards, four.rewards), (t, (one.rewards - four.rewards).abs().max())
+            assert torch.equal(one.truncations, four.truncations) and torch.equal(one.terminations, four.terminations), t
+            e1, e2 = one.sim_env, four.sim_env
+            assert torch.equal(e1.sim_steps, e2.sim_steps), t
+            m1, m2 = e1.robot_manager.robot.control_allocator.motor_model, e2.robot_manager.robot.control_allocator.motor_model
+            assert torch.equal(m1.thrust_soa, m2.thrust_soa), (t, (m1.thrust_soa - m2.thrust_soa).abs().max())
+            w1, w2 = e1.global_tensor_dict.get("robot_wrench_cmd"), e2.global_tensor_dict.get("robot_wrench_cmd")
+            if w1 is not None:
+                assert torch.equal(w1, w2), t
+    finally:
+        cfg.episode_len_steps = 500
+        if ctl_cfg is not None:
+            ctl_cfg.randomize_params = old_rand
+
+
 def test_config4_octarotor_lidar_task_runs():
     """BASELINE config 4 at small N: base_octarotor + octarotor_velocity_control + 32x512 LiDAR
     (range + segmentation), 10 sub-steps, disturbances on, sync-free."""
