@@ -201,6 +201,8 @@ _SIGNATURES = {
     ),
     "agx_obs_navigation": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, _P, _P, _P]),
+    "agx_env_step_kernel": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxTaskArgs),
+                                      C.c_char_p, C.c_int]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
     "agx_post_step_position": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P]),
     "agx_position_task_step": (C.c_int, [C.POINTER(AgxPositionStepPlan), _P, _P]),

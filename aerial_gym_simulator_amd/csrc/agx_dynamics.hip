@@ -1256,6 +1256,74 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
   if (WITH_OBS) step_rows_signal(B);
 }
 
+// k_reset_masked<4, WITH_OBS> with four lanes per env (see k_env_step_quad_position): the refresh of every env's derived
+// tensors and the observation are vector work; the reset of an env itself (rare: a few of 8192 per step) stays the scalar
+// code, run by the first lane of the env's quad, which then hands the new state to the other three.
+__global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
+                                                                 const float *__restrict__ target, float *__restrict__ obs) {
+  const int tid = threadIdx.x;
+  const int l = tid & 3, l3 = l < 3 ? l : 2;
+  const int i = blockIdx.x * 16 + (tid >> 2);
+  if (blockIdx.x == 0 && tid == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
+  const bool valid = i < n;
+  float p = 0.0f, q = 0.0f, v = 0.0f, w = 0.0f, vbody = 0.0f, wbody = 0.0f, tgt = 0.0f;
+  bool mine = false;
+  int ep = 0;
+  if (valid) {  // every load before the flag is looked at
+    p = AGX_AT(B.state, 0 + l3); q = AGX_AT(B.state, 3 + l); v = AGX_AT(B.state, 7 + l3); w = AGX_AT(B.state, 10 + l3);
+    vbody = AGX_AT(B.derived, 10 + l3); wbody = AGX_AT(B.derived, 13 + l3);
+    tgt = AGX_AT(target, l3);
+    mine = B.reset_mask[i] != 0;
+    if (B.episode_count) ep = B.episode_count[i];
+  }
+  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  if (any) {
+    const bool lead = mine && l == 0;
+    ResetDraws<4> D{};
+    if (R.u_state) {
+      if (lead) host_reset_draws<4>(P, R, i, D);
+    } else {
+      wave_reset_draws<4>(R, B.env_index_base + i, ep, lead, D);  // draws are keyed by the GLOBAL env index
+    }
+    if (__ballot(mine) != 0ull) {  // some env of this wave resets
+      EnvState s{};
+      if (lead) s = reset_env<4>(P, B, n, R, i, ep, D);
+      // the quad takes the new state over from its first lane
+      const float npv = q4::by_lane(l3, q4::bc<0>(s.p.x), q4::bc<0>(s.p.y), q4::bc<0>(s.p.z));
+      const float nq = q4::by_lane(l, q4::bc<0>(s.q.x), q4::bc<0>(s.q.y), q4::bc<0>(s.q.z), q4::bc<0>(s.q.w));
+      const float nv = q4::by_lane(l3, q4::bc<0>(s.v.x), q4::bc<0>(s.v.y), q4::bc<0>(s.v.z));
+      const float nw = q4::by_lane(l3, q4::bc<0>(s.w.x), q4::bc<0>(s.w.y), q4::bc<0>(s.w.z));
+      p = mine ? npv : p; q = mine ? nq : q; v = mine ? nv : v; w = mine ? nw : w;
+    }
+    // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
+    const QuadDerived d = update_states_quad(q, v, w);
+    if (valid) {
+      if (l < 3) {
+        AGX_AT(B.derived, 0 + l) = d.euler;
+        AGX_AT(B.derived, 7 + l) = d.vveh;
+        AGX_AT(B.derived, 10 + l) = d.vbody;
+        AGX_AT(B.derived, 13 + l) = d.wbody;
+      }
+      AGX_AT(B.derived, 3 + l) = d.qveh;
+    }
+    vbody = d.vbody;
+    wbody = d.wbody;
+  }
+  if (valid) {  // position_setpoint_task.py:194-203: target - p | q | v_body | w_body
+    float *o = obs + (size_t)i * 13;
+    const float e = tgt - p;
+    if (l < 3) { o[l] = e; o[7 + l] = vbody; o[10 + l] = wbody; }
+    o[3 + l] = q;
+    if (float *rows = B.step_rows[B.flag_parity]) {
+      float *r = rows + (size_t)i * 16;
+      if (l < 3) { row_store(r + l, e); row_store(r + 7 + l, vbody); row_store(r + 10 + l, wbody); }
+      row_store(r + 3 + l, q);
+      if (l == 0) write_step_row_tail(B, i, r, 13);
+    }
+  }
+  step_rows_signal(B);
+}
+
 // AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295)
 __global__ void __launch_bounds__(256) k_reset_assets(AgxEnvBuffers B, int n, int K, AgxResetArgs R, const float *__restrict__ u1,
                                                        const float *__restrict__ u2, const float *__restrict__ u_sel,
@@ -1404,6 +1472,20 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   return check_launch("agx_env_step");
 }
 
+extern "C" int agx_env_step_kernel(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, int k, const AgxTaskArgs *task, char *out,
+                                   int cap) {
+  AGX_REQUIRE(P && B && out && cap > 0 && n > 0, "bad arguments");
+  AgxTaskArgs T{};
+  if (task) T = *task;
+  const int block = pick_block(n);
+  if (k == 1 && block == 64 && P->num_motors == 4 && P->controller == AGX_CTRL_POSITION && quad_kernel_usable(P, B, &T))
+    snprintf(out, (size_t)cap, "k_env_step_quad_position_%d", blocks_for(n, 16) * 64);
+  else
+    snprintf(out, (size_t)cap, "k_env_step<%d,%d,%s,%s>_%d", P->num_motors, P->controller, k == 1 ? "true" : "false",
+             block == 64 ? "true" : "false", blocks_for(n, block) * block);
+  return AGX_OK;
+}
+
 extern "C" int agx_dynamics_substeps(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *actions_in,
                                      int k, void *stream) {
   return agx_env_step(P, B, n, actions_in, k, nullptr, stream);
@@ -1504,6 +1586,11 @@ extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffe
   if (int e = check_reset(P, B, n, R)) return e;
   AGX_REQUIRE(target && obs && B->state && B->derived, "null buffer");
   const int block = pick_block(n);
+  const char *qe = getenv("AGX_ENV_STEP_QUAD");
+  if (block == 64 && P->num_motors == 4 && !(qe && qe[0] == '0')) {
+    hipLaunchKernelGGL(k_reset_masked_quad_obs, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, *R, target, obs);
+    return check_launch("agx_post_step_position");
+  }
   AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, true>), dim3(blocks_for(n, block)), dim3(block), 0,
                                                    (hipStream_t)stream, *P, *B, n, *R, target, obs));
   return check_launch("agx_post_step_position");

@@ -193,13 +193,14 @@ def valu_roofline(kernel_key, launch_s):
 
 
 def env_step_key(task, k):
-    """key of the env-step kernel instance in the PMC file: template arguments + grid size in threads"""
+    """key of the env-step kernel instance in the PMC file (template arguments + grid size in threads), as the library
+    names the instance it launches for these arguments"""
+    import ctypes as C
+
     env = task.sim_env
-    P, n = env._params, env.num_envs
-    wide = n <= 65536
-    block = 64 if wide else 256
-    grid = ((n + block - 1) // block) * block
-    return "k_env_step<%d,%d,%s,%s>_%d" % (P.num_motors, P.controller, "true" if k == 1 else "false", "true" if wide else "false", grid)
+    buf = C.create_string_buffer(128)
+    env._lib.agx_env_step_kernel(env._params, env._buffers, env.num_envs, int(k), env.task_args, buf, 128)
+    return buf.value.decode()
 
 
 def raycast_grid_threads(task):
@@ -597,7 +598,7 @@ def main():
         vr = valu_roofline(ekey, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9,
                                          "unit": "G wave64-instr/s", "frac": None}
         out["roofline"] = dict(vr, **{
-            "kernel": "k_env_step<4, position> (k sub-steps + reward epilogue)",
+            "kernel": ekey.rsplit("_", 1)[0] + " (sub-step(s) + reward epilogue)",
             "launch_us": kt * 1e6,
             "traffic": pmc_traffic(ekey),
             "traffic_stale": pmc_stale(),

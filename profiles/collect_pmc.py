@@ -24,7 +24,8 @@ def load(path, counter):
             import re
 
             m = re.search(r"k_env_step<([^>]*)>", name)  # <motors, controller id, single sub-step, one-wave workgroups>
-            key = ("k_env_step<%s>" % m.group(1).replace(" ", "") if m else "k_env_step", int(r["Grid_Size"]))
+            key = ("k_env_step<%s>" % m.group(1).replace(" ", "") if m
+                   else ("k_env_step_quad_position" if "k_env_step_quad_position" in name else "k_env_step"), int(r["Grid_Size"]))
         elif "k_raycast" in name:
             import re
 
