@@ -168,12 +168,6 @@ typedef struct AgxEnvBuffers {
 const char *agx_last_error(void);
 int agx_abi_version(void);
 
-/* Which kernel instance agx_env_step launches for these arguments, as "<kernel name incl. template arguments>_<grid size
- * in threads>" (e.g. "k_env_step<4,2,false,true>_8192", "k_env_step_quad_position_32768"): the key under which profilers
- * list it (bench.py pairs its live launch time with the committed rocprofv3 counters of that instance).             */
-int agx_env_step_kernel(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, int k_substeps,
-                        const AgxTaskArgs *task, char *out, int out_capacity);
-
 /* ---- dynamics -------------------------------------------------------------------
  * agx_dynamics_substeps: `k` physics sub-steps of every env, fused in one launch.
  * Replaces, per sub-step: RobotManagerIGE.pre_physics_step (robot_manager.py:486-489),
@@ -206,6 +200,12 @@ typedef struct AgxTaskArgs {
  * in ONE launch (task may be NULL or kind NONE).                                           */
 int agx_env_step(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                  const float *actions_in, int k_substeps, const AgxTaskArgs *task, void *stream);
+
+/* Which kernel instance agx_env_step launches for these arguments, as "<kernel name incl. template arguments>_<grid size
+ * in threads>" (e.g. "k_env_step<4,2,false,true>_8192", "k_env_step_quad_position_32768"): the key under which profilers
+ * list it (bench.py pairs its live launch time with the committed rocprofv3 counters of that instance).             */
+int agx_env_step_kernel(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, int k_substeps,
+                        const AgxTaskArgs *task, char *out, int out_capacity);
 
 /* BaseMultirotor.update_states alone (base_multirotor.py:287-294). */
 int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
