@@ -1001,22 +1001,39 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     // (each lane keeps the minimum of its column over the rows of the cell row), then the columns of one cell are
     // reduced across lanes.  min is exact and order-free, so any arrangement gives the bits of the serial loop.
     const float *img = pixels + (size_t)i * ns * H * W;  // sensor 0
-    const int ch = (H + gh - 1) / gh, cw = (W + gw - 1) / gw;
+    const int ch = (H + gh - 1) / gh;
+    // wide images (W >= 256, cells a multiple of 4 pixels wide: the 32 x 512 LiDAR): a lane takes 4 consecutive pixels per
+    // load (1 KB per wave instruction instead of 256 B) and the sweep below runs over these groups of 4
+    const bool vec4 = (W & 3) == 0 && W >= 256 && (((W + gw - 1) / gw) & 3) == 0 && ((size_t)img & 15) == 0;
+    const int Wv = vec4 ? W >> 2 : W;                    // columns the sweep sees
+    const int cw = ((W + gw - 1) / gw) >> (vec4 ? 2 : 0);  // cell width in such columns
     const bool pow2 = (cw & (cw - 1)) == 0 && cw < 64;
     float imin = INFINITY;  // NavigationTask.post_image_reward_addition on the same sweep (min_pixel != NULL, ns == 1)
     for (int cy = 0; cy < gh; ++cy) {
       const int y0 = cy * ch, y1 = min(y0 + ch, H);
       float cell = INFINITY;  // lane c < gw: cell (cy, c)
-      for (int x0 = 0; x0 < W && y0 < y1; x0 += 64) {
+      for (int x0 = 0; x0 < Wv && y0 < y1; x0 += 64) {
         const int x = x0 + lane;
         float m = INFINITY;
-        if (x < W) {
+        if (x < Wv) {
           for (int y = y0; y < y1; ++y) {
-            const float v = img[(size_t)y * W + x];
-            m = fminf(m, v);
-            float v10 = 10.0f * v;
-            if (v10 < 0.0f) v10 = 10.0f;
-            imin = fminf(imin, v10);
+            if (vec4) {
+              const float4 v4 = *reinterpret_cast<const float4 *>(img + (size_t)y * W + 4 * x);
+              const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                m = fminf(m, vv[k]);
+                float v10 = 10.0f * vv[k];
+                if (v10 < 0.0f) v10 = 10.0f;
+                imin = fminf(imin, v10);
+              }
+            } else {
+              const float v = img[(size_t)y * W + x];
+              m = fminf(m, v);
+              float v10 = 10.0f * v;
+              if (v10 < 0.0f) v10 = 10.0f;
+              imin = fminf(imin, v10);
+            }
           }
         }
         if (pow2) {  // cells are aligned groups of cw lanes: butterfly inside the group, lane c fetches its group's value
@@ -1025,9 +1042,9 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
           const float t = __shfl(m, src & 63);
           if (src >= 0 && src < 64 && lane < gw) cell = fminf(cell, t);
         } else {
-          const int c_lo = x0 / cw, c_hi = min(x0 + 63, W - 1) / cw;
-          for (int c = c_lo; c <= c_hi; ++c) {  // wave-uniform: the cells this 64-pixel chunk touches
-            float t = (x < W && x / cw == c) ? m : INFINITY;
+          const int c_lo = x0 / cw, c_hi = min(x0 + 63, Wv - 1) / cw;
+          for (int c = c_lo; c <= c_hi; ++c) {  // wave-uniform: the cells this 64-column chunk touches
+            float t = (x < Wv && x / cw == c) ? m : INFINITY;
             for (int off = 32; off > 0; off >>= 1) t = fminf(t, __shfl_xor(t, off));
             if (lane == c) cell = fminf(cell, t);
           }
