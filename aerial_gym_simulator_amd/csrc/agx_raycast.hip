@@ -87,7 +87,7 @@ __device__ unsigned long long g_ray_stats[8];
 #endif
 
 struct Ray {
-  V3 o, d;
+  V3 op, d;   // op: the origin's components in the order (kx, ky, kz) the triangle test uses them
   V3 rcp, orcp;  // 1 / d clamped to +-1e30, and o * rcp (slab test only; the triangle test uses d)
   int kz;     // dominant axis
   bool swap;  // d[kz] < 0 : kx/ky swapped
@@ -100,7 +100,6 @@ struct Ray {
 AGX_DEV float pick(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 
 AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
-  r.o = o;
   r.d = d;
   const float kRcpMax = 1.0e30f;
   r.rcp = V3{fminf(fmaxf(1.0f / d.x, -kRcpMax), kRcpMax), fminf(fmaxf(1.0f / d.y, -kRcpMax), kRcpMax),
@@ -114,6 +113,7 @@ AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
   r.swap = dz < 0.0f;
   if (r.swap) { int t = kx; kx = ky; ky = t; }
   r.kz = kz;
+  r.op = V3{pick(o, kx), pick(o, ky), pick(o, kz)};
   r.Sx = pick(d, kx) / dz;
   r.Sy = pick(d, ky) / dz;
   r.Sz = 1.0f / dz;
@@ -122,17 +122,37 @@ AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
   r.active = active;
 }
 
-// warp intersect.h intersect_ray_tri_woop (t only)
+// warp intersect.h intersect_ray_tri_woop (t only).
+// The vertices are wave-uniform (scalar loads); which of their components plays x / y / z depends on the ray's dominant
+// axis.  `ukz` >= 0: every active ray of the packet has the same dominant axis and orientation (`ukz`, `uswap`: the usual
+// case for an 8 x 8 pixel tile or a 16 x 4 LiDAR bundle) -- the component choice is then made ONCE on the scalar unit
+// instead of with two v_cndmask per component and lane (18 of the ~95 vector instructions of a triangle test): the leaf
+// test switches on the packet's (axis, orientation) into one of six instances with the components fixed at compile time.
+// Mixed packet: per-lane choice.  Same operands, same operations either way.
+// UPID: 2 * kz + swap when known at compile time (the caller switches on the packet's wave-uniform value), -1 = per lane
+template <int UPID>
 AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
-  V3 A = a - r.o, B = b - r.o, C = c - r.o;
-  int kz = r.kz;
-  int kx = kz == 2 ? 0 : kz + 1;
-  int ky = kx == 2 ? 0 : kx + 1;
-  if (r.swap) { int t = kx; kx = ky; ky = t; }
-  float Akz = pick(A, kz), Bkz = pick(B, kz), Ckz = pick(C, kz);
-  float Ax = pick(A, kx) - r.Sx * Akz, Ay = pick(A, ky) - r.Sy * Akz;
-  float Bx = pick(B, kx) - r.Sx * Bkz, By = pick(B, ky) - r.Sy * Bkz;
-  float Cx = pick(C, kx) - r.Sx * Ckz, Cy = pick(C, ky) - r.Sy * Ckz;
+  float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz;
+  if (UPID >= 0) {
+    constexpr int kz = UPID >> 1;
+    constexpr int kx0 = kz == 2 ? 0 : kz + 1;
+    constexpr int ky0 = kx0 == 2 ? 0 : kx0 + 1;
+    constexpr int kx = (UPID & 1) ? ky0 : kx0, ky = (UPID & 1) ? kx0 : ky0;
+    Akx = pick(a, kx) - r.op.x; Aky = pick(a, ky) - r.op.y; Akz = pick(a, kz) - r.op.z;
+    Bkx = pick(b, kx) - r.op.x; Bky = pick(b, ky) - r.op.y; Bkz = pick(b, kz) - r.op.z;
+    Ckx = pick(c, kx) - r.op.x; Cky = pick(c, ky) - r.op.y; Ckz = pick(c, kz) - r.op.z;
+  } else {
+    int kz = r.kz;
+    int kx = kz == 2 ? 0 : kz + 1;
+    int ky = kx == 2 ? 0 : kx + 1;
+    if (r.swap) { int t = kx; kx = ky; ky = t; }
+    Akx = pick(a, kx) - r.op.x; Aky = pick(a, ky) - r.op.y; Akz = pick(a, kz) - r.op.z;
+    Bkx = pick(b, kx) - r.op.x; Bky = pick(b, ky) - r.op.y; Bkz = pick(b, kz) - r.op.z;
+    Ckx = pick(c, kx) - r.op.x; Cky = pick(c, ky) - r.op.y; Ckz = pick(c, kz) - r.op.z;
+  }
+  float Ax = Akx - r.Sx * Akz, Ay = Aky - r.Sy * Akz;
+  float Bx = Bkx - r.Sx * Bkz, By = Bky - r.Sy * Bkz;
+  float Cx = Ckx - r.Sx * Ckz, Cy = Cky - r.Sy * Ckz;
   float U = diff_product(Cx, By, Cy, Bx);
   float V = diff_product(Ax, Cy, Ay, Cx);
   float W = diff_product(Bx, Ay, By, Ax);
@@ -158,11 +178,22 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
 
 // ANY: occlusion query -- the first accepted hit retires the lane (it stops voting in ray_box)
 template <bool ANY>
-AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want) {
+AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want, int upid) {
   if (!want) return;
   const float *t = tris + (size_t)f * 9;
   float th;
-  if (ray_tri(r, V3{t[0], t[1], t[2]}, V3{t[3], t[4], t[5]}, V3{t[6], t[7], t[8]}, th)) {
+  const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
+  bool hit;
+  switch (upid) {  // wave-uniform
+    case 0: hit = ray_tri<0>(r, a, b, c, th); break;
+    case 1: hit = ray_tri<1>(r, a, b, c, th); break;
+    case 2: hit = ray_tri<2>(r, a, b, c, th); break;
+    case 3: hit = ray_tri<3>(r, a, b, c, th); break;
+    case 4: hit = ray_tri<4>(r, a, b, c, th); break;
+    case 5: hit = ray_tri<5>(r, a, b, c, th); break;
+    default: hit = ray_tri<-1>(r, a, b, c, th); break;
+  }
+  if (hit) {
     if (ANY) {
       if (th >= 0.0f && th < r.best) {
         r.face = f;
@@ -199,8 +230,18 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
 template <bool ANY = false>
 AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  // do all active rays of the packet share the dominant axis and its orientation?
+  int upid = -1;  // 2 * kz + swap, or -1 (mixed)
+  {
+    const int pid = r.kz * 2 + (r.swap ? 1 : 0);
+    const unsigned long long act = __ballot(r.active);
+    if (act) {
+      const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
+      if (__ballot(r.active && pid != p0) == 0ull) upid = p0;
+    }
+  }
   if (nt == 1) {
-    test_leaf<ANY>(r, tris, 0, r.active);
+    test_leaf<ANY>(r, tris, 0, r.active, upid);
     return;
   }
   int sp = 0;
@@ -220,16 +261,16 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     unsigned long long ml = __ballot(hl), mr = __ballot(hr);
     if (cl < 0) {
       if (ml) {
-        test_leaf<ANY>(r, tris, ~cl, hl);
-        if (cl2 >= 0) test_leaf<ANY>(r, tris, cl2, hl);
+        test_leaf<ANY>(r, tris, ~cl, hl, upid);
+        if (cl2 >= 0) test_leaf<ANY>(r, tris, cl2, hl, upid);
         AGX_STAT(2, cl2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(ml));
       }
       ml = 0;
     }
     if (cr < 0) {
       if (mr) {
-        test_leaf<ANY>(r, tris, ~cr, hr);
-        if (cr2 >= 0) test_leaf<ANY>(r, tris, cr2, hr);
+        test_leaf<ANY>(r, tris, ~cr, hr, upid);
+        if (cr2 >= 0) test_leaf<ANY>(r, tris, cr2, hr, upid);
         AGX_STAT(2, cr2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(mr));
       }
       mr = 0;
@@ -294,14 +335,17 @@ AGX_DEV float apply_range_limits(const RangeEpilogue &RL, float p) {
 enum { RAY_BASIC = 0, RAY_NORMAL = 1, RAY_STEREO = 2 };
 constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
 
-// Register budget: BASIC / NORMAL need 57-61 VGPRs (8 waves per SIMD); STEREO carries two rays' worth of state over the
-// second traversal and would take 67 (7 waves per SIMD): it is compiled for 8 waves (64 VGPRs, a few more SGPR spills),
-// measured 1.26 -> 1.14 ms per 2048-env stereo frame (profiles/r02_raycast_variants.txt).
+// Register budget: every instance is compiled for 8 waves per SIMD (64 VGPRs; BASIC / NORMAL fit without a VGPR spill)
+// except STEREO, which carries two rays' worth of state over the second traversal next to the six compile-time instances
+// of the triangle test: 6 waves (80 VGPRs), no spill.  Measured round 2 (profiles/r02_raycast_variants.txt).
+#ifndef AGX_RAY_WAVES
+#define AGX_RAY_WAVES 8
+#endif
 #ifndef AGX_RAY_STEREO_WAVES
-#define AGX_RAY_STEREO_WAVES 8
+#define AGX_RAY_STEREO_WAVES 6
 #endif
 template <bool LIDAR, bool USE_LDS, int VARIANT>
-__global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : 1) k_raycast(CamArgs CA, LidarArgs LA, RangeEpilogue RL, const float *__restrict__ ray_vectors,
+__global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : AGX_RAY_WAVES) k_raycast(CamArgs CA, LidarArgs LA, RangeEpilogue RL, const float *__restrict__ ray_vectors,
                                                           const float *__restrict__ sensor_pos,
                                                           const float *__restrict__ sensor_quat,
                                                           const float *__restrict__ tri_world,

@@ -6,7 +6,7 @@ libaerialgym_hip.so (no GPU needed).  Guards what DESIGN.md section 3 states abo
 * the straight-line quadrotor kernels of BASELINE configs 1/2 (`SINGLE`, 256-thread workgroups, 3 waves per
   SIMD) have no spill and no scratch either;
 * the ray-cast kernels of configs 3/4 (BASIC / NORMAL, camera and LiDAR) stay at <= 64 VGPRs (8 waves per
-  SIMD), stereo included; none of them uses scratch or static LDS."""
+  SIMD), the stereo variant at <= 80 (6 waves); none of them uses scratch or static LDS."""
 import os
 import re
 import subprocess
@@ -100,7 +100,8 @@ def test_raycast_kernels_fit_eight_waves_per_simd(meta):
     for name, r in rays.items():
         variant = int(re.match(r"void agx::k_raycast<(true|false), false, (\d)>", name).group(2))
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["group_segment_fixed_size"] == 0, name
-        assert r["vgpr_count"] <= 64, (name, r["vgpr_count"])  # stereo included (compiled for 8 waves per SIMD)
+        # BASIC / NORMAL: 8 waves per SIMD; STEREO (two rays' state + the six instances of the triangle test): 6
+        assert r["vgpr_count"] <= (80 if variant == 2 else 64), (name, r["vgpr_count"])
 
 
 def test_no_kernel_of_the_hot_path_uses_scratch(meta):
