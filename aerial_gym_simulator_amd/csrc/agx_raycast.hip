@@ -226,6 +226,8 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
 }
 
+AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
+
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
 template <bool ANY = false>
@@ -234,10 +236,10 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
   int upid = -1;  // 2 * kz + swap, or -1 (mixed)
   {
     const int pid = r.kz * 2 + (r.swap ? 1 : 0);
-    const unsigned long long act = __ballot(r.active);
+    const unsigned long long act = vote(r.active);
     if (act) {
       const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
-      if (__ballot(r.active && pid != p0) == 0ull) upid = p0;
+      if (vote(r.active && pid != p0) == 0ull) upid = p0;
     }
   }
   if (nt == 1) {
@@ -258,7 +260,7 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     float tl, tr;
     bool hl = ray_box(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
     bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
-    unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+    unsigned long long ml = vote(hl), mr = vote(hr);
     if (cl < 0) {
       if (ml) {
         test_leaf<ANY>(r, tris, ~cl, hl, upid);
@@ -278,8 +280,8 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     int next = -1;
     if (ml && mr) {
       // majority vote on which child is nearer among lanes that hit both
-      unsigned long long both = __ballot(hl && hr);
-      unsigned long long lfirst = __ballot(hl && hr && tl <= tr);
+      unsigned long long both = vote(hl && hr);
+      unsigned long long lfirst = vote(hl && hr && tl <= tr);
       bool left_first = both ? (2 * __popcll(lfirst) >= __popcll(both)) : (__popcll(ml) >= __popcll(mr));
       next = left_first ? cl : cr;
       int far = left_first ? cr : cl;
