@@ -641,6 +641,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 // split launches, other controllers / motor counts.
 // ---------------------------------------------------------------------------------------
 namespace q4 = quad;
+AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // BaseMultirotor.update_states (base_multirotor.py:287-294) of one env on its lane quad
 struct QuadDerived {
@@ -836,6 +837,289 @@ __global__ void __launch_bounds__(64, 1)
     if (l == 0) {
       B.sim_steps[i] = steps;
       if (T.kind == AGX_TASK_POSITION) {
+        T.reward[i] = rew;
+        B.reset_mask[i] = reset ? 1 : 0;
+      }
+      B.crashes[i] = crashed ? 1 : 0;
+      B.truncations[i] = trunc ? 1 : 0;
+    }
+  }
+  if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+}
+
+// ---------------------------------------------------------------------------------------
+// Four lanes per env for the sub-step LOOP of the navigation tasks (BASELINE configs 2 / 4 and the LiDAR navigation
+// task): quadrotor, Lee velocity or acceleration control, k sub-steps, obstacles, device disturbance draws, navigation
+// reward epilogue.  Same contract as k_env_step_quad_position: per component the IEEE operations of
+// k_env_step<4, CTRL, false, .> in the same order.  The obstacle test splits the env's boxes over the four lanes (the flag
+// is a boolean OR: any order).
+// ---------------------------------------------------------------------------------------
+// base_lee_controller.py:201-215 on the quad: (1 0 -sp; 0 cr sr cp; 0 -sr cr cp) (0, 0, rz)
+AGX_DEV float euler_rates_to_body_rates_quad(float euler, float rz) {
+  const int l = q4::lane_in_quad();
+  float sn, cs;
+  sincos_bounded(euler, sn, cs);  // lane 0: roll, lane 1: pitch
+  const float sr = q4::bc<0>(sn), cr = q4::bc<0>(cs), sp = q4::bc<1>(sn), cp = q4::bc<1>(cs);
+  const float m0 = q4::by_lane(l, 1.0f, 0.0f, 0.0f);
+  const float m1 = q4::by_lane(l, 0.0f, cr, -sr);
+  const float m2 = q4::by_lane(l, -sp, sr * cp, cr * cp);
+  return (m0 * 0.0f + m1 * 0.0f) + m2 * rz;
+}
+// utils/math.py:156-172 (quat_from_euler_xyz) with (roll, pitch, yaw) in lanes 0..2 of `ang`
+AGX_DEV float quat_from_euler_quad(float ang) {
+  const int l = q4::lane_in_quad();
+  float sn, cs;
+  sincos_bounded(ang * 0.5f, sn, cs);
+  const float sr = q4::bc<0>(sn), cr = q4::bc<0>(cs), sp = q4::bc<1>(sn), cp = q4::bc<1>(cs), sy = q4::bc<2>(sn), cy = q4::bc<2>(cs);
+  // x: cy sr cp - sy cr sp   y: cy cr sp + sy sr cp   z: sy cr cp - cy sr sp   w: cy cr cp + sy sr sp
+  const float a1 = l == 2 ? sy : cy, b1 = l == 0 ? sr : cr, c1 = l == 1 ? sp : cp;
+  const float a2 = l == 2 ? cy : sy, b2 = l == 0 ? cr : sr, c2 = l == 1 ? cp : sp;
+  const float t1 = a1 * b1 * c1, t2 = a2 * b2 * c2;
+  return (l == 0 || l == 2) ? t1 - t2 : t1 + t2;
+}
+
+template <int CTRL>
+__global__ void __launch_bounds__(64, 1)
+    k_env_step_quad_loop(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k, AgxTaskArgs T) {
+  static_assert(CTRL == AGX_CTRL_VELOCITY || CTRL == AGX_CTRL_ACCELERATION, "control laws built in quad form");
+  extern __shared__ float traj[];  // [k][3][16] sub-step positions of the wave's 16 envs (only with obstacles)
+  const int tid = threadIdx.x;
+  const int l = tid & 3, l3 = l < 3 ? l : 2, slot = tid >> 2;
+  const int i = blockIdx.x * 16 + slot;
+  bool reset = false;
+  if (i < n) {
+    float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
+    float u = AGX_AT(B.motor_thrust, l);
+    const float kT = P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f;
+    const float tinc = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform;
+    const float tdec = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform;
+    const float a_in = actions_in[(size_t)i * 4 + l];
+    const float a_old = AGX_AT(B.actions, l);
+    const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
+    const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
+    const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
+    const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
+    const float grav = P.gravity[l3];
+    const float in0 = P.inertia[3 * l3 + 0], in1 = P.inertia[3 * l3 + 1], in2 = P.inertia[3 * l3 + 2];
+    const float ii0 = P.inertia_inv[3 * l3 + 0], ii1 = P.inertia_inv[3 * l3 + 1], ii2 = P.inertia_inv[3 * l3 + 2];
+    float pinv[6], mapf[4], mapt[4];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pinv[c] = P.alloc_pinv[6 * l + c];
+    const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mapf[j] = wmap[4 * l3 + j];
+      mapt[j] = wmap[4 * (3 + l3) + j];
+    }
+    const float dmax = B.disturb_max[l3], dmax_t = B.disturb_max[3 + l3];
+    const float mass = P.mass, dt = P.dt;
+    const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions (the same every sub-step)
+    QuadDerived d{};
+    float fz = 0.0f, torque = 0.0f, fb = 0.0f;
+    float tlo = p, thi = p;
+    for (int sub = 0; sub < k; ++sub) {
+      d = update_states_quad(q, v, w);
+      // ---- controller
+      float f, qd;
+      if (CTRL == AGX_CTRL_VELOCITY) {  // velocity_control.py:18-51
+        const float sp_vel_w = q4::quat_rotate(d.qveh, a);  // (a0, a1, a2) in the vehicle frame
+        const float pe = p - p;                             // position set-point = current position
+        const float ve = sp_vel_w - v;
+        const float acc = kp * pe + kv * ve;
+        f = (acc - grav) * mass;
+      } else {  // acceleration_control.py:16-45
+        f = (a - grav) * mass;
+      }
+      {
+        const float t1 = q * q4::bc<2>(q), t2 = q4::perm<1, 0, 2, 3>(q) * q4::bc<3>(q);
+        const float c2a = 2.0f * (l == 1 ? t1 - t2 : t1 + t2);
+        const float sqq = q * q;
+        const float m22 = 1.0f - 2.0f * (q4::bc<0>(sqq) + q4::bc<1>(sqq));
+        fz = q4::dot3(f, l == 2 ? m22 : c2a);
+      }
+      const float yaw = q4::bc<2>(d.euler);
+      if (CTRL == AGX_CTRL_VELOCITY) {  // desired_orientation_pos_vel(f, yaw)
+        const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
+        float sy, cy;
+        sincos_bounded(yaw, sy, cy);
+        const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
+        const float cb = q4::cross3(b3, tmp);
+        const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
+        const float b1 = q4::cross3(b2, b3);
+        qd = q4::rotmat_cols_to_quat(b1, b2, b3);
+      } else {  // desired_orientation_forces_yaw(f, yaw): pitch = atan2(f.x, f.z), roll = atan2(-f.y, sqrt(f.z^2 + f.x^2))
+        const float fx = q4::bc<0>(f), fy = q4::bc<1>(f), fzc = q4::bc<2>(f);
+        const float num = q4::by_lane(l, -fy, fx, 0.0f);
+        const float den = q4::by_lane(l, sqrtf(fzc * fzc + fx * fx), fzc, 1.0f);
+        const float ang = atan2_cw(num, den);
+        qd = quat_from_euler_quad(l == 2 ? yaw : ang);
+      }
+      // ---- compute_body_torque with the rate set-point euler_rates_to_body_rates(euler, (0, 0, a3))
+      float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
+      if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
+      const float qe = q4::quat_mul(q4::conj(q), qd);
+      const float pp = q4::rot1(qe) * q4::rot2(qe);
+      const float pw = qe * q4::bc<3>(qe);
+      const float mp = 2.0f * (pp + pw);
+      const float mm = 2.0f * (pp - pw);
+      const float rot_err = 0.5f * (l == 1 ? mm - mp : -(mp - mm));
+      const float wsp_b = q4::quat_rotate(qe, wsp);
+      const float wb = d.wbody;
+      const float jw = (in0 * q4::bc<0>(wb) + in1 * q4::bc<1>(wb)) + in2 * q4::bc<2>(wb);
+      const float ff = q4::cross3(wb, jw);
+      const float we = wb - wsp_b;
+      torque = ((-kr) * rot_err - kw * we) + ff;
+      // ---- allocation + motor model + body wrench
+      float r = 0.0f;
+      r += pinv[0] * 0.0f;
+      r += pinv[1] * 0.0f;
+      r += pinv[2] * fz;
+      r += pinv[3] * q4::bc<0>(torque);
+      r += pinv[4] * q4::bc<1>(torque);
+      r += pinv[5] * q4::bc<2>(torque);
+      u = motor_update(P, r, u, kT, tinc, tdec);
+      float tb = 0.0f;
+      fb = 0.0f;
+      const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
+      fb += mapf[0] * u0; fb += mapf[1] * u1; fb += mapf[2] * u2; fb += mapf[3] * u3;
+      tb += mapt[0] * u0; tb += mapt[1] * u1; tb += mapt[2] * u2; tb += mapt[3] * u3;
+      if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234), draws supplied by the host
+        const float *dd = B.disturb + (size_t)sub * 7 * n + i;
+        const float occ = dd[0];
+        fb += ((dmax - (-dmax)) * dd[(size_t)(1 + l3) * n] + (-dmax)) * occ;
+        tb += ((dmax_t - (-dmax_t)) * dd[(size_t)(4 + l3) * n] + (-dmax_t)) * occ;
+      } else if (B.disturb_prob > 0.0f) {  // same, drawn in place (every lane of the quad draws the env's 7 uniforms)
+        float ud[7];
+        rng_fill<7>(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_DISTURB + sub, ud);
+        const float occ = ud[0] < B.disturb_prob ? 1.0f : 0.0f;
+        fb += ((dmax - (-dmax)) * q4::by_lane(l3, ud[1], ud[2], ud[3]) + (-dmax)) * occ;
+        tb += ((dmax_t - (-dmax_t)) * q4::by_lane(l3, ud[4], ud[5], ud[6]) + (-dmax_t)) * occ;
+      }
+      // ---- integrate
+      const float fw = q4::quat_rotate(q, fb);
+      const float wbi = q4::quat_rotate_inverse(q, w);
+      const float jwi = (in0 * q4::bc<0>(wbi) + in1 * q4::bc<1>(wbi)) + in2 * q4::bc<2>(wbi);
+      const float rhs = tb - q4::cross3(wbi, jwi);
+      const float dwb = (ii0 * q4::bc<0>(rhs) + ii1 * q4::bc<1>(rhs)) + ii2 * q4::bc<2>(rhs);
+      const float wb_new = wbi + dt * dwb;
+      float w_new = q4::quat_rotate(q, wb_new);
+      float v_new = v + dt * fdiv(fw, mass);
+      v_new = v_new + grav * dt;
+      const float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
+      const float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
+      v_new = v_new * ml;
+      w_new = w_new * ma;
+      const float v2 = q4::dot3(v_new, v_new), w2 = q4::dot3(w_new, w_new);
+      if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
+      if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
+      p = p + v_new * dt;
+      const float wm2 = q4::dot3(w_new, w_new);
+      if (wm2 != 0.0f) {
+        const float wm = fsqrt(wm2);
+        const float half = dt * wm * 0.5f;
+        float sn, cs;
+        sincos_bounded(half, sn, cs);
+        const float sc = fdiv(sn, wm);
+        const float x1 = w_new * sc;
+        const float r3 = (x1 * q4::bc<3>(q) + q4::rot1(x1) * q4::rot2(q)) - q4::rot2(x1) * q4::rot1(q);
+        const float xq = x1 * q;
+        const float rw = (-q4::bc<0>(xq) - q4::bc<1>(xq)) - q4::bc<2>(xq);
+        float rq = l == 3 ? rw : r3;
+        rq += q * cs;
+        const float nn = fsqrt(q4::dot4(rq, rq));
+        q = fdiv(rq, nn);
+      }
+      v = v_new;
+      w = w_new;
+      if (B.boxes) {
+        if (l < 3) traj[(sub * 3 + l) * 16 + slot] = p;
+        if (sub == 0) { tlo = p; thi = p; }
+        tlo = fminf(tlo, p);
+        thi = fmaxf(thi, p);
+      }
+    }
+    if (B.body_force && l < 3 && k > 0) AGX_AT(B.body_force, l) = fb;
+    // ---- obstacles: the env's boxes over the four lanes
+    bool crashed = false;
+    if (B.boxes && k > 0) {
+      const V3 lo = V3{q4::bc<0>(tlo), q4::bc<1>(tlo), q4::bc<2>(tlo)}, hi = V3{q4::bc<0>(thi), q4::bc<1>(thi), q4::bc<2>(thi)};
+      const float rad = P.collision_radius, r2 = rad * rad;
+      bool hit = false;
+      for (int b = l; b < B.num_boxes; b += 4) {
+        const float *bx = B.boxes + (size_t)b * 11 * n + i;
+        const V3 c = V3{bx[0], bx[(size_t)n], bx[2 * (size_t)n]};
+        const float reach = bx[10 * (size_t)n] + rad + 1.0e-3f;
+        const float dx = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.0f);
+        const float dy = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.0f);
+        const float dz = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.0f);
+        if (dx * dx + dy * dy + dz * dz > reach * reach) continue;
+        const Q4 bq = Q4{bx[3 * (size_t)n], bx[4 * (size_t)n], bx[5 * (size_t)n], bx[6 * (size_t)n]};
+        const V3 bh = V3{bx[7 * (size_t)n], bx[8 * (size_t)n], bx[9 * (size_t)n]};
+        for (int sub = 0; sub < k; ++sub) {
+          const V3 ps = V3{traj[(sub * 3 + 0) * 16 + slot], traj[(sub * 3 + 1) * 16 + slot], traj[(sub * 3 + 2) * 16 + slot]};
+          hit = hit || sphere_hits_box(ps, c, bq, bh, r2);
+        }
+      }
+      crashed = ((vote(hit) >> (tid & 60)) & 0xFull) != 0ull;
+    }
+    // ---- stores
+    if (l < 3) AGX_AT(B.state, 0 + l) = p;
+    AGX_AT(B.state, 3 + l) = q;
+    if (l < 3) {
+      AGX_AT(B.state, 7 + l) = v;
+      AGX_AT(B.state, 10 + l) = w;
+    }
+    if (k > 0) {
+      if (l < 3) {
+        AGX_AT(B.derived, 0 + l) = d.euler;
+        AGX_AT(B.derived, 7 + l) = d.vveh;
+        AGX_AT(B.derived, 10 + l) = d.vbody;
+        AGX_AT(B.derived, 13 + l) = d.wbody;
+      }
+      AGX_AT(B.derived, 3 + l) = d.qveh;
+      AGX_AT(B.motor_thrust, l) = u;
+      if (B.wrench_cmd && l < 3) {
+        AGX_AT(B.wrench_cmd, l) = l == 2 ? fz : 0.0f;
+        AGX_AT(B.wrench_cmd, 3 + l) = torque;
+      }
+      // RobotManagerIGE.pre_physics_step runs every sub-step: prev <- cur, cur <- action
+      AGX_AT(B.prev_actions, l) = k >= 2 ? a_in : a_old;
+      AGX_AT(B.actions, l) = a_in;
+    }
+    // ---- EnvManager bookkeeping + task epilogue (scalar code, the same in the four lanes; lane 0 stores)
+    const float acur = k > 0 ? a_in : a_old;
+    const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : AGX_AT(B.prev_actions, l));
+    const int steps = B.sim_steps[i] + 1;
+    bool trunc = false;
+    float rew = 0.0f;
+    if (T.kind != AGX_TASK_NONE) {
+      const float tgt = AGX_AT(T.target, l3);
+      if (T.kind == AGX_TASK_POSITION) {
+        EnvState s;
+        s.p = V3{q4::bc<0>(p), q4::bc<1>(p), q4::bc<2>(p)};
+        s.q = Q4{q4::bc<0>(q), q4::bc<1>(q), q4::bc<2>(q), q4::bc<3>(q)};
+        s.v = V3{0, 0, 0};
+        s.w = V3{0, 0, 0};
+        rew = reward_position(s, Q4{q4::bc<0>(d.qveh), q4::bc<1>(d.qveh), q4::bc<2>(d.qveh), q4::bc<3>(d.qveh)},
+                              V3{q4::bc<0>(d.wbody), q4::bc<1>(d.wbody), q4::bc<2>(d.wbody)},
+                              V3{q4::bc<0>(tgt), q4::bc<1>(tgt), q4::bc<2>(tgt)}, crashed);
+      } else {
+        const float ppe = AGX_AT(T.pos_err, l3);
+        const float pe = q4::quat_rotate_inverse(d.qveh, tgt - p);
+        if (l < 3) {
+          AGX_AT(T.prev_pos_err, l) = ppe;
+          AGX_AT(T.pos_err, l) = pe;
+        }
+        rew = reward_navigation(T.rp, T.curriculum_progress, V3{q4::bc<0>(pe), q4::bc<1>(pe), q4::bc<2>(pe)},
+                                V3{q4::bc<0>(ppe), q4::bc<1>(ppe), q4::bc<2>(ppe)}, q4::bc<0>(acur), q4::bc<2>(acur), q4::bc<3>(acur),
+                                q4::bc<0>(aprev), q4::bc<2>(aprev), q4::bc<3>(aprev), crashed);
+      }
+      trunc = steps > T.episode_len;
+      reset = (crashed && T.reset_on_collision) || trunc;
+    }
+    if (l == 0) {
+      B.sim_steps[i] = steps;
+      if (T.kind != AGX_TASK_NONE) {
         T.reward[i] = rew;
         B.reset_mask[i] = reset ? 1 : 0;
       }
@@ -1443,6 +1727,19 @@ static bool quad_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, 
   return true;
 }
 
+// ... and the sub-step loop of the velocity / acceleration controlled quadrotors (navigation tasks)
+static bool quad_loop_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, int k) {
+  const char *e = getenv("AGX_ENV_STEP_QUAD");
+  if ((e && e[0] == '0') || pick_block(n) != 64 || k < 1 || P->num_motors != 4 || P->num_actions != 4 || B->launch_flags != 0)
+    return false;
+  if (P->controller != AGX_CTRL_VELOCITY && P->controller != AGX_CTRL_ACCELERATION) return false;
+  for (int c = 0; c < 3; ++c)
+    if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
+        P->ang_drag_quadratic[c] != 0.0f)
+      return false;
+  return true;
+}
+
 template <int M, int CTRL, bool WIDE>
 static void launch_env_step(int k, int n, int block, size_t lds, hipStream_t stream, const AgxRobotParams &P, const AgxEnvBuffers &B,
                             const float *actions_in, const AgxTaskArgs &T) {
@@ -1479,6 +1776,16 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
                        T);
     return check_launch("agx_env_step");
   }
+  if (quad_loop_kernel_usable(P, B, n, k)) {
+    const size_t lds4 = B->boxes ? (size_t)k * 3 * 16 * sizeof(float) : 0;
+    if (P->controller == AGX_CTRL_VELOCITY)
+      hipLaunchKernelGGL((k_env_step_quad_loop<AGX_CTRL_VELOCITY>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P,
+                         *B, n, actions_in, k, T);
+    else
+      hipLaunchKernelGGL((k_env_step_quad_loop<AGX_CTRL_ACCELERATION>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream,
+                         *P, *B, n, actions_in, k, T);
+    return check_launch("agx_env_step");
+  }
   AGX_DISPATCH_M(P->num_motors,
                  AGX_DISPATCH_CTRL(P->controller, {
                    if (block == 64)
@@ -1497,6 +1804,8 @@ extern "C" int agx_env_step_kernel(const AgxRobotParams *P, const AgxEnvBuffers 
   const int block = pick_block(n);
   if (k == 1 && block == 64 && P->num_motors == 4 && P->controller == AGX_CTRL_POSITION && quad_kernel_usable(P, B, &T))
     snprintf(out, (size_t)cap, "k_env_step_quad_position_%d", blocks_for(n, 16) * 64);
+  else if (quad_loop_kernel_usable(P, B, n, k))
+    snprintf(out, (size_t)cap, "k_env_step_quad_loop<%d>_%d", P->controller, blocks_for(n, 16) * 64);
   else
     snprintf(out, (size_t)cap, "k_env_step<%d,%d,%s,%s>_%d", P->num_motors, P->controller, k == 1 ? "true" : "false",
              block == 64 ? "true" : "false", blocks_for(n, block) * block);

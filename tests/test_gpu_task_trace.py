@@ -289,6 +289,59 @@ def test_four_lanes_per_env_kernel_is_bit_identical_to_the_one_lane_kernel(n, ra
             ctl_cfg.randomize_params = old_rand
 
 
+@pytest.mark.parametrize("which", ["navigation_task", "lidar_navigation_task"])
+def test_four_lanes_per_env_substep_loop_is_bit_identical_to_the_one_lane_kernel(which, monkeypatch):
+    """k_env_step_quad_loop<velocity | acceleration> (10 sub-steps, obstacles split over the lanes of the quad, device
+    disturbance draws, navigation reward epilogue) against k_env_step<4, CTRL, false, true>: state, derived tensors,
+    motors, rewards, flags, position errors equal bit for bit over several episodes (AGX_ENV_STEP_QUAD=0 selects the
+    one-lane kernel)."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import task_config as tc
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg = getattr(tc, which + "_config")
+    old = (cfg.device, cfg.args, cfg.episode_len_steps)
+    cfg.device, cfg.args, cfg.episode_len_steps = DEV, {"rng_seed": 77}, 25
+    try:
+        n = 150
+        one = task_registry.make_task(which, seed=31, num_envs=n, headless=True)
+        one.reset()  # (make_task seeds the host generator the first reset draws from: reset before the next make_task)
+        four = task_registry.make_task(which, seed=31, num_envs=n, headless=True)
+        four.reset()
+        import ctypes as C
+
+        for t, want in ((one, "0"), (four, "1")):
+            monkeypatch.setenv("AGX_ENV_STEP_QUAD", want)
+            env = t.sim_env
+            buf = C.create_string_buffer(128)
+            env._lib.agx_env_step_kernel(env._params, env._buffers, n, env.num_physics_steps(), env.task_args, buf, 128)
+            assert buf.value.decode().startswith("k_env_step_quad_loop<" if want == "1" else "k_env_step<4,"), buf.value
+        g = torch.Generator(device=DEV).manual_seed(2)
+        A = one.task_config.action_space_dim
+        n_crash = 0
+        for t in range(70):
+            a = torch.rand(n, A, device=DEV, generator=g) * 2 - 1
+            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "0")
+            o1 = one.step(a)
+            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "1")
+            four.step(a)
+            n_crash += int(o1[2].sum())
+            for k in ("robot_state_tensor", "robot_actions", "robot_prev_actions", "robot_euler_angles", "robot_body_linvel",
+                      "robot_body_angvel", "robot_vehicle_orientation", "robot_vehicle_linvel"):
+                assert torch.equal(one.obs_dict[k], four.obs_dict[k]), (t, k, (one.obs_dict[k] - four.obs_dict[k]).abs().max())
+            do = (one.task_obs["observations"] != four.task_obs["observations"])
+            assert not do.any(), (t, do.any(dim=0).nonzero().flatten().tolist()[:20], int(do.any(dim=1).sum()))
+            assert torch.equal(one.rewards, four.rewards), (t, (one.rewards - four.rewards).abs().max())
+            assert torch.equal(one.truncations, four.truncations) and torch.equal(one.terminations, four.terminations), t
+            m1 = one.sim_env.robot_manager.robot.control_allocator.motor_model
+            m2 = four.sim_env.robot_manager.robot.control_allocator.motor_model
+            assert torch.equal(m1.thrust_soa, m2.thrust_soa), t
+            assert torch.equal(one.pos_err_soa, four.pos_err_soa) and torch.equal(one.prev_pos_err_soa, four.prev_pos_err_soa), t
+        assert n_crash >= 1  # the obstacle test was exercised
+    finally:
+        cfg.device, cfg.args, cfg.episode_len_steps = old
+
+
 def test_config4_octarotor_lidar_task_runs():
     """BASELINE config 4 at small N: base_octarotor + octarotor_velocity_control + 32x512 LiDAR
     (range + segmentation), 10 sub-steps, disturbances on, sync-free."""
