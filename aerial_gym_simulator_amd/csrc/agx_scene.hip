@@ -141,6 +141,24 @@ AGX_DEV int delta_keys(const unsigned long long *keys, int nt, int i, int j) {
   return __clzll(keys[i] ^ keys[j]);  // keys are unique (the triangle index is in the low word)
 }
 
+// floats of the LDS region that holds the internal nodes' boxes and, before them, the bounds reduction's scratch
+AGX_DEV constexpr int bvh_box_floats_c(int nt, int threads) { return (nt - 1) * 6 > 6 * threads ? (nt - 1) * 6 : 6 * threads; }
+// box of tree node c: internal nodes from LDS, leaves (c >= n_int) from their triangle, grown by kBoxEps
+AGX_DEV void node_box(const float *box, const unsigned long long *keys, const float *__restrict__ tris, int n_int, int c, float (&o)[6]) {
+  if (c >= n_int) {
+    const int f = (int)(uint32_t)(keys[c - n_int] & 0xFFFFFFFFull);
+    const float *t = tris + (size_t)f * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      o[k] = fminf(fminf(t[k], t[3 + k]), t[6 + k]) - kBoxEps;
+      o[3 + k] = fmaxf(fmaxf(t[k], t[3 + k]), t[6 + k]) + kBoxEps;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = box[(size_t)c * 6 + k];
+  }
+}
+
 // Node record written to HBM (16 floats):
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
@@ -148,11 +166,15 @@ AGX_DEV int delta_keys(const unsigned long long *keys, int nt, int i, int j) {
 AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
-  float *box = reinterpret_cast<float *>(keys + npad);                              // [(2nt-1)][6] internal then leaves
-  int *parent = reinterpret_cast<int *>(box + (size_t)(2 * nt - 1) * 6);           // [2nt-1]
+  // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
+  // needed (twice).  That, and the reduction scratch sharing the box region (it is dead before the first box is written),
+  // takes the footprint from 115 KB to 72 KB for T = 1272: TWO workgroups per CU, i.e. 512 envs in flight instead of 256
+  // (with 300-400 dirty envs per step at 8192 envs the rebuild was two rounds: 150 -> see profiles/r02_small_batch.txt).
+  float *box = reinterpret_cast<float *>(keys + npad);                              // [nt-1][6] (>= the reduction scratch)
+  int *parent = reinterpret_cast<int *>(box + bvh_box_floats_c(nt, kBvhThreads));                  // [2nt-1]
   int *child = parent + (2 * nt - 1);                                               // [nt-1][2]
   int *counter = child + 2 * (nt - 1);                                              // [nt-1]
-  float *red = reinterpret_cast<float *>(counter + (nt - 1));                       // [6][kBvhThreads]
+  float *red = box;                                                                 // [6][kBvhThreads], first phase only
   const int tid = threadIdx.x;
   const float *tris = tri_world + (size_t)env * nt * 9;
 
@@ -314,17 +336,6 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     counter[i] = 0;
   }
   if (tid == 0) parent[0] = -1;
-  // --- leaf boxes (grown by kBoxEps)
-  for (int i = tid; i < nt; i += kBvhThreads) {
-    int f = (int)(uint32_t)(keys[i] & 0xFFFFFFFFull);
-    const float *t = tris + (size_t)f * 9;
-    float *b = box + (size_t)(n_int + i) * 6;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      b[c] = fminf(fminf(t[c], t[3 + c]), t[6 + c]) - kBoxEps;
-      b[3 + c] = fmaxf(fmaxf(t[c], t[3 + c]), t[6 + c]) + kBoxEps;
-    }
-  }
   __syncthreads();
   // --- bottom-up box propagation: the second arriver at a node merges its children
   for (int i = tid; i < nt; i += kBvhThreads) {
@@ -333,7 +344,9 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       __threadfence_block();  // release: this thread's box is written before the arrival
       if (atomicAdd(&counter[node], 1) == 0) break;
       __threadfence_block();  // acquire: the sibling's box is read after the arrival
-      const float *a = box + (size_t)child[2 * node] * 6, *b = box + (size_t)child[2 * node + 1] * 6;
+      float a[6], b[6];
+      node_box(box, keys, tris, n_int, child[2 * node], a);
+      node_box(box, keys, tris, n_int, child[2 * node + 1], b);
       float *o = box + (size_t)node * 6;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -349,11 +362,11 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   float *out = nodes + (size_t)env * (nt - 1) * 16;
   for (int i = tid; i < n_int; i += kBvhThreads) {
     int ref[2], second[2];
-    const float *bx[2];
+    float bx[2][6];
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       int c = child[2 * i + side];
-      bx[side] = box + (size_t)c * 6;
+      node_box(box, keys, tris, n_int, c, bx[side]);
       second[side] = -1;
       if (c >= n_int) {
         ref[side] = ~(int)(uint32_t)(keys[c - n_int] & 0xFFFFFFFFull);
@@ -413,8 +426,8 @@ __global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int np
 }
 
 static size_t bvh_lds_bytes(int nt, int npad) {
-  return (size_t)npad * 8 + (size_t)(2 * nt - 1) * 24 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 +
-         (size_t)6 * kBvhThreads * 4 + 64;
+  const size_t box_floats = (size_t)(nt - 1) * 6 > (size_t)6 * kBvhThreads ? (size_t)(nt - 1) * 6 : (size_t)6 * kBvhThreads;
+  return (size_t)npad * 8 + box_floats * 4 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 + 64;
 }
 
 }  // namespace agx
@@ -488,7 +501,7 @@ extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *t
   }
   AGX_REQUIRE(lds <= 160 * 1024 - 256, "LBVH build needs %zu bytes of LDS (> 160 KiB)", lds);
   if (mask) hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
-  const int grid = n < 512 ? n : 512;  // one resident workgroup per CU (LDS bound) x 2 to cover the tail
+  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
   hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object,
                      tri_world, mask ? work : nullptr, nodes);
   return check_launch("agx_bvh_build");
