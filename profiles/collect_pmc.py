@@ -23,9 +23,8 @@ def load(path, counter):
         elif "k_env_step" in name:
             import re
 
-            m = re.search(r"k_env_step<([^>]*)>", name)  # <motors, controller id, single sub-step, one-wave workgroups>
-            key = ("k_env_step<%s>" % m.group(1).replace(" ", "") if m
-                   else ("k_env_step_quad_position" if "k_env_step_quad_position" in name else "k_env_step"), int(r["Grid_Size"]))
+            m = re.search(r"(k_env_step\w*)(<[^>]*>)?", name)  # k_env_step<motors, ctrl, single, wide> | k_env_step_quad_*
+            key = (m.group(1) + (m.group(2) or "").replace(" ", ""), int(r["Grid_Size"]))
         elif "k_raycast" in name:
             import re
 
