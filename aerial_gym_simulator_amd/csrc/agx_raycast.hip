@@ -270,6 +270,10 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
       ml = 0;
     }
     if (cr < 0) {
+      if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
+        hr = hr && (tr <= r.best) && r.active;
+        mr = vote(hr);
+      }
       if (mr) {
         test_leaf<ANY>(r, tris, ~cr, hr, upid);
         if (cr2 >= 0) test_leaf<ANY>(r, tris, cr2, hr, upid);
