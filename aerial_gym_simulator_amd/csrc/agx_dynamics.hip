@@ -661,6 +661,119 @@ AGX_DEV QuadDerived update_states_quad(float q, float v, float w) {
   return d;
 }
 
+// Per-lane constants of the quad kernels: component l of a vector, row l of a matrix, motor l (indexed kernel-argument loads)
+struct QuadConsts {
+  float grav, in0, in1, in2, ii0, ii1, ii2, pinv[6], mapf[4], mapt[4], mass, dt;
+};
+AGX_DEV QuadConsts load_quad_consts(const AgxRobotParams &P, int l, int l3) {
+  QuadConsts C;
+  C.grav = P.gravity[l3];
+  C.in0 = P.inertia[3 * l3 + 0]; C.in1 = P.inertia[3 * l3 + 1]; C.in2 = P.inertia[3 * l3 + 2];
+  C.ii0 = P.inertia_inv[3 * l3 + 0]; C.ii1 = P.inertia_inv[3 * l3 + 1]; C.ii2 = P.inertia_inv[3 * l3 + 2];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) C.pinv[c] = P.alloc_pinv[6 * l + c];  // motor l
+  const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    C.mapf[j] = wmap[4 * l3 + j];        // force row l
+    C.mapt[j] = wmap[4 * (3 + l3) + j];  // torque row l
+  }
+  C.mass = P.mass;
+  C.dt = P.dt;
+  return C;
+}
+// f . third column of quat_to_rotmat(q) = (2 (xz + yw), 2 (yz - xw), 1 - 2 (xx + yy)): the thrust command of the Lee laws
+AGX_DEV float quad_thrust_along_body_z(float q, float f, int l) {
+  const float t1 = q * q4::bc<2>(q), t2 = q4::perm<1, 0, 2, 3>(q) * q4::bc<3>(q);
+  const float c2a = 2.0f * (l == 1 ? t1 - t2 : t1 + t2);
+  const float sqq = q * q;
+  const float m22 = 1.0f - 2.0f * (q4::bc<0>(sqq) + q4::bc<1>(sqq));
+  return q4::dot3(f, l == 2 ? m22 : c2a);
+}
+// base_lee_controller.py:173-194 (desired_orientation_pos_vel)
+AGX_DEV float quad_desired_orientation_pos_vel(float f, float yaw, int l) {
+  const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
+  float sy, cy;
+  sincos_bounded(yaw, sy, cy);
+  const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
+  const float cb = q4::cross3(b3, tmp);
+  const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
+  const float b1 = q4::cross3(b2, b3);
+  return q4::rotmat_cols_to_quat(b1, b2, b3);
+}
+// base_lee_controller.py:136-154 (compute_body_torque); ZERO_RATE: the angular-velocity set-point is the constant 0
+template <bool ZERO_RATE>
+AGX_DEV float quad_body_torque(const QuadConsts &C, float q, float qd, float wb, float wsp, float kr, float kw, int l) {
+  const float qe = q4::quat_mul(q4::conj(q), qd);
+  const float pp = q4::rot1(qe) * q4::rot2(qe);  // (yz, zx, xy)
+  const float pw = qe * q4::bc<3>(qe);           // (xw, yw, zw)
+  const float mp = 2.0f * (pp + pw);             // (m21, m02, m10)
+  const float mm = 2.0f * (pp - pw);             // (m12, m20, m01)
+  const float rot_err = 0.5f * (l == 1 ? mm - mp : -(mp - mm));
+  const float jw = (C.in0 * q4::bc<0>(wb) + C.in1 * q4::bc<1>(wb)) + C.in2 * q4::bc<2>(wb);
+  const float ff = q4::cross3(wb, jw);
+  const float we = ZERO_RATE ? wb : wb - q4::quat_rotate(qe, wsp);
+  return ((-kr) * rot_err - kw * we) + ff;
+}
+// allocation (lane l = motor l) + motor model + body wrench (lane l = row l of the force / of the torque)
+AGX_DEV void quad_allocate(const AgxRobotParams &P, const QuadConsts &C, float fz, float torque, float &u, float kT, float tinc,
+                           float tdec, float &fb, float &tb) {
+  float r = 0.0f;
+  r += C.pinv[0] * 0.0f;
+  r += C.pinv[1] * 0.0f;
+  r += C.pinv[2] * fz;
+  r += C.pinv[3] * q4::bc<0>(torque);
+  r += C.pinv[4] * q4::bc<1>(torque);
+  r += C.pinv[5] * q4::bc<2>(torque);
+  u = motor_update(P, r, u, kT, tinc, tdec);
+  fb = 0.0f;
+  tb = 0.0f;
+  const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
+  fb += C.mapf[0] * u0; fb += C.mapf[1] * u1; fb += C.mapf[2] * u2; fb += C.mapf[3] * u3;
+  tb += C.mapt[0] * u0; tb += C.mapt[1] * u1; tb += C.mapt[2] * u2; tb += C.mapt[3] * u3;
+}
+// the rigid-body update (integrate(), DESIGN.md "integrator") on the quad
+AGX_DEV void quad_integrate(const AgxRobotParams &P, const QuadConsts &C, float &p, float &q, float &v, float &w, float fb, float tb,
+                            int l) {
+  const float dt = C.dt;
+  const float fw = q4::quat_rotate(q, fb);
+  const float wbi = q4::quat_rotate_inverse(q, w);
+  const float jwi = (C.in0 * q4::bc<0>(wbi) + C.in1 * q4::bc<1>(wbi)) + C.in2 * q4::bc<2>(wbi);
+  const float rhs = tb - q4::cross3(wbi, jwi);
+  const float dwb = (C.ii0 * q4::bc<0>(rhs) + C.ii1 * q4::bc<1>(rhs)) + C.ii2 * q4::bc<2>(rhs);
+  const float wb_new = wbi + dt * dwb;
+  float w_new = q4::quat_rotate(q, wb_new);
+  float v_new = v + dt * fdiv(fw, C.mass);
+  v_new = v_new + C.grav * dt;
+  const float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
+  const float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
+  v_new = v_new * ml;
+  w_new = w_new * ma;
+  const float v2 = q4::dot3(v_new, v_new), w2 = q4::dot3(w_new, w_new);
+  if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
+  if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
+  p = p + v_new * dt;
+  const float wm2 = q4::dot3(w_new, w_new);
+  if (wm2 != 0.0f) {
+    const float wm = fsqrt(wm2);
+    const float half = dt * wm * 0.5f;
+    float sn, cs;
+    sincos_bounded(half, sn, cs);
+    const float sc = fdiv(sn, wm);
+    const float x1 = w_new * sc;  // (x1, y1, z1)
+    // (x1 w + y1 z - z1 y, y1 w + z1 x - x1 z, z1 w + x1 y - y1 x, -(x1 x) - y1 y - z1 z)
+    const float r3 = (x1 * q4::bc<3>(q) + q4::rot1(x1) * q4::rot2(q)) - q4::rot2(x1) * q4::rot1(q);
+    const float xq = x1 * q;
+    const float rw = (-q4::bc<0>(xq) - q4::bc<1>(xq)) - q4::bc<2>(xq);
+    float rq = l == 3 ? rw : r3;
+    rq += q * cs;
+    const float nn = fsqrt(q4::dot4(rq, rq));
+    q = fdiv(rq, nn);
+  }
+  v = v_new;
+  w = w_new;
+}
+
 __global__ void __launch_bounds__(64, 1)
     k_env_step_quad_position(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, AgxTaskArgs T) {
   const int tid = threadIdx.x;
@@ -680,20 +793,7 @@ __global__ void __launch_bounds__(64, 1)
     const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
     const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
-    // per-lane constants: component l of a vector, row l of a matrix (indexed kernel-argument loads)
-    const float grav = P.gravity[l3];
-    const float in0 = P.inertia[3 * l3 + 0], in1 = P.inertia[3 * l3 + 1], in2 = P.inertia[3 * l3 + 2];
-    const float ii0 = P.inertia_inv[3 * l3 + 0], ii1 = P.inertia_inv[3 * l3 + 1], ii2 = P.inertia_inv[3 * l3 + 2];
-    float pinv[6], mapf[4], mapt[4];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) pinv[c] = P.alloc_pinv[6 * l + c];  // motor l
-    const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mapf[j] = wmap[4 * l3 + j];        // force row l
-      mapt[j] = wmap[4 * (3 + l3) + j];  // torque row l
-    }
-    const float mass = P.mass, dt = P.dt;
+    const QuadConsts C = load_quad_consts(P, l, l3);
 
     // ---- update_states + controller (position_control.py:20-51)
     const QuadDerived d = update_states_quad(q, v, w);
@@ -702,87 +802,16 @@ __global__ void __launch_bounds__(64, 1)
     const float pe = a - p;
     const float ve = 0.0f - v;
     const float acc = kp * pe + kv * ve;
-    const float f = (acc - grav) * mass;
-    // third column of quat_to_rotmat(q): (2 (xz + yw), 2 (yz - xw), 1 - 2 (xx + yy))
-    const float t1 = q * q4::bc<2>(q), t2 = q4::perm<1, 0, 2, 3>(q) * q4::bc<3>(q);
-    const float c2a = 2.0f * (l == 1 ? t1 - t2 : t1 + t2);
-    const float sqq = q * q;
-    const float m22 = 1.0f - 2.0f * (q4::bc<0>(sqq) + q4::bc<1>(sqq));
-    const float fz = q4::dot3(f, l == 2 ? m22 : c2a);
-    // desired_orientation_pos_vel(f, yaw set-point)
-    const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
-    float sy, cy;
-    sincos_bounded(q4::bc<3>(a), sy, cy);
-    const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
-    const float cb = q4::cross3(b3, tmp);
-    const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
-    const float b1 = q4::cross3(b2, b3);
-    const float qd = q4::rotmat_cols_to_quat(b1, b2, b3);
-    // compute_body_torque (rate set-point 0)
-    const float qe = q4::quat_mul(q4::conj(q), qd);
-    const float pp = q4::rot1(qe) * q4::rot2(qe);  // (yz, zx, xy)
-    const float pw = qe * q4::bc<3>(qe);           // (xw, yw, zw)
-    const float mp = 2.0f * (pp + pw);             // (m21, m02, m10)
-    const float mm = 2.0f * (pp - pw);             // (m12, m20, m01)
-    const float rot_err = 0.5f * (l == 1 ? mm - mp : -(mp - mm));
-    const float wb = d.wbody;
-    const float jw = (in0 * q4::bc<0>(wb) + in1 * q4::bc<1>(wb)) + in2 * q4::bc<2>(wb);
-    const float ff = q4::cross3(wb, jw);
-    const float torque = ((-kr) * rot_err - kw * wb) + ff;
+    const float f = (acc - C.grav) * C.mass;
+    const float fz = quad_thrust_along_body_z(q, f, l);
+    const float qd = quad_desired_orientation_pos_vel(f, q4::bc<3>(a), l);
+    const float torque = quad_body_torque<true>(C, q, qd, d.wbody, 0.0f, kr, kw, l);
 
-    // ---- allocation + motor model: lane l = motor l
-    float r = 0.0f;
-    r += pinv[0] * 0.0f;
-    r += pinv[1] * 0.0f;
-    r += pinv[2] * fz;
-    r += pinv[3] * q4::bc<0>(torque);
-    r += pinv[4] * q4::bc<1>(torque);
-    r += pinv[5] * q4::bc<2>(torque);
-    u = motor_update(P, r, u, kT, tinc, tdec);
-    // body wrench: lane l = row l
-    float fb = 0.0f, tb = 0.0f;
-    const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
-    fb += mapf[0] * u0; fb += mapf[1] * u1; fb += mapf[2] * u2; fb += mapf[3] * u3;
-    tb += mapt[0] * u0; tb += mapt[1] * u1; tb += mapt[2] * u2; tb += mapt[3] * u3;
+    // ---- allocation + motor model + body wrench, rigid-body update
+    float fb, tb;
+    quad_allocate(P, C, fz, torque, u, kT, tinc, tdec, fb, tb);
     if (B.body_force && l < 3) AGX_AT(B.body_force, l) = fb;
-
-    // ---- integrate (the rigid-body update)
-    const float fw = q4::quat_rotate(q, fb);
-    const float wbi = q4::quat_rotate_inverse(q, w);
-    const float jwi = (in0 * q4::bc<0>(wbi) + in1 * q4::bc<1>(wbi)) + in2 * q4::bc<2>(wbi);
-    const float rhs = tb - q4::cross3(wbi, jwi);
-    const float dwb = (ii0 * q4::bc<0>(rhs) + ii1 * q4::bc<1>(rhs)) + ii2 * q4::bc<2>(rhs);
-    const float wb_new = wbi + dt * dwb;
-    float w_new = q4::quat_rotate(q, wb_new);
-    float v_new = v + dt * fdiv(fw, mass);
-    v_new = v_new + grav * dt;
-    const float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
-    const float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
-    v_new = v_new * ml;
-    w_new = w_new * ma;
-    const float v2 = q4::dot3(v_new, v_new), w2 = q4::dot3(w_new, w_new);
-    if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
-    if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
-    p = p + v_new * dt;
-    const float wm2 = q4::dot3(w_new, w_new);
-    if (wm2 != 0.0f) {
-      const float wm = fsqrt(wm2);
-      const float half = dt * wm * 0.5f;
-      float sn, cs;
-      sincos_bounded(half, sn, cs);
-      const float sc = fdiv(sn, wm);
-      const float x1 = w_new * sc;  // (x1, y1, z1)
-      // (x1 w + y1 z - z1 y, y1 w + z1 x - x1 z, z1 w + x1 y - y1 x, -(x1 x) - y1 y - z1 z)
-      const float r3 = (x1 * q4::bc<3>(q) + q4::rot1(x1) * q4::rot2(q)) - q4::rot2(x1) * q4::rot1(q);
-      const float xq = x1 * q;
-      const float rw = (-q4::bc<0>(xq) - q4::bc<1>(xq)) - q4::bc<2>(xq);
-      float rq = l == 3 ? rw : r3;
-      rq += q * cs;
-      const float nn = fsqrt(q4::dot4(rq, rq));
-      q = fdiv(rq, nn);
-    }
-    v = v_new;
-    w = w_new;
+    quad_integrate(P, C, p, q, v, w, fb, tb, l);
 
     // ---- stores: state, derived, motors, controller output, actions
     if (l < 3) AGX_AT(B.state, 0 + l) = p;
@@ -899,20 +928,8 @@ __global__ void __launch_bounds__(64, 1)
     const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
     const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
-    const float grav = P.gravity[l3];
-    const float in0 = P.inertia[3 * l3 + 0], in1 = P.inertia[3 * l3 + 1], in2 = P.inertia[3 * l3 + 2];
-    const float ii0 = P.inertia_inv[3 * l3 + 0], ii1 = P.inertia_inv[3 * l3 + 1], ii2 = P.inertia_inv[3 * l3 + 2];
-    float pinv[6], mapf[4], mapt[4];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) pinv[c] = P.alloc_pinv[6 * l + c];
-    const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      mapf[j] = wmap[4 * l3 + j];
-      mapt[j] = wmap[4 * (3 + l3) + j];
-    }
+    const QuadConsts C = load_quad_consts(P, l, l3);
     const float dmax = B.disturb_max[l3], dmax_t = B.disturb_max[3 + l3];
-    const float mass = P.mass, dt = P.dt;
     const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions (the same every sub-step)
     QuadDerived d{};
     float fz = 0.0f, torque = 0.0f, fb = 0.0f;
@@ -921,68 +938,31 @@ __global__ void __launch_bounds__(64, 1)
       d = update_states_quad(q, v, w);
       // ---- controller
       float f, qd;
+      const float yaw = q4::bc<2>(d.euler);
       if (CTRL == AGX_CTRL_VELOCITY) {  // velocity_control.py:18-51
         const float sp_vel_w = q4::quat_rotate(d.qveh, a);  // (a0, a1, a2) in the vehicle frame
         const float pe = p - p;                             // position set-point = current position
         const float ve = sp_vel_w - v;
         const float acc = kp * pe + kv * ve;
-        f = (acc - grav) * mass;
+        f = (acc - C.grav) * C.mass;
+        qd = quad_desired_orientation_pos_vel(f, yaw, l);
       } else {  // acceleration_control.py:16-45
-        f = (a - grav) * mass;
-      }
-      {
-        const float t1 = q * q4::bc<2>(q), t2 = q4::perm<1, 0, 2, 3>(q) * q4::bc<3>(q);
-        const float c2a = 2.0f * (l == 1 ? t1 - t2 : t1 + t2);
-        const float sqq = q * q;
-        const float m22 = 1.0f - 2.0f * (q4::bc<0>(sqq) + q4::bc<1>(sqq));
-        fz = q4::dot3(f, l == 2 ? m22 : c2a);
-      }
-      const float yaw = q4::bc<2>(d.euler);
-      if (CTRL == AGX_CTRL_VELOCITY) {  // desired_orientation_pos_vel(f, yaw)
-        const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
-        float sy, cy;
-        sincos_bounded(yaw, sy, cy);
-        const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
-        const float cb = q4::cross3(b3, tmp);
-        const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
-        const float b1 = q4::cross3(b2, b3);
-        qd = q4::rotmat_cols_to_quat(b1, b2, b3);
-      } else {  // desired_orientation_forces_yaw(f, yaw): pitch = atan2(f.x, f.z), roll = atan2(-f.y, sqrt(f.z^2 + f.x^2))
+        f = (a - C.grav) * C.mass;
+        // desired_orientation_forces_yaw(f, yaw): pitch = atan2(f.x, f.z), roll = atan2(-f.y, sqrt(f.z^2 + f.x^2))
         const float fx = q4::bc<0>(f), fy = q4::bc<1>(f), fzc = q4::bc<2>(f);
         const float num = q4::by_lane(l, -fy, fx, 0.0f);
         const float den = q4::by_lane(l, sqrtf(fzc * fzc + fx * fx), fzc, 1.0f);
         const float ang = atan2_cw(num, den);
         qd = quat_from_euler_quad(l == 2 ? yaw : ang);
       }
-      // ---- compute_body_torque with the rate set-point euler_rates_to_body_rates(euler, (0, 0, a3))
+      fz = quad_thrust_along_body_z(q, f, l);
+      // compute_body_torque with the rate set-point euler_rates_to_body_rates(euler, (0, 0, a3))
       float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
       if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
-      const float qe = q4::quat_mul(q4::conj(q), qd);
-      const float pp = q4::rot1(qe) * q4::rot2(qe);
-      const float pw = qe * q4::bc<3>(qe);
-      const float mp = 2.0f * (pp + pw);
-      const float mm = 2.0f * (pp - pw);
-      const float rot_err = 0.5f * (l == 1 ? mm - mp : -(mp - mm));
-      const float wsp_b = q4::quat_rotate(qe, wsp);
-      const float wb = d.wbody;
-      const float jw = (in0 * q4::bc<0>(wb) + in1 * q4::bc<1>(wb)) + in2 * q4::bc<2>(wb);
-      const float ff = q4::cross3(wb, jw);
-      const float we = wb - wsp_b;
-      torque = ((-kr) * rot_err - kw * we) + ff;
+      torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
       // ---- allocation + motor model + body wrench
-      float r = 0.0f;
-      r += pinv[0] * 0.0f;
-      r += pinv[1] * 0.0f;
-      r += pinv[2] * fz;
-      r += pinv[3] * q4::bc<0>(torque);
-      r += pinv[4] * q4::bc<1>(torque);
-      r += pinv[5] * q4::bc<2>(torque);
-      u = motor_update(P, r, u, kT, tinc, tdec);
-      float tb = 0.0f;
-      fb = 0.0f;
-      const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
-      fb += mapf[0] * u0; fb += mapf[1] * u1; fb += mapf[2] * u2; fb += mapf[3] * u3;
-      tb += mapt[0] * u0; tb += mapt[1] * u1; tb += mapt[2] * u2; tb += mapt[3] * u3;
+      float tb;
+      quad_allocate(P, C, fz, torque, u, kT, tinc, tdec, fb, tb);
       if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234), draws supplied by the host
         const float *dd = B.disturb + (size_t)sub * 7 * n + i;
         const float occ = dd[0];
@@ -995,42 +975,7 @@ __global__ void __launch_bounds__(64, 1)
         fb += ((dmax - (-dmax)) * q4::by_lane(l3, ud[1], ud[2], ud[3]) + (-dmax)) * occ;
         tb += ((dmax_t - (-dmax_t)) * q4::by_lane(l3, ud[4], ud[5], ud[6]) + (-dmax_t)) * occ;
       }
-      // ---- integrate
-      const float fw = q4::quat_rotate(q, fb);
-      const float wbi = q4::quat_rotate_inverse(q, w);
-      const float jwi = (in0 * q4::bc<0>(wbi) + in1 * q4::bc<1>(wbi)) + in2 * q4::bc<2>(wbi);
-      const float rhs = tb - q4::cross3(wbi, jwi);
-      const float dwb = (ii0 * q4::bc<0>(rhs) + ii1 * q4::bc<1>(rhs)) + ii2 * q4::bc<2>(rhs);
-      const float wb_new = wbi + dt * dwb;
-      float w_new = q4::quat_rotate(q, wb_new);
-      float v_new = v + dt * fdiv(fw, mass);
-      v_new = v_new + grav * dt;
-      const float ml = fmaxf(1.0f - P.linear_damping * dt, 0.0f);
-      const float ma = fmaxf(1.0f - P.angular_damping * dt, 0.0f);
-      v_new = v_new * ml;
-      w_new = w_new * ma;
-      const float v2 = q4::dot3(v_new, v_new), w2 = q4::dot3(w_new, w_new);
-      if (v2 > P.max_linear_velocity * P.max_linear_velocity) v_new = v_new * fdiv(P.max_linear_velocity, fsqrt(v2));
-      if (w2 > P.max_angular_velocity * P.max_angular_velocity) w_new = w_new * fdiv(P.max_angular_velocity, fsqrt(w2));
-      p = p + v_new * dt;
-      const float wm2 = q4::dot3(w_new, w_new);
-      if (wm2 != 0.0f) {
-        const float wm = fsqrt(wm2);
-        const float half = dt * wm * 0.5f;
-        float sn, cs;
-        sincos_bounded(half, sn, cs);
-        const float sc = fdiv(sn, wm);
-        const float x1 = w_new * sc;
-        const float r3 = (x1 * q4::bc<3>(q) + q4::rot1(x1) * q4::rot2(q)) - q4::rot2(x1) * q4::rot1(q);
-        const float xq = x1 * q;
-        const float rw = (-q4::bc<0>(xq) - q4::bc<1>(xq)) - q4::bc<2>(xq);
-        float rq = l == 3 ? rw : r3;
-        rq += q * cs;
-        const float nn = fsqrt(q4::dot4(rq, rq));
-        q = fdiv(rq, nn);
-      }
-      v = v_new;
-      w = w_new;
+      quad_integrate(P, C, p, q, v, w, fb, tb, l);
       if (B.boxes) {
         if (l < 3) traj[(sub * 3 + l) * 16 + slot] = p;
         if (sub == 0) { tlo = p; thi = p; }
