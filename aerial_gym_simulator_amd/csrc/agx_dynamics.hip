@@ -877,9 +877,9 @@ __global__ void __launch_bounds__(64, 1)
 }
 
 // ---------------------------------------------------------------------------------------
-// Four lanes per env for the sub-step LOOP of the navigation tasks (BASELINE configs 2 / 4 and the LiDAR navigation
-// task): quadrotor, Lee velocity or acceleration control, k sub-steps, obstacles, device disturbance draws, navigation
-// reward epilogue.  Same contract as k_env_step_quad_position: per component the IEEE operations of
+// Four lanes per env for the sub-step LOOP (BASELINE configs 2 / 4, the LiDAR navigation task, the reference's default
+// attitude-controlled position task): quadrotor, any of the six Lee laws, k sub-steps, obstacles, device disturbance
+// draws, task epilogue.  Same contract as k_env_step_quad_position: per component the IEEE operations of
 // k_env_step<4, CTRL, false, .> in the same order.  The obstacle test splits the env's boxes over the four lanes (the flag
 // is a boolean OR: any order).
 // ---------------------------------------------------------------------------------------
@@ -907,10 +907,61 @@ AGX_DEV float quat_from_euler_quad(float ang) {
   return (l == 0 || l == 2) ? t1 - t2 : t1 + t2;
 }
 
+// One env's control law on its lane quad (control/controllers/*.py; run_controller<CTRL> above is the one-lane form):
+// thrust along body z and body torque from the clipped action `a` (a0..a3 in lanes 0..3).
+template <int CTRL>
+AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts &C, float p, float q, float v, const QuadDerived &d, float a,
+                             float kp, float kv, float kr, float kw, int l, float &fz, float &torque) {
+  const float yaw = q4::bc<2>(d.euler);
+  if (CTRL == AGX_CTRL_POSITION || CTRL == AGX_CTRL_VELOCITY || CTRL == AGX_CTRL_VEL_STEERING) {
+    float acc;
+    if (CTRL == AGX_CTRL_POSITION) {  // position_control.py:20-51: kp (sp - p) + kv (0 - v)
+      acc = kp * (a - p) + kv * (0.0f - v);
+    } else {  // velocity_control.py:18-51, velocity_steeing_angle_controller.py:15-45: set-point = the current position
+      const float sp_vel_w = q4::quat_rotate(d.qveh, a);  // (a0, a1, a2) in the vehicle frame
+      acc = kp * (p - p) + kv * (sp_vel_w - v);
+    }
+    const float f = (acc - C.grav) * C.mass;
+    fz = quad_thrust_along_body_z(q, f, l);
+    const float qd = quad_desired_orientation_pos_vel(f, CTRL == AGX_CTRL_VELOCITY ? yaw : q4::bc<3>(a), l);
+    if (CTRL == AGX_CTRL_POSITION) {
+      torque = quad_body_torque<true>(C, q, qd, d.wbody, 0.0f, kr, kw, l);
+    } else {
+      float wsp = euler_rates_to_body_rates_quad(d.euler, CTRL == AGX_CTRL_VELOCITY ? q4::bc<3>(a) : 0.0f);
+      if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
+      torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
+    }
+  } else if (CTRL == AGX_CTRL_ACCELERATION) {  // acceleration_control.py:16-45
+    const float f = (a - C.grav) * C.mass;
+    fz = quad_thrust_along_body_z(q, f, l);
+    // desired_orientation_forces_yaw(f, yaw): pitch = atan2(f.x, f.z), roll = atan2(-f.y, sqrt(f.z^2 + f.x^2))
+    const float fx = q4::bc<0>(f), fy = q4::bc<1>(f), fzc = q4::bc<2>(f);
+    const float num = q4::by_lane(l, -fy, fx, 0.0f);
+    const float den = q4::by_lane(l, sqrtf(fzc * fzc + fx * fx), fzc, 1.0f);
+    const float ang = atan2_cw(num, den);
+    const float qd = quat_from_euler_quad(l == 2 ? yaw : ang);
+    float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
+    if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
+    torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
+  } else if (CTRL == AGX_CTRL_ATTITUDE) {  // attitude_control.py:16-43
+    const float g0 = P.gravity[0], g1 = P.gravity[1], g2 = P.gravity[2];
+    fz = (q4::bc<0>(a) + 1.0f) * C.mass * sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
+    if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
+    const float qd = quat_from_euler_quad(q4::by_lane(l, q4::bc<1>(a), q4::bc<2>(a), yaw));
+    torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
+  } else {  // AGX_CTRL_RATES: rates_control.py:16-30 (line 25's broadcast bug -> z component)
+    fz = (q4::bc<0>(a) - P.gravity[2]) * C.mass;
+    float wsp = q4::perm<1, 2, 3, 3>(a);  // (a1, a2, a3)
+    if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
+    torque = quad_body_torque<false>(C, q, q, d.wbody, wsp, kr, kw, l);
+  }
+}
+
 template <int CTRL>
 __global__ void __launch_bounds__(64, 1)
     k_env_step_quad_loop(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k, AgxTaskArgs T) {
-  static_assert(CTRL == AGX_CTRL_VELOCITY || CTRL == AGX_CTRL_ACCELERATION, "control laws built in quad form");
+  static_assert(CTRL >= AGX_CTRL_POSITION && CTRL <= AGX_CTRL_VEL_STEERING, "the six Lee laws of the quadrotor");
   extern __shared__ float traj[];  // [k][3][16] sub-step positions of the wave's 16 envs (only with obstacles)
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2, slot = tid >> 2;
@@ -936,30 +987,7 @@ __global__ void __launch_bounds__(64, 1)
     float tlo = p, thi = p;
     for (int sub = 0; sub < k; ++sub) {
       d = update_states_quad(q, v, w);
-      // ---- controller
-      float f, qd;
-      const float yaw = q4::bc<2>(d.euler);
-      if (CTRL == AGX_CTRL_VELOCITY) {  // velocity_control.py:18-51
-        const float sp_vel_w = q4::quat_rotate(d.qveh, a);  // (a0, a1, a2) in the vehicle frame
-        const float pe = p - p;                             // position set-point = current position
-        const float ve = sp_vel_w - v;
-        const float acc = kp * pe + kv * ve;
-        f = (acc - C.grav) * C.mass;
-        qd = quad_desired_orientation_pos_vel(f, yaw, l);
-      } else {  // acceleration_control.py:16-45
-        f = (a - C.grav) * C.mass;
-        // desired_orientation_forces_yaw(f, yaw): pitch = atan2(f.x, f.z), roll = atan2(-f.y, sqrt(f.z^2 + f.x^2))
-        const float fx = q4::bc<0>(f), fy = q4::bc<1>(f), fzc = q4::bc<2>(f);
-        const float num = q4::by_lane(l, -fy, fx, 0.0f);
-        const float den = q4::by_lane(l, sqrtf(fzc * fzc + fx * fx), fzc, 1.0f);
-        const float ang = atan2_cw(num, den);
-        qd = quat_from_euler_quad(l == 2 ? yaw : ang);
-      }
-      fz = quad_thrust_along_body_z(q, f, l);
-      // compute_body_torque with the rate set-point euler_rates_to_body_rates(euler, (0, 0, a3))
-      float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
-      if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
-      torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
+      quad_controller<CTRL>(P, C, p, q, v, d, a, kp, kv, kr, kw, l, fz, torque);
       // ---- allocation + motor model + body wrench
       float tb;
       quad_allocate(P, C, fz, torque, u, kT, tinc, tdec, fb, tb);
@@ -1677,7 +1705,7 @@ static bool quad_loop_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers
   const char *e = getenv("AGX_ENV_STEP_QUAD");
   if ((e && e[0] == '0') || pick_block(n) != 64 || k < 1 || P->num_motors != 4 || P->num_actions != 4 || B->launch_flags != 0)
     return false;
-  if (P->controller != AGX_CTRL_VELOCITY && P->controller != AGX_CTRL_ACCELERATION) return false;
+  if (P->controller < AGX_CTRL_POSITION || P->controller > AGX_CTRL_VEL_STEERING) return false;
   for (int c = 0; c < 3; ++c)
     if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
         P->ang_drag_quadratic[c] != 0.0f)
@@ -1723,12 +1751,21 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   }
   if (quad_loop_kernel_usable(P, B, n, k)) {
     const size_t lds4 = B->boxes ? (size_t)k * 3 * 16 * sizeof(float) : 0;
-    if (P->controller == AGX_CTRL_VELOCITY)
-      hipLaunchKernelGGL((k_env_step_quad_loop<AGX_CTRL_VELOCITY>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P,
-                         *B, n, actions_in, k, T);
-    else
-      hipLaunchKernelGGL((k_env_step_quad_loop<AGX_CTRL_ACCELERATION>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream,
-                         *P, *B, n, actions_in, k, T);
+    switch (P->controller) {
+#define AGX_QUAD_LOOP(C_)                                                                                                        \
+  case C_:                                                                                                                       \
+    hipLaunchKernelGGL((k_env_step_quad_loop<C_>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P, *B, n,     \
+                       actions_in, k, T);                                                                                        \
+    break;
+      AGX_QUAD_LOOP(AGX_CTRL_POSITION)
+      AGX_QUAD_LOOP(AGX_CTRL_VELOCITY)
+      AGX_QUAD_LOOP(AGX_CTRL_ATTITUDE)
+      AGX_QUAD_LOOP(AGX_CTRL_RATES)
+      AGX_QUAD_LOOP(AGX_CTRL_ACCELERATION)
+      AGX_QUAD_LOOP(AGX_CTRL_VEL_STEERING)
+#undef AGX_QUAD_LOOP
+      default: break;
+    }
     return check_launch("agx_env_step");
   }
   AGX_DISPATCH_M(P->num_motors,

@@ -387,3 +387,41 @@ def test_device_disturbance_stream(orc):
     H2.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
     H2.substeps(g["action"][0], K)
     assert rel_err(H2.get("state"), st) > 1e-4
+
+
+@pytest.mark.parametrize("case", ["quad_position", "quad_velocity", "quad_attitude", "quad_rates", "quad_acceleration",
+                                  "quad_velocity_steering"])
+@pytest.mark.parametrize("k", [1, 4])
+def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch):
+    """Every Lee law of the quadrotor has a four-lanes-per-env kernel (k_env_step_quad_position for one position-control
+    sub-step, k_env_step_quad_loop<CTRL> otherwise): agx_env_step_kernel names it, and k sub-steps from the golden case's
+    recorded states / actions / gains give bit for bit the buffers of the one-lane kernel (AGX_ENV_STEP_QUAD=0)."""
+    import ctypes as C
+
+    from gpu_harness import DynHarness
+
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    n = g["state"].shape[1]
+    outs = {}
+    for quad in ("0", "1"):
+        monkeypatch.setenv("AGX_ENV_STEP_QUAD", quad)
+        H = DynHarness(pd, n)
+        H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"])
+        H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])
+        buf = C.create_string_buffer(128)
+        H.lib.agx_env_step_kernel(H.P, H.B, n, k, None, buf, 128)
+        name = buf.value.decode()
+        if quad == "1":
+            assert name.startswith("k_env_step_quad_position" if (case == "quad_position" and k == 1) else "k_env_step_quad_loop<"), name
+        else:
+            assert name.startswith("k_env_step<4,"), name
+        got = []
+        for s in range(g["state"].shape[0]):
+            H.set(state=g["state"][s], thrust=g["thrust_in"][s])
+            H.substeps(g["action"][s], k)
+            got.append([H.get(x).copy() for x in ("state", "thrust", "derived", "wrench")])
+        outs[quad] = got
+    for s, (a, b) in enumerate(zip(outs["0"], outs["1"])):
+        for name, x, y in zip(("state", "thrust", "derived", "wrench"), a, b):
+            assert np.array_equal(x, y), (case, k, s, name, np.abs(x - y).max())
