@@ -661,22 +661,27 @@ AGX_DEV QuadDerived update_states_quad(float q, float v, float w) {
   return d;
 }
 
-// Per-lane constants of the quad kernels: component l of a vector, row l of a matrix, motor l (indexed kernel-argument loads)
+// Per-lane constants of the quad kernels: component l of a vector, row l of a matrix, motors l (and l + 4 of an 8-motor robot)
+// (indexed kernel-argument loads)
+template <int M>
 struct QuadConsts {
-  float grav, in0, in1, in2, ii0, ii1, ii2, pinv[6], mapf[4], mapt[4], mass, dt;
+  float grav, in0, in1, in2, ii0, ii1, ii2, pinv[M / 4][6], mapf[M], mapt[M], mass, dt;
 };
-AGX_DEV QuadConsts load_quad_consts(const AgxRobotParams &P, int l, int l3) {
-  QuadConsts C;
+template <int M>
+AGX_DEV QuadConsts<M> load_quad_consts(const AgxRobotParams &P, int l, int l3) {
+  QuadConsts<M> C;
   C.grav = P.gravity[l3];
   C.in0 = P.inertia[3 * l3 + 0]; C.in1 = P.inertia[3 * l3 + 1]; C.in2 = P.inertia[3 * l3 + 2];
   C.ii0 = P.inertia_inv[3 * l3 + 0]; C.ii1 = P.inertia_inv[3 * l3 + 1]; C.ii2 = P.inertia_inv[3 * l3 + 2];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) C.pinv[c] = P.alloc_pinv[6 * l + c];  // motor l
+  for (int h = 0; h < M / 4; ++h)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) C.pinv[h][c] = P.alloc_pinv[6 * (l + 4 * h) + c];  // motor l + 4 h
   const float *wmap = P.root_link_mode != 0 ? P.alloc : P.wrench_map;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    C.mapf[j] = wmap[4 * l3 + j];        // force row l
-    C.mapt[j] = wmap[4 * (3 + l3) + j];  // torque row l
+  for (int j = 0; j < M; ++j) {
+    C.mapf[j] = wmap[M * l3 + j];        // force row l
+    C.mapt[j] = wmap[M * (3 + l3) + j];  // torque row l
   }
   C.mass = P.mass;
   C.dt = P.dt;
@@ -702,8 +707,8 @@ AGX_DEV float quad_desired_orientation_pos_vel(float f, float yaw, int l) {
   return q4::rotmat_cols_to_quat(b1, b2, b3);
 }
 // base_lee_controller.py:136-154 (compute_body_torque); ZERO_RATE: the angular-velocity set-point is the constant 0
-template <bool ZERO_RATE>
-AGX_DEV float quad_body_torque(const QuadConsts &C, float q, float qd, float wb, float wsp, float kr, float kw, int l) {
+template <bool ZERO_RATE, int M>
+AGX_DEV float quad_body_torque(const QuadConsts<M> &C, float q, float qd, float wb, float wsp, float kr, float kw, int l) {
   const float qe = q4::quat_mul(q4::conj(q), qd);
   const float pp = q4::rot1(qe) * q4::rot2(qe);  // (yz, zx, xy)
   const float pw = qe * q4::bc<3>(qe);           // (xw, yw, zw)
@@ -715,25 +720,36 @@ AGX_DEV float quad_body_torque(const QuadConsts &C, float q, float qd, float wb,
   const float we = ZERO_RATE ? wb : wb - q4::quat_rotate(qe, wsp);
   return ((-kr) * rot_err - kw * we) + ff;
 }
-// allocation (lane l = motor l) + motor model + body wrench (lane l = row l of the force / of the torque)
-AGX_DEV void quad_allocate(const AgxRobotParams &P, const QuadConsts &C, float fz, float torque, float &u, float kT, float tinc,
-                           float tdec, float &fb, float &tb) {
-  float r = 0.0f;
-  r += C.pinv[0] * 0.0f;
-  r += C.pinv[1] * 0.0f;
-  r += C.pinv[2] * fz;
-  r += C.pinv[3] * q4::bc<0>(torque);
-  r += C.pinv[4] * q4::bc<1>(torque);
-  r += C.pinv[5] * q4::bc<2>(torque);
-  u = motor_update(P, r, u, kT, tinc, tdec);
+// allocation (lane l = motors l, l + 4) + motor model + body wrench (lane l = row l of the force / of the torque);
+// `force`: the commanded body force, (0, 0, thrust) for the Lee laws
+template <int M>
+AGX_DEV void quad_allocate(const AgxRobotParams &P, const QuadConsts<M> &C, float force, float torque, float (&u)[M / 4],
+                           const float (&kT)[M / 4], const float (&tinc)[M / 4], const float (&tdec)[M / 4], float &fb, float &tb) {
+  const float w0 = q4::bc<0>(force), w1 = q4::bc<1>(force), w2 = q4::bc<2>(force);
+  const float w3 = q4::bc<0>(torque), w4 = q4::bc<1>(torque), w5 = q4::bc<2>(torque);
+#pragma unroll
+  for (int h = 0; h < M / 4; ++h) {
+    float r = 0.0f;
+    r += C.pinv[h][0] * w0;
+    r += C.pinv[h][1] * w1;
+    r += C.pinv[h][2] * w2;
+    r += C.pinv[h][3] * w3;
+    r += C.pinv[h][4] * w4;
+    r += C.pinv[h][5] * w5;
+    u[h] = motor_update(P, r, u[h], kT[h], tinc[h], tdec[h]);
+  }
   fb = 0.0f;
   tb = 0.0f;
-  const float u0 = q4::bc<0>(u), u1 = q4::bc<1>(u), u2 = q4::bc<2>(u), u3 = q4::bc<3>(u);
-  fb += C.mapf[0] * u0; fb += C.mapf[1] * u1; fb += C.mapf[2] * u2; fb += C.mapf[3] * u3;
-  tb += C.mapt[0] * u0; tb += C.mapt[1] * u1; tb += C.mapt[2] * u2; tb += C.mapt[3] * u3;
+#pragma unroll
+  for (int h = 0; h < M / 4; ++h) {
+    const float u0 = q4::bc<0>(u[h]), u1 = q4::bc<1>(u[h]), u2 = q4::bc<2>(u[h]), u3 = q4::bc<3>(u[h]);
+    fb += C.mapf[4 * h + 0] * u0; fb += C.mapf[4 * h + 1] * u1; fb += C.mapf[4 * h + 2] * u2; fb += C.mapf[4 * h + 3] * u3;
+    tb += C.mapt[4 * h + 0] * u0; tb += C.mapt[4 * h + 1] * u1; tb += C.mapt[4 * h + 2] * u2; tb += C.mapt[4 * h + 3] * u3;
+  }
 }
 // the rigid-body update (integrate(), DESIGN.md "integrator") on the quad
-AGX_DEV void quad_integrate(const AgxRobotParams &P, const QuadConsts &C, float &p, float &q, float &v, float &w, float fb, float tb,
+template <int M>
+AGX_DEV void quad_integrate(const AgxRobotParams &P, const QuadConsts<M> &C, float &p, float &q, float &v, float &w, float fb, float tb,
                             int l) {
   const float dt = C.dt;
   const float fw = q4::quat_rotate(q, fb);
@@ -783,17 +799,17 @@ __global__ void __launch_bounds__(64, 1)
   if (i < n) {
     // ---- loads: one instruction per vector
     float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
-    float u = AGX_AT(B.motor_thrust, l);  // motor l
-    const float kT = P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f;
-    const float tinc = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform;
-    const float tdec = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform;
+    float u[1] = {AGX_AT(B.motor_thrust, l)};  // motor l
+    const float kT[1] = {P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f};
+    const float tinc[1] = {B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform};
+    const float tdec[1] = {B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform};
     const float a_in = actions_in[(size_t)i * 4 + l];
     const float a_old = AGX_AT(B.actions, l);
     const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
     const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
     const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
-    const QuadConsts C = load_quad_consts(P, l, l3);
+    const QuadConsts<4> C = load_quad_consts<4>(P, l, l3);
 
     // ---- update_states + controller (position_control.py:20-51)
     const QuadDerived d = update_states_quad(q, v, w);
@@ -809,7 +825,7 @@ __global__ void __launch_bounds__(64, 1)
 
     // ---- allocation + motor model + body wrench, rigid-body update
     float fb, tb;
-    quad_allocate(P, C, fz, torque, u, kT, tinc, tdec, fb, tb);
+    quad_allocate<4>(P, C, l == 2 ? fz : 0.0f, torque, u, kT, tinc, tdec, fb, tb);
     if (B.body_force && l < 3) AGX_AT(B.body_force, l) = fb;
     quad_integrate(P, C, p, q, v, w, fb, tb, l);
 
@@ -825,7 +841,7 @@ __global__ void __launch_bounds__(64, 1)
       AGX_AT(B.derived, 13 + l) = d.wbody;
     }
     AGX_AT(B.derived, 3 + l) = d.qveh;
-    AGX_AT(B.motor_thrust, l) = u;
+    AGX_AT(B.motor_thrust, l) = u[0];
     if (B.wrench_cmd) {
       if (l < 3) {
         AGX_AT(B.wrench_cmd, l) = l == 2 ? fz : 0.0f;
@@ -908,11 +924,23 @@ AGX_DEV float quat_from_euler_quad(float ang) {
 }
 
 // One env's control law on its lane quad (control/controllers/*.py; run_controller<CTRL> above is the one-lane form):
-// thrust along body z and body torque from the clipped action `a` (a0..a3 in lanes 0..3).
-template <int CTRL>
-AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts &C, float p, float q, float v, const QuadDerived &d, float a,
-                             float kp, float kv, float kr, float kw, int l, float &fz, float &torque) {
+// commanded body force ((0, 0, thrust) for the Lee laws) and body torque from the clipped action `a` (a0..a3 in lanes 0..3;
+// the fully actuated law: position set-point in `a`, orientation set-point xyzw in `a2`).
+template <int CTRL, int M>
+AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts<M> &C, float p, float q, float v, const QuadDerived &d, float a,
+                             float a2, float kp, float kv, float kr, float kw, int l, float &force, float &torque) {
   const float yaw = q4::bc<2>(d.euler);
+  float fz = 0.0f;
+  if (CTRL == AGX_CTRL_FULLY_ACTUATED) {  // fully_actuated_control.py:14-32
+    float nq = sqrtf(q4::dot4(a2, a2));
+    nq = nq < 1e-9f ? 1e-9f : nq;
+    const float qd = a2 / nq;
+    const float acc = kp * (a - p) + kv * (0.0f - v);
+    const float f = (acc - C.grav) * C.mass;
+    force = q4::quat_rotate_inverse(q, f);
+    torque = quad_body_torque<true>(C, q, qd, d.wbody, 0.0f, kr, kw, l);
+    return;
+  }
   if (CTRL == AGX_CTRL_POSITION || CTRL == AGX_CTRL_VELOCITY || CTRL == AGX_CTRL_VEL_STEERING) {
     float acc;
     if (CTRL == AGX_CTRL_POSITION) {  // position_control.py:20-51: kp (sp - p) + kv (0 - v)
@@ -956,12 +984,17 @@ AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts &C, float
     if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
     torque = quad_body_torque<false>(C, q, q, d.wbody, wsp, kr, kw, l);
   }
+  force = l == 2 ? fz : 0.0f;
 }
 
-template <int CTRL>
+template <int M, int CTRL>
 __global__ void __launch_bounds__(64, 1)
     k_env_step_quad_loop(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k, AgxTaskArgs T) {
-  static_assert(CTRL >= AGX_CTRL_POSITION && CTRL <= AGX_CTRL_VEL_STEERING, "the six Lee laws of the quadrotor");
+  static_assert((M == 4 && CTRL >= AGX_CTRL_POSITION && CTRL <= AGX_CTRL_VEL_STEERING) || (M == 8 && CTRL == AGX_CTRL_FULLY_ACTUATED),
+                "the six Lee laws of the quadrotor; the fully actuated octarotor (two motors per lane)");
+  constexpr bool FA = CTRL == AGX_CTRL_FULLY_ACTUATED;  // 7 actions: position set-point (3) + orientation set-point xyzw (4)
+  constexpr int A = FA ? 7 : 4;
+  constexpr int MH = M / 4;
   extern __shared__ float traj[];  // [k][3][16] sub-step positions of the wave's 16 envs (only with obstacles)
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2, slot = tid >> 2;
@@ -969,28 +1002,35 @@ __global__ void __launch_bounds__(64, 1)
   bool reset = false;
   if (i < n) {
     float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
-    float u = AGX_AT(B.motor_thrust, l);
-    const float kT = P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f;
-    const float tinc = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform;
-    const float tdec = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform;
-    const float a_in = actions_in[(size_t)i * 4 + l];
+    float u[MH], kT[MH], tinc[MH], tdec[MH];
+#pragma unroll
+    for (int h = 0; h < MH; ++h) {  // motors l and l + 4
+      u[h] = AGX_AT(B.motor_thrust, l + 4 * h);
+      kT[h] = P.use_rps ? AGX_AT(B.motor_kT, l + 4 * h) : 1.0f;
+      tinc[h] = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l + 4 * h) : P.tau_inc_uniform;
+      tdec[h] = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l + 4 * h) : P.tau_dec_uniform;
+    }
+    const float a_in = actions_in[(size_t)i * A + l];  // (a0 .. a3); fully actuated: position set-point in lanes 0..2
     const float a_old = AGX_AT(B.actions, l);
+    const float a_in2 = FA ? actions_in[(size_t)i * A + 3 + l] : 0.0f;  // fully actuated: orientation set-point xyzw
+    const float a_old2 = FA ? AGX_AT(B.actions, 3 + l) : 0.0f;
     const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
     const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
     const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
-    const QuadConsts C = load_quad_consts(P, l, l3);
+    const QuadConsts<M> C = load_quad_consts<M>(P, l, l3);
     const float dmax = B.disturb_max[l3], dmax_t = B.disturb_max[3 + l3];
     const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions (the same every sub-step)
+    const float a2 = clamp_minmax(a_in2, -10.0f, 10.0f);
     QuadDerived d{};
-    float fz = 0.0f, torque = 0.0f, fb = 0.0f;
+    float force = 0.0f, torque = 0.0f, fb = 0.0f;
     float tlo = p, thi = p;
     for (int sub = 0; sub < k; ++sub) {
       d = update_states_quad(q, v, w);
-      quad_controller<CTRL>(P, C, p, q, v, d, a, kp, kv, kr, kw, l, fz, torque);
+      quad_controller<CTRL>(P, C, p, q, v, d, a, a2, kp, kv, kr, kw, l, force, torque);
       // ---- allocation + motor model + body wrench
       float tb;
-      quad_allocate(P, C, fz, torque, u, kT, tinc, tdec, fb, tb);
+      quad_allocate<M>(P, C, force, torque, u, kT, tinc, tdec, fb, tb);
       if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234), draws supplied by the host
         const float *dd = B.disturb + (size_t)sub * 7 * n + i;
         const float occ = dd[0];
@@ -1050,18 +1090,28 @@ __global__ void __launch_bounds__(64, 1)
         AGX_AT(B.derived, 13 + l) = d.wbody;
       }
       AGX_AT(B.derived, 3 + l) = d.qveh;
-      AGX_AT(B.motor_thrust, l) = u;
+#pragma unroll
+      for (int h = 0; h < MH; ++h) AGX_AT(B.motor_thrust, l + 4 * h) = u[h];
       if (B.wrench_cmd && l < 3) {
-        AGX_AT(B.wrench_cmd, l) = l == 2 ? fz : 0.0f;
+        AGX_AT(B.wrench_cmd, l) = force;
         AGX_AT(B.wrench_cmd, 3 + l) = torque;
       }
       // RobotManagerIGE.pre_physics_step runs every sub-step: prev <- cur, cur <- action
-      AGX_AT(B.prev_actions, l) = k >= 2 ? a_in : a_old;
-      AGX_AT(B.actions, l) = a_in;
+      if (!FA || l < 3) {
+        AGX_AT(B.prev_actions, l) = k >= 2 ? a_in : a_old;
+        AGX_AT(B.actions, l) = a_in;
+      }
+      if (FA) {
+        AGX_AT(B.prev_actions, 3 + l) = k >= 2 ? a_in2 : a_old2;
+        AGX_AT(B.actions, 3 + l) = a_in2;
+      }
     }
     // ---- EnvManager bookkeeping + task epilogue (scalar code, the same in the four lanes; lane 0 stores)
     const float acur = k > 0 ? a_in : a_old;
     const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : AGX_AT(B.prev_actions, l));
+    // action component 3 as the navigation reward reads it: a3, or the first orientation component of the 7-D command
+    const float acur3 = FA ? q4::bc<0>(k > 0 ? a_in2 : a_old2) : q4::bc<3>(acur);
+    const float aprev3 = FA ? q4::bc<0>(k >= 2 ? a_in2 : (k == 1 ? a_old2 : AGX_AT(B.prev_actions, 3 + l))) : q4::bc<3>(aprev);
     const int steps = B.sim_steps[i] + 1;
     bool trunc = false;
     float rew = 0.0f;
@@ -1084,8 +1134,8 @@ __global__ void __launch_bounds__(64, 1)
           AGX_AT(T.pos_err, l) = pe;
         }
         rew = reward_navigation(T.rp, T.curriculum_progress, V3{q4::bc<0>(pe), q4::bc<1>(pe), q4::bc<2>(pe)},
-                                V3{q4::bc<0>(ppe), q4::bc<1>(ppe), q4::bc<2>(ppe)}, q4::bc<0>(acur), q4::bc<2>(acur), q4::bc<3>(acur),
-                                q4::bc<0>(aprev), q4::bc<2>(aprev), q4::bc<3>(aprev), crashed);
+                                V3{q4::bc<0>(ppe), q4::bc<1>(ppe), q4::bc<2>(ppe)}, q4::bc<0>(acur), q4::bc<2>(acur), acur3,
+                                q4::bc<0>(aprev), q4::bc<2>(aprev), aprev3, crashed);
       }
       trunc = steps > T.episode_len;
       reset = (crashed && T.reset_on_collision) || trunc;
@@ -1703,9 +1753,11 @@ static bool quad_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, 
 // ... and the sub-step loop of the velocity / acceleration controlled quadrotors (navigation tasks)
 static bool quad_loop_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, int k) {
   const char *e = getenv("AGX_ENV_STEP_QUAD");
-  if ((e && e[0] == '0') || pick_block(n) != 64 || k < 1 || P->num_motors != 4 || P->num_actions != 4 || B->launch_flags != 0)
-    return false;
-  if (P->controller < AGX_CTRL_POSITION || P->controller > AGX_CTRL_VEL_STEERING) return false;
+  if ((e && e[0] == '0') || pick_block(n) != 64 || k < 1 || B->launch_flags != 0) return false;
+  const bool lee_quad = P->num_motors == 4 && P->num_actions == 4 && P->controller >= AGX_CTRL_POSITION &&
+                        P->controller <= AGX_CTRL_VEL_STEERING;
+  const bool fa_octa = P->num_motors == 8 && P->num_actions == 7 && P->controller == AGX_CTRL_FULLY_ACTUATED;
+  if (!lee_quad && !fa_octa) return false;
   for (int c = 0; c < 3; ++c)
     if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
         P->ang_drag_quadratic[c] != 0.0f)
@@ -1754,7 +1806,7 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
     switch (P->controller) {
 #define AGX_QUAD_LOOP(C_)                                                                                                        \
   case C_:                                                                                                                       \
-    hipLaunchKernelGGL((k_env_step_quad_loop<C_>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P, *B, n,     \
+    hipLaunchKernelGGL((k_env_step_quad_loop<4, C_>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P, *B, n,     \
                        actions_in, k, T);                                                                                        \
     break;
       AGX_QUAD_LOOP(AGX_CTRL_POSITION)
@@ -1764,6 +1816,10 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
       AGX_QUAD_LOOP(AGX_CTRL_ACCELERATION)
       AGX_QUAD_LOOP(AGX_CTRL_VEL_STEERING)
 #undef AGX_QUAD_LOOP
+      case AGX_CTRL_FULLY_ACTUATED:
+        hipLaunchKernelGGL((k_env_step_quad_loop<8, AGX_CTRL_FULLY_ACTUATED>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream,
+                           *P, *B, n, actions_in, k, T);
+        break;
       default: break;
     }
     return check_launch("agx_env_step");
@@ -1787,7 +1843,7 @@ extern "C" int agx_env_step_kernel(const AgxRobotParams *P, const AgxEnvBuffers 
   if (k == 1 && block == 64 && P->num_motors == 4 && P->controller == AGX_CTRL_POSITION && quad_kernel_usable(P, B, &T))
     snprintf(out, (size_t)cap, "k_env_step_quad_position_%d", blocks_for(n, 16) * 64);
   else if (quad_loop_kernel_usable(P, B, n, k))
-    snprintf(out, (size_t)cap, "k_env_step_quad_loop<%d>_%d", P->controller, blocks_for(n, 16) * 64);
+    snprintf(out, (size_t)cap, "k_env_step_quad_loop<%d,%d>_%d", P->num_motors, P->controller, blocks_for(n, 16) * 64);
   else
     snprintf(out, (size_t)cap, "k_env_step<%d,%d,%s,%s>_%d", P->num_motors, P->controller, k == 1 ? "true" : "false",
              block == 64 ? "true" : "false", blocks_for(n, block) * block);

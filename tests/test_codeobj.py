@@ -61,9 +61,9 @@ def test_four_lanes_per_env_kernel(meta):
     r = next(iter(ks.values()))
     assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, r
     assert r["group_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64 and r["vgpr_count"] <= 128, r
-    # the sub-step loop (the six Lee laws of the quadrotor) and the reset / observation launch
+    # the sub-step loop (the six Lee laws of the quadrotor, the fully actuated octarotor) and the reset / observation launch
     loops = {n: r for n, r in meta.items() if "k_env_step_quad_loop<" in n or "k_reset_masked_quad_obs" in n}
-    assert len(loops) == 7
+    assert len(loops) == 8
     for name, r in loops.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64, (name, r)
         assert r["vgpr_count"] <= 168, (name, r["vgpr_count"])

@@ -390,12 +390,13 @@ def test_device_disturbance_stream(orc):
 
 
 @pytest.mark.parametrize("case", ["quad_position", "quad_velocity", "quad_attitude", "quad_rates", "quad_acceleration",
-                                  "quad_velocity_steering"])
+                                  "quad_velocity_steering", "octarotor_fully_actuated"])
 @pytest.mark.parametrize("k", [1, 4])
 def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch):
-    """Every Lee law of the quadrotor has a four-lanes-per-env kernel (k_env_step_quad_position for one position-control
-    sub-step, k_env_step_quad_loop<CTRL> otherwise): agx_env_step_kernel names it, and k sub-steps from the golden case's
-    recorded states / actions / gains give bit for bit the buffers of the one-lane kernel (AGX_ENV_STEP_QUAD=0)."""
+    """Every Lee law of the quadrotor and the fully actuated octarotor (BASELINE configs[3]: two motors per lane) have a
+    four-lanes-per-env kernel (k_env_step_quad_position for one position-control sub-step, k_env_step_quad_loop<M, CTRL>
+    otherwise): agx_env_step_kernel names it, and k sub-steps from the golden case's recorded states / actions / gains give
+    bit for bit the buffers of the one-lane kernel (AGX_ENV_STEP_QUAD=0)."""
     import ctypes as C
 
     from gpu_harness import DynHarness
@@ -415,7 +416,7 @@ def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch)
         if quad == "1":
             assert name.startswith("k_env_step_quad_position" if (case == "quad_position" and k == 1) else "k_env_step_quad_loop<"), name
         else:
-            assert name.startswith("k_env_step<4,"), name
+            assert name.startswith("k_env_step<8," if case.startswith("octarotor") else "k_env_step<4,"), name
         got = []
         for s in range(g["state"].shape[0]):
             H.set(state=g["state"][s], thrust=g["thrust_in"][s])
