@@ -16,7 +16,10 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_golden as gg  # noqa: E402  (the shared output directory: tests/golden, or wherever the provenance test points it)
+
+OUT = gg.OUT
 
 
 def main(ref="/root/reference"):
@@ -30,7 +33,7 @@ def main(ref="/root/reference"):
     out["logstd"] = m["a2c_network.sigma"].numpy().astype(np.float32)
     out["last_mean_rewards"] = np.float64(float(ck["last_mean_rewards"]))
     out["epoch"], out["frame"] = np.int64(ck["epoch"]), np.int64(ck["frame"])
-    dst = os.path.join(ROOT, "tests", "golden", "policy_attitude_actor.npz")
+    dst = os.path.join(OUT, "policy_attitude_actor.npz")
     np.savez_compressed(dst, **out)
     print(dst, {k: getattr(v, "shape", v) for k, v in out.items()})
 

@@ -249,12 +249,12 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
         "gg.OUT = %r\n"
         "gg.main()\n"
         "import gen_golden_imu as gi, gen_golden_lidar_nav as gl, gen_golden_sensors as gs, gen_golden_assets as ga\n"
-        "import gen_golden_nav_glue as gn\n"
-        "[m.main() for m in (gi, gl, gs, ga, gn) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
+        "import gen_golden_nav_glue as gn, gen_golden_policy as gp\n"
+        "[m.main() for m in (gi, gl, gs, ga, gn, gp) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
     )
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
     made = sorted(os.listdir(tmp_path))
-    assert len(made) >= 24
+    assert len(made) >= 25 and "policy_attitude_actor.npz" in made
     for name in made:
         new, old = np.load(tmp_path / name), np.load(os.path.join(ROOT, "tests", "golden", name))
         assert set(new.files) == set(old.files), name
