@@ -104,6 +104,10 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=Tr
             # while the next step computes and the previous step's result is handed out
             gather_buf.exchange(env._parity, overlap=overlap)
 
+    # set-up has finished on the device before the warm-up starts: the launches that follow a process's FIRST device
+    # synchronize are slow (+0.09 ms over the next ~20 steps, profiles/r02_short_run_probe.txt); without this line that first
+    # synchronize is the one that opens the timed region, and a 20-step run reads 16.8 instead of 12.7 us per step
+    torch.cuda.synchronize()
     for i in range(warmup):
         one(i)
     if gather_buf is not None:
