@@ -83,6 +83,21 @@ class navigation_task_config:
     @staticmethod
     def action_transformation_function(action):
         """navigation_task_config.py:87-117: (speed, inclination, yaw-rate) -> velocity command."""
+        # the reference's arithmetic with fewer launches (9 instead of 17): `* max_speed / 2.0` is `* 2.0 / 2.0`, exact in
+        # binary floating point, and the products are written straight into their column
+        a = torch.clamp(action, -1.0, 1.0)
+        max_yawrate, max_inclination = torch.pi / 3, torch.pi / 4
+        speed = a[:, 0] + 1.0
+        inclination = max_inclination * a[:, 1]
+        out = torch.zeros((a.shape[0], 4), device=a.device)
+        torch.mul(speed, torch.cos(inclination), out=out[:, 0])
+        torch.mul(speed, torch.sin(inclination), out=out[:, 2])
+        torch.mul(a[:, 2], max_yawrate, out=out[:, 3])
+        return out
+
+    @staticmethod
+    def action_transformation_function_as_written(action):
+        """the same function in the reference's own wording (navigation_task_config.py:87-117); tests compare the two"""
         a = torch.clamp(action, -1.0, 1.0)
         max_speed, max_yawrate, max_inclination = 2.0, torch.pi / 3, torch.pi / 4
         speed = a[:, 0] + 1.0
@@ -110,12 +125,11 @@ class fully_actuated_lidar_navigation_task_config(navigation_task_config):
         """(x, y, z, yaw) in [-1, 1] -> position set-point within +-(5, 5, 2.5) m, level attitude at yaw * pi."""
         a = torch.clamp(action, -1.0, 1.0)
         out = torch.zeros((a.shape[0], 7), device=a.device)
-        out[:, 0] = 5.0 * a[:, 0]
-        out[:, 1] = 5.0 * a[:, 1]
-        out[:, 2] = 2.5 * a[:, 2]
+        torch.mul(a[:, 0:2], 5.0, out=out[:, 0:2])
+        torch.mul(a[:, 2], 2.5, out=out[:, 2])
         half = 0.5 * torch.pi * a[:, 3]
-        out[:, 5] = torch.sin(half)
-        out[:, 6] = torch.cos(half)
+        torch.sin(half, out=out[:, 5])
+        torch.cos(half, out=out[:, 6])
         return out
 
 
@@ -182,7 +196,7 @@ class lidar_navigation_task_config:  # lidar_navigation_task_config.py:5-108
     def action_transformation_function(action):
         """lidar_navigation_task_config.py:98-108: +-2 m/s^2 acceleration command, +-pi/3 rad/s yaw rate."""
         a = torch.clamp(action, -1.0, 1.0)
-        out = torch.zeros((a.shape[0], 4), device=a.device)
-        out[:, 0:3] = 2 * a[:, 0:3]
-        out[:, 3] = a[:, 3] * (torch.pi / 3)
+        out = torch.empty((a.shape[0], 4), device=a.device)
+        torch.mul(a[:, 0:3], 2, out=out[:, 0:3])
+        torch.mul(a[:, 3], torch.pi / 3, out=out[:, 3])
         return out

@@ -364,3 +364,12 @@ def test_replayed_step_graph_equals_eager_stepping(task_name, cfg_name):
         assert int(graphed.sim_env._step_counter_dev[0]) == 80
     finally:
         cfg.episode_len_steps, cfg.args, cfg.device = old
+
+
+def test_action_transformation_forms_agree_on_the_device():
+    """navigation_task_config.action_transformation_function (9 launches) against the reference's wording (17): equal bit for
+    bit on the device too (`* 2.0 / 2.0` is exact)."""
+    from aerial_gym_simulator_amd.config.task_config import navigation_task_config as cfg
+
+    a = torch.rand(1 << 16, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 3.0 - 1.5
+    assert torch.equal(cfg.action_transformation_function(a), cfg.action_transformation_function_as_written(a))
