@@ -15,7 +15,11 @@ import torch.distributed as dist  # noqa: E402
 
 rank, world, port, mode, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-dist.init_process_group("gloo", rank=rank, world_size=world)
+import datetime  # noqa: E402
+import faulthandler  # noqa: E402
+
+faulthandler.dump_traceback_later(330, exit=False)  # a stuck rank says where (the harness prints this output on its time-out)
+dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))  # a dead peer is an error, not a 30-minute wait
 torch.cuda.set_device(0)
 DEV = "cuda:0"
 

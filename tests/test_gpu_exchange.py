@@ -198,7 +198,7 @@ def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
             cfg.controller_name = old[2]
 
 
-def _run_world2(mode, steps, extra_env=None, timeout=240):
+def _run_world2(mode, steps, extra_env=None, timeout=420):
     import subprocess
     import sys
 
@@ -210,7 +210,10 @@ def _run_world2(mode, steps, extra_env=None, timeout=240):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, AGX_RCCL_PATH=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    # (the double's rendezvous bound is generous here: on a loaded box one rank's set-up can trail the other's by tens of
+    #  seconds; the failure-path test sets its own, short one)
+    env = dict(os.environ, AGX_RCCL_PATH=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", AGX_FAKERCCL_TIMEOUT_S="150")
+    env.update(extra_env or {})
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_world2_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), mode, str(steps)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
@@ -222,7 +225,13 @@ def _run_world2(mode, steps, extra_env=None, timeout=240):
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
-            raise AssertionError(f"world-2 exchange ({mode}) hung for {timeout} s")
+            tails = []
+            for r, q in enumerate(procs):  # what each rank printed before it was killed (a rank that died leaves its peer waiting)
+                try:
+                    tails.append(f"--- rank {r} (exit code {q.poll()}):\n" + (q.communicate(timeout=10)[0] or "")[-2500:])
+                except Exception as e:  # noqa: BLE001
+                    tails.append(f"--- rank {r}: no output ({e})")
+            raise AssertionError(f"world-2 exchange ({mode}) did not finish within {timeout} s\n" + "\n".join(tails))
         outs.append(out)
     return [p.returncode for p in procs], outs
 
