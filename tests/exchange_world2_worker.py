@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_exchange.py::test_rccl_thread_exchange_world2_*: one of TWO processes sharing the box's
+"""Worker of tests/test_gpu_world2_exchange.py::test_rccl_thread_exchange_world2_*: one of TWO processes sharing the box's
 single GPU.  torch.distributed runs on gloo (control traffic only); the library-side exchange (csrc/agx_exchange.hip:
 worker thread, communication stream, device-flag hand-off, done events) binds tests/fakerccl/libfakerccl.so through
 AGX_RCCL_PATH, a stream-ordered shared-memory all-gather, because RCCL refuses two ranks on one device.
