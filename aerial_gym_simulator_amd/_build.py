@@ -16,7 +16,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaerialgym_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["agx_api.cpp", "agx_dynamics.hip", "agx_scene.hip", "agx_raycast.hip", "agx_lidar_nav.hip", "agx_imu.hip", "agx_task_glue.hip", "agx_exchange.hip"]
+SOURCES = ["agx_api.cpp", "agx_math_eval.hip", "agx_dynamics.hip", "agx_scene.hip", "agx_raycast.hip", "agx_lidar_nav.hip", "agx_imu.hip", "agx_task_glue.hip", "agx_exchange.hip"]
 # -ffp-contract=off: every + - * / sqrt is one IEEE operation (bit-exact predicates, see
 # DESIGN.md "numerics"); correctly rounded fp32 divide / sqrt is hipcc's default.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -25,7 +25,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 def source_hash():
     """sha256 over the kernel sources, the C header and the compile flags: identifies the code a counter file under
-    profiles/ was measured on (bench.py marks `traffic` stale when it differs)."""
+    profiles/ was measured on (bench.py marks `traffic` stale when it differs).  The same string is compiled INTO the
+    library (`agx_build_id()`, -DAGX_BUILD_ID), so `binary_is_current()` / `_lib.load()` compare sources and binary
+    directly instead of trusting file times."""
     import hashlib
 
     h = hashlib.sha256(" ".join(FLAGS).encode())
@@ -34,6 +36,26 @@ def source_hash():
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
+
+
+def binary_build_id(path=None):
+    """the build id embedded in a built library (None: no library, or one from before ABI 8)"""
+    import ctypes
+
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        fn = lib.agx_build_id
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
+def binary_is_current():
+    return binary_build_id() == source_hash()
 
 
 def _hipcc():
@@ -78,16 +100,22 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "aerial_gym_hip.h"))
     objs, cmds = [], []
+    build_id = source_hash()
+    # the binary says which sources it was built from: anything else than the current hash is rebuilt, whatever the file
+    # times are (a library copied from elsewhere, a checkout that reset mtimes)
+    relink = force or binary_build_id() != build_id
     for src in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             raise RuntimeError(f"missing source {path}")
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [path] + headers):
-            cmds.append([hipcc] + FLAGS + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj])
+        is_api = src == "agx_api.cpp"  # carries the build id: recompiled (1 s) with every relink
+        if force or _stale(obj, [path] + headers) or (is_api and relink):
+            extra = ['-DAGX_BUILD_ID="%s"' % build_id] if is_api else []
+            cmds.append([hipcc] + FLAGS + extra + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj])
     _run_parallel(cmds, verbose)
-    if force or _stale(LIB_PATH, objs):
+    if relink or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd))
@@ -102,7 +130,8 @@ def _build_variant(extra_flags, lib_path, verbose):
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, f"{tag}_{os.path.splitext(src)[0]}.o")
         objs.append(obj)
-        cmds.append([hipcc] + FLAGS + list(extra_flags) + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
+        ident = ['-DAGX_BUILD_ID="%s+%s"' % (source_hash(), tag)] if src == "agx_api.cpp" else []
+        cmds.append([hipcc] + FLAGS + list(extra_flags) + ident + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
     _run_parallel(cmds, verbose)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs, check=True)
     for o in objs:

@@ -34,6 +34,7 @@ class AgxRobotParams(C.Structure):
         ("controller", C.c_int32),
         ("root_link_mode", C.c_int32),
         ("dt", C.c_float),
+        ("dt_over_6", C.c_float),
         ("gravity", C.c_float * 3),
         ("mass", C.c_float),
         ("inertia", C.c_float * 9),
@@ -184,11 +185,13 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 7  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 8  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
     "agx_abi_version": (C.c_int, []),
+    "agx_build_id": (C.c_char_p, []),
+    "agx_math_eval": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
     "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
     "agx_env_step": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.POINTER(AgxTaskArgs), _P]),
     "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),
@@ -300,6 +303,17 @@ def load():
         raise RuntimeError(f"libaerialgym_hip.so ABI version {lib.agx_abi_version()} != {ABI_VERSION}: stale build?")
     _lib = lib
     return lib
+
+
+def build_id():
+    """identity of the LOADED binary (hash of the sources + flags it was compiled from, `agx_build_id`)"""
+    return load().agx_build_id().decode()
+
+
+def binary_matches_sources():
+    """True when the loaded library was built from the kernel sources lying next to it (counter files under profiles/ are
+    stamped with `build_id()`; a stale library shipped with newer sources shows up here, not in file times)"""
+    return build_id() == _build.source_hash()
 
 
 def check(code, what=""):

@@ -17,3 +17,7 @@ int fail(int code, const char *fmt, ...) {
 
 extern "C" const char *agx_last_error(void) { return agx::error_buffer(); }
 extern "C" int agx_abi_version(void) { return AGX_ABI_VERSION; }
+#ifndef AGX_BUILD_ID
+#error "AGX_BUILD_ID must be defined by the build (aerial_gym_simulator_amd/_build.py: hash of the sources and flags)"
+#endif
+extern "C" const char *agx_build_id(void) { return AGX_BUILD_ID; }

@@ -35,10 +35,21 @@ AGX_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
 AGX_DEV V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 AGX_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 AGX_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// torch.cross: ATen evaluates a_j b_k - a_k b_j inside one compiled expression, which the compiler contracts into a fused
+// multiply-subtract, fma(a_j, b_k, -(a_k b_j)) -- the second product is rounded, the first is not (bit-equal to torch on
+// 10^5 random vectors; nvcc's default fmad gives the same form).  Every cross product of the dynamics path is a torch.cross
+// in the reference (utils/math.py:63,319-346, base_lee_controller.py:144,181-183).  Sums of separately written torch ops
+// (a * b + c as two calls) round separately: that is `dot` and everything else here (contraction is off).
 AGX_DEV V3 cross(V3 a, V3 b) {
+  return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
+}
+// the plain three-rounding form (geometry that is not torch's: scene normals, the ray-cast's Warp restatement)
+AGX_DEV V3 cross_plain(V3 a, V3 b) {
   return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-AGX_DEV float norm(V3 a) { return sqrtf(dot(a, a)); }
+// torch.norm(x, dim) of a 3-vector: the reduction kernel accumulates acc = fma(x_k, x_k, acc) from x_0^2 (bit-equal on
+// 10^5 random vectors)
+AGX_DEV float norm(V3 a) { return sqrtf(__builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x))); }
 AGX_DEV V3 qvec(Q4 q) { return V3{q.x, q.y, q.z}; }
 AGX_DEV Q4 conj(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
 
@@ -118,93 +129,111 @@ AGX_DEV M33 quat_to_rotmat(Q4 q) {
   return m;
 }
 // ---- elementary functions -------------------------------------------------------------------------
-// sincos_bounded / atan2_cw / asin_cw / exp_cw are explicit single-precision kernels (cephes-style range reduction +
-// minimax polynomial; S. Moshier's sinf.c, atanf.c, asinf.c, expf.c) written as individually rounded IEEE operations.
-// The CPU restatement the parity tests check against evaluates the SAME sequences, so with contraction off the dynamics path is
-// bit-reproducible there (ocml's and glibc's sinf / atan2f / expf agree only to ~1 ulp, like torch's own CPU and CUDA
-// kernels); accuracy vs libm is <= 2.5 ulp on the ranges used (DESIGN.md "numerics").
-//
-// sin and cos of the same angle.  Every angle on this path is bounded (|x| < 64: Euler angles,
-// half angles, yaw set-points clipped to +-10), so a 3-term Cody-Waite reduction by pi/2 is
-// exact enough and the Payne-Hanek slow path of the generic sinf/cosf (hundreds of
-// instructions and ~100 VGPRs of dead weight per call site) is not needed.
+// sincos_bounded / atan2_cw / asin_cw / exp_cw: evaluated in float64 (fp64 vector ops run at half the fp32 rate on
+// gfx950) and rounded to float32 ONCE, i.e. correctly rounded in practice (the float result differs from the nearest
+// float only when the exact value lies within ~2e-15 relative of a rounding boundary).  torch's sin / atan2 / exp
+// (SLEEF, glibc, libdevice) are 1-ulp implementations that differ among themselves; the correctly rounded value is the
+// one they all approximate, and with it the per-step body rates stay within 1e-5 of the reference's recorded ones
+// (DESIGN.md "numerics"; rounds 1-2 used <= 2.5-ulp fp32 cephes kernels: 1.9e-5).  Argument reduction with explicit
+// fused multiply-adds, near-minimax polynomials (coefficients: gen_math_coeffs.py next to this file).  The CPU restatement the
+// parity tests check against evaluates the SAME sequence of IEEE double operations, so with contraction off the
+// dynamics path is bit-reproducible there.
+constexpr double kPio2Hi = 0x1.921fb54442d18p+0, kPio2Lo = 0x1.1a62633145c07p-54, kPio4 = 0x1.921fb54442d18p-1;
+constexpr double kPiD = 0x1.921fb54442d18p+1, kTwoOverPi = 0x1.45f306dc9c883p-1, kTanPio8 = 0x1.a827999fcef32p-2;
+constexpr double kLn2Hi = 0x1.62e42fefa39efp-1, kLn2Lo = 0x1.abc9e3b39803fp-56, kInvLn2 = 0x1.71547652b82fep+0;
+
+AGX_DEV double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// sin and cos of the same angle.  Every angle on this path is bounded (|x| < 64: Euler angles, half angles, yaw
+// set-points clipped to +-10): k = rint(x 2/pi), r = x - k pi/2 with pi/2 = hi + lo.
 AGX_DEV void sincos_bounded(float x, float &sn, float &cs) {
-  const float kTwoOverPi = 0.636619772367581343f;
-  float kf = rintf(x * kTwoOverPi);
-  int k = (int)kf;
-  // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8 (cephes DP1..3 x 2)
-  float r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
-  float z = r * r;
-  float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-  float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-  float s0 = (k & 1) ? pc : ps;
-  float c0 = (k & 1) ? ps : pc;
-  sn = (k & 2) ? -s0 : s0;
-  cs = ((k + 1) & 2) ? -c0 : c0;
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * kTwoOverPi);
+  const int k = (int)kd;
+  double r = fmad(-kd, kPio2Hi, xd);
+  r = fmad(-kd, kPio2Lo, r);
+  const double z = r * r;
+  double ps = 0x1.5e098556d302ep-33;
+  ps = fmad(ps, z, -0x1.ae60069e53ef1p-26);
+  ps = fmad(ps, z, 0x1.71de379252004p-19);
+  ps = fmad(ps, z, -0x1.a01a019e80693p-13);
+  ps = fmad(ps, z, 0x1.1111111110ba5p-7);
+  ps = fmad(ps, z, -0x1.5555555555555p-3);
+  const double s = fmad(z * r, ps, r);
+  double pc = 0x1.1c808728603bbp-29;
+  pc = fmad(pc, z, -0x1.27e25ca05d2bep-22);
+  pc = fmad(pc, z, 0x1.a019ff501e5c1p-16);
+  pc = fmad(pc, z, -0x1.6c16c16b5fdb7p-10);
+  pc = fmad(pc, z, 0x1.5555555555434p-5);
+  const double c = fmad(z * z, pc, fmad(-0.5, z, 1.0));
+  const double s0 = (k & 1) ? c : s;
+  const double c0 = (k & 1) ? s : c;
+  sn = (float)((k & 2) ? -s0 : s0);
+  cs = (float)(((k + 1) & 2) ? -c0 : c0);
 }
 
-// cephes atanf: reduction at tan(3 pi / 8) and tan(pi / 8)
-AGX_DEV float atan_cw(float xx) {
-  float x = fabsf(xx), y;
-  if (x > 2.414213562373095f) {
-    y = 1.5707963267948966f;
-    x = -(1.0f / x);
-  } else if (x > 0.4142135623730950f) {
-    y = 0.7853981633974483f;
-    x = (x - 1.0f) / (x + 1.0f);
-  } else {
-    y = 0.0f;
-  }
-  float z = x * x;
-  float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
-  y = y + p;
-  return (xx < 0.0f) ? -y : y;
+// angle of the point (ax, ay), ax, ay >= 0 and not both 0, in [0, pi/2]: octant reduction min / max with the second
+// reduction at tan(pi/8) folded into the same division ((n - d) / (n + d), both exact)
+AGX_DEV double atan2_pos(double ay, double ax) {
+  const bool swap = ay > ax;
+  const double n = swap ? ax : ay, d = swap ? ay : ax;
+  const bool mid = n > kTanPio8 * d;
+  const double num = mid ? n - d : n, den = mid ? n + d : d;
+  const double t = num / den;
+  const double z = t * t;
+  double p = 0x1.7439839062d96p-6;
+  p = fmad(p, z, -0x1.6f15a83e9672ap-5);
+  p = fmad(p, z, 0x1.d5dcd0576e964p-5);
+  p = fmad(p, z, -0x1.105d0bc7abc71p-4);
+  p = fmad(p, z, 0x1.3b0671b310199p-4);
+  p = fmad(p, z, -0x1.745c7de4bec48p-4);
+  p = fmad(p, z, 0x1.c71c6dc4ee1e0p-4);
+  p = fmad(p, z, -0x1.2492491dbb541p-3);
+  p = fmad(p, z, 0x1.999999999083bp-3);
+  p = fmad(p, z, -0x1.5555555555545p-2);
+  double a = fmad(z * t, p, t);
+  if (mid) a = kPio4 + a;
+  if (swap) a = kPio2Hi - a;
+  return a;
 }
 // atan2 for finite arguments; atan2(0, 0) = 0 like torch (every consumer takes the angle modulo 2 pi)
 AGX_DEV float atan2_cw(float y, float x) {
-  const float half_pi = 1.5707963267948966f;
   if (x == 0.0f) {
     if (y == 0.0f) return 0.0f;
-    return (y > 0.0f) ? half_pi : -half_pi;
+    return (y > 0.0f) ? (float)kPio2Hi : -(float)kPio2Hi;
   }
-  float z = atan_cw(y / x);
-  if (x < 0.0f) z = (y < 0.0f) ? z - kPi : z + kPi;
-  return z;
+  double a = atan2_pos(__builtin_fabs((double)y), __builtin_fabs((double)x));
+  if (x < 0.0f) a = kPiD - a;
+  return (float)((y < 0.0f) ? -a : a);
 }
-// cephes asinf, |x| <= 1
+// asin, |x| <= 1: the angle of (sqrt((1 - |x|)(1 + |x|)), |x|); both factors are exact in double
 AGX_DEV float asin_cw(float xx) {
-  float a = fabsf(xx), x, z;
-  bool flag = false;
-  if (a < 1.0e-4f) return xx;
-  if (a > 0.5f) {
-    z = 0.5f * (1.0f - a);
-    x = sqrtf(z);
-    flag = true;
-  } else {
-    x = a;
-    z = x * x;
-  }
-  z = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
-  if (flag) {
-    z = z + z;
-    z = 1.5707963267948966f - z;
-  }
-  return (xx < 0.0f) ? -z : z;
+  const double a = __builtin_fabs((double)xx);
+  const double c = __builtin_sqrt((1.0 - a) * (1.0 + a));
+  const double r = atan2_pos(a, c);
+  return (float)((xx < 0.0f) ? -r : r);
 }
-AGX_DEV float pow2i(int n) { return __uint_as_float((uint32_t)(n + 127) << 23); }  // 2^n, -126 <= n <= 127
-// cephes expf; results below the smallest normal are flushed to 0
+// exp; results below the smallest normal float are flushed to 0
 AGX_DEV float exp_cw(float x) {
   if (x > 88.7228317f) return INFINITY;
   if (x < -87.3365402f) return 0.0f;
-  float z = floorf(1.44269504088896341f * x + 0.5f);
-  float r = x - z * 0.693359375f;
-  r = r - z * -2.12194440e-4f;
-  int n = (int)z;
-  float rr = r * r;
-  float p = (((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r + 1.6666665459e-1f) * r +
-             5.0000001201e-1f) * rr + r + 1.0f;
-  int n1 = n / 2, n2 = n - n1;
-  return p * pow2i(n1) * pow2i(n2);
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * kInvLn2);
+  const int k = (int)kd;
+  double r = fmad(-kd, kLn2Hi, xd);
+  r = fmad(-kd, kLn2Lo, r);
+  double p = 0x1.288088c0e67a5p-22;
+  p = fmad(p, r, 0x1.72c79824255e0p-19);
+  p = fmad(p, r, 0x1.a019c971b4d98p-16);
+  p = fmad(p, r, 0x1.a019ad55d1aa7p-13);
+  p = fmad(p, r, 0x1.6c16c1739a511p-10);
+  p = fmad(p, r, 0x1.1111111c5719ap-7);
+  p = fmad(p, r, 0x1.5555555554ca7p-5);
+  p = fmad(p, r, 0x1.5555555553b48p-3);
+  p = fmad(p, r, 0x1.0000000000000p-1);
+  const double e = fmad(r * r, p, 1.0 + r);
+  const double two_k = __longlong_as_double((long long)(k + 1023) << 52);  // 2^k, -126 <= k <= 128
+  return (float)(e * two_k);
 }
 
 // utils/math.py:156-172

@@ -63,7 +63,7 @@ AGX_DEV float fsqrt(float x) { return sqrtf(x); }
 #endif
 // v / |v| the way torch evaluates it: the norm first, then one division per component
 AGX_DEV V3 normalized(V3 v) {
-  float nv = fsqrt(dot(v, v));
+  float nv = norm(v);
   return V3{fdiv(v.x, nv), fdiv(v.y, nv), fdiv(v.z, nv)};
 }
 }  // namespace agx
@@ -290,12 +290,12 @@ AGX_DEV Wrench run_controller(const AgxRobotParams &P, const EnvState &s, const 
 AGX_DEV float clamp_minmax(float x, float lo, float hi) { return fmaxf(fminf(x, hi), lo); }
 AGX_DEV float sgnf(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 AGX_DEV float motor_rate(float err, float mix, float max_rate) { return clamp_minmax(mix * err, -max_rate, max_rate); }
-AGX_DEV float rk4_delta(float ref, float cur, float mix, float max_rate, float dt) {
+AGX_DEV float rk4_delta(float ref, float cur, float mix, float max_rate, float dt, float dt_over_6) {
   float k1 = motor_rate(ref - cur, mix, max_rate);
   float k2 = motor_rate(ref - (cur + 0.5f * dt * k1), mix, max_rate);
   float k3 = motor_rate(ref - (cur + 0.5f * dt * k2), mix, max_rate);
   float k4 = motor_rate(ref - (cur + dt * k3), mix, max_rate);
-  return (dt / 6.0f) * (k1 + 2.0f * k2 + 2.0f * k3 + k4);
+  return dt_over_6 * (k1 + 2.0f * k2 + 2.0f * k3 + k4);
 }
 AGX_DEV float motor_update(const AgxRobotParams &P, float ref, float cur, float kT, float tau_inc, float tau_dec) {
   const float dt = P.dt;
@@ -307,12 +307,12 @@ AGX_DEV float motor_update(const AgxRobotParams &P, float ref, float cur, float 
     float cur_rpm = fsqrt(fdiv(cur, kT));
     float des_rpm = fsqrt(fdiv(ref, kT));
     if (P.integration_rk4)
-      cur_rpm += rk4_delta(des_rpm, cur_rpm, mix, P.max_rate, dt);
+      cur_rpm += rk4_delta(des_rpm, cur_rpm, mix, P.max_rate, dt, P.dt_over_6);
     else
       cur_rpm += motor_rate(des_rpm - cur_rpm, mix, P.max_rate) * dt;
     return kT * (cur_rpm * cur_rpm);
   }
-  if (P.integration_rk4) return cur + rk4_delta(ref, cur, mix, P.max_rate, dt);
+  if (P.integration_rk4) return cur + rk4_delta(ref, cur, mix, P.max_rate, dt, P.dt_over_6);
   return cur + motor_rate(err, mix, P.max_rate) * dt;
 }
 
@@ -428,7 +428,7 @@ AGX_DEV float reward_position(const EnvState &s, Q4 qveh, V3 wb, V3 tgt, bool &c
   float dist_reward = (20.0f - dist) / 40.0f;
   V3 up = quat_rotate(s.q, V3{0.0f, 0.0f, 1.0f});  // quat_axis(q, 2)
   float tilt = fabsf(1.0f - up.z);
-  float up_reward = 0.2f / (0.1f + tilt * tilt);
+  float up_reward = (1.0f / (0.1f + tilt * tilt)) * 0.2f;  // `0.2 / tensor` is tensor.reciprocal() * 0.2 in torch (eager and TorchScript)
   float spin = norm(wb);
   float ang_reward = (1.0f / (1.0f + spin * spin)) * 3.0f;
   float total = pos_reward + dist_reward + pos_reward * (up_reward + ang_reward);
@@ -536,24 +536,31 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
         for (int j = 0; j < M; ++j) acc += (root_link ? P.alloc[M * r + j] : P.wrench_map[M * r + j]) * u[j];
         bw[r] = acc;
       }
-      // simulate_drag (base_multirotor.py:260-285), pre-physics body velocities; all-zero coefficients (base quadrotor)
-      // add +-0 to every component: skipped (a scalar test of kernel arguments)
+      // The ROOT link's entry of robot_force / robot_torque_tensor: the allocator's wrench in root-link mode, else 0.
+      // simulate_drag (base_multirotor.py:260-285; pre-physics body velocities) and apply_disturbance (:213-234) accumulate
+      // into it with `+=`, in that order; the net wrench on the rigid composite is the motor links' sum plus that entry.  So
+      // with forces at the motor links, drag AND disturbance are summed first and added to the links' sum once (`root`);
+      // with one of the two, or in root-link mode, that is the running sum below.  All-zero drag coefficients (base
+      // quadrotor) add +-0 to every component: skipped (a scalar test of kernel arguments).
+      const bool any_dist = B.disturb != nullptr || B.disturb_prob > 0.0f;
+      const bool split_root = !root_link && has_drag && any_dist;  // wave-uniform
+      float dr[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, di[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       if (has_drag) {
         float vbn = norm(d.vbody);
-        bw[0] += (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
-        bw[1] += (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
-        bw[2] += (-P.lin_drag_linear[2] * d.vbody.z) + (-P.lin_drag_quadratic[2] * vbn * d.vbody.z);
-        bw[3] += (-P.ang_drag_linear[0] * d.wbody.x) + (-P.ang_drag_quadratic[0] * fabsf(d.wbody.x) * d.wbody.x);
-        bw[4] += (-P.ang_drag_linear[1] * d.wbody.y) + (-P.ang_drag_quadratic[1] * fabsf(d.wbody.y) * d.wbody.y);
-        bw[5] += (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
+        dr[0] = (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
+        dr[1] = (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
+        dr[2] = (-P.lin_drag_linear[2] * d.vbody.z) + (-P.lin_drag_quadratic[2] * vbn * d.vbody.z);
+        dr[3] = (-P.ang_drag_linear[0] * d.wbody.x) + (-P.ang_drag_quadratic[0] * fabsf(d.wbody.x) * d.wbody.x);
+        dr[4] = (-P.ang_drag_linear[1] * d.wbody.y) + (-P.ang_drag_quadratic[1] * fabsf(d.wbody.y) * d.wbody.y);
+        dr[5] = (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
       }
-      if (B.disturb) {  // apply_disturbance (base_multirotor.py:213-234), draws supplied by the host
+      if (B.disturb) {  // draws supplied by the host
         const float *dd = B.disturb + (size_t)(sub_base + sub) * 7 * n + i;
         float occ = dd[0];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           float lo = -B.disturb_max[c], hi = B.disturb_max[c];
-          bw[c] += ((hi - lo) * dd[(size_t)(1 + c) * n] + lo) * occ;
+          di[c] = ((hi - lo) * dd[(size_t)(1 + c) * n] + lo) * occ;
         }
       } else if (B.disturb_prob > 0.0f) {  // same, drawn in place: 7 uniforms per env and sub-step
         float ud[7];
@@ -562,8 +569,12 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           float lo = -B.disturb_max[c], hi = B.disturb_max[c];
-          bw[c] += ((hi - lo) * ud[1 + c] + lo) * occ;
+          di[c] = ((hi - lo) * ud[1 + c] + lo) * occ;
         }
+      }
+      if (has_drag || any_dist) {  // an absent term is +0: x + 0 = x
+#pragma unroll
+        for (int c = 0; c < 6; ++c) bw[c] = split_root ? bw[c] + (dr[c] + di[c]) : (bw[c] + dr[c]) + di[c];
       }
       if (B.body_force && sub == k - 1) {  // what the IMU's force sensor sees (agx_imu_update)
         AGX_AT(B.body_force, 0) = bw[0]; AGX_AT(B.body_force, 1) = bw[1]; AGX_AT(B.body_force, 2) = bw[2];
@@ -697,12 +708,12 @@ AGX_DEV float quad_thrust_along_body_z(float q, float f, int l) {
 }
 // base_lee_controller.py:173-194 (desired_orientation_pos_vel)
 AGX_DEV float quad_desired_orientation_pos_vel(float f, float yaw, int l) {
-  const float b3 = fdiv(f, fsqrt(q4::dot3(f, f)));
+  const float b3 = fdiv(f, q4::norm3(f));
   float sy, cy;
   sincos_bounded(yaw, sy, cy);
   const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
   const float cb = q4::cross3(b3, tmp);
-  const float b2 = fdiv(cb, fsqrt(q4::dot3(cb, cb)));
+  const float b2 = fdiv(cb, q4::norm3(cb));
   const float b1 = q4::cross3(b2, b3);
   return q4::rotmat_cols_to_quat(b1, b2, b3);
 }
@@ -858,7 +869,7 @@ __global__ void __launch_bounds__(64, 1)
     if (T.kind == AGX_TASK_POSITION) {
       const float tgt = AGX_AT(T.target, l3);
       const float pe_t = q4::quat_apply(q4::conj(d.qveh), tgt - p);  // quat_apply_inverse
-      const float dist = fsqrt(q4::dot3(pe_t, pe_t));
+      const float dist = q4::norm3(pe_t);
       // 3 exp(-8 d^2) + 2 exp(-4 d^2): both exponentials in one evaluation (lanes 0 / 1)
       const float ex = exp_cw((l == 0 ? -8.0f : -4.0f) * dist * dist);
       const float pos_reward = 3.0f * q4::bc<0>(ex) + 2.0f * q4::bc<1>(ex);
@@ -866,11 +877,11 @@ __global__ void __launch_bounds__(64, 1)
       const float axis_z = l == 2 ? 1.0f : 0.0f;
       const float up = q4::bc<2>(q4::quat_rotate(q, axis_z));  // quat_axis(q, 2).z
       const float tilt = fabsf(1.0f - up);
-      const float spin = fsqrt(q4::dot3(d.wbody, d.wbody));
-      // 0.2 / (0.1 + tilt^2) and 1 / (1 + spin^2): one division (lanes 0 / 1)
-      const float quo = (l == 0 ? 0.2f : 1.0f) / (l == 0 ? 0.1f + tilt * tilt : 1.0f + spin * spin);
+      const float spin = q4::norm3(d.wbody);
+      // 0.2 / (0.1 + tilt^2) = reciprocal * 0.2 (torch's scalar / tensor) and (1 / (1 + spin^2)) * 3: one division (lanes 0 / 1)
+      const float quo = (1.0f / (l == 0 ? 0.1f + tilt * tilt : 1.0f + spin * spin)) * (l == 0 ? 0.2f : 3.0f);
       const float up_reward = q4::bc<0>(quo);
-      const float ang_reward = q4::bc<1>(quo) * 3.0f;
+      const float ang_reward = q4::bc<1>(quo);
       float total = pos_reward + dist_reward + pos_reward * (up_reward + ang_reward);
       total = 1.0f * total;
       if (dist > 8.0f) crashed = true;
@@ -973,7 +984,7 @@ AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts<M> &C, fl
     torque = quad_body_torque<false>(C, q, qd, d.wbody, wsp, kr, kw, l);
   } else if (CTRL == AGX_CTRL_ATTITUDE) {  // attitude_control.py:16-43
     const float g0 = P.gravity[0], g1 = P.gravity[1], g2 = P.gravity[2];
-    fz = (q4::bc<0>(a) + 1.0f) * C.mass * sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    fz = (q4::bc<0>(a) + 1.0f) * C.mass * norm(V3{g0, g1, g2});  // torch.norm(gravity)
     float wsp = euler_rates_to_body_rates_quad(d.euler, q4::bc<3>(a));
     if (l == 2) wsp = fminf(fmaxf(wsp, -P.max_yaw_rate), P.max_yaw_rate);
     const float qd = quat_from_euler_quad(q4::by_lane(l, q4::bc<1>(a), q4::bc<2>(a), yaw));

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_lidar_image_obs(AgxEnvBuffers B, int n,
   float tmin = INFINITY;
   for (int j = tid; j < npts; j += blockDim.x) {
     V3 d = V3{pc[3 * j] - p.x, pc[3 * j + 1] - p.y, pc[3 * j + 2] - p.z};
-    float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    float r = norm(d);  // torch.norm(world_dir_vectors, dim=-1)
     float den = r + 1e-6f;
     V3 u = V3{d.x / den, d.y / den, d.z / den};
     float rc = r;

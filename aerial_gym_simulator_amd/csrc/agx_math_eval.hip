@@ -1,0 +1,31 @@
+// agx_math_eval: the elementary functions of the dynamics path (agx_device_math.h) evaluated on the device for a vector
+// of arguments.  Diagnostic entry of the C ABI: the parity tests check device == CPU restatement bit for bit on
+// millions of arguments (the dynamics kernels inline exactly these functions).
+#include "agx_common.h"
+#include "agx_device_math.h"
+
+namespace {
+using namespace agx;
+
+__global__ void k_math_eval(int which, int n, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s, c;
+  switch (which) {
+    case AGX_MATH_SIN: sincos_bounded(x[i], s, c); out[i] = s; break;
+    case AGX_MATH_COS: sincos_bounded(x[i], s, c); out[i] = c; break;
+    case AGX_MATH_ATAN2: out[i] = atan2_cw(x[i], y[i]); break;
+    case AGX_MATH_ASIN: out[i] = asin_cw(x[i]); break;
+    default: out[i] = exp_cw(x[i]); break;
+  }
+}
+}  // namespace
+
+extern "C" int agx_math_eval(int which, int n, const float *x, const float *y, float *out, void *stream) {
+  AGX_REQUIRE(which >= AGX_MATH_SIN && which <= AGX_MATH_EXP, "which = %d: not an AGX_MATH_* id", which);
+  AGX_REQUIRE(n >= 0, "n = %d", n);
+  AGX_REQUIRE(n == 0 || (x && out && (which != AGX_MATH_ATAN2 || y)), "null buffer");
+  if (n == 0) return AGX_OK;
+  hipLaunchKernelGGL(k_math_eval, dim3(agx::blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, which, n, x, y, out);
+  return agx::check_launch("agx_math_eval");
+}

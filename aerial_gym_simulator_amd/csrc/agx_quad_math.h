@@ -41,10 +41,15 @@ AGX_DEV float dot4(float a, float b) {
   const float p = a * b;
   return ((bc<0>(p) + bc<1>(p)) + bc<2>(p)) + bc<3>(p);
 }
-// (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+// torch.cross (agx_device_math.h `cross`): component i = fma(a_j, b_k, -(a_k b_j))
 AGX_DEV float cross3(float a, float b) {
-  const float d = a * rot1(b) - rot1(a) * b;  // lane x: a.x*b.y - a.y*b.x = the z component, y: x, z: y
+  const float d = __builtin_fmaf(a, rot1(b), -(rot1(a) * b));  // lane x: fma(a.x, b.y, -(a.y b.x)) = the z component, y: x, z: y
   return rot1(d);
+}
+// torch.norm of a 3-vector (agx_device_math.h `norm`): sqrt(fma(z, z, fma(y, y, x x))), replicated
+AGX_DEV float norm3(float a) {
+  const float x = bc<0>(a), y = bc<1>(a), z = bc<2>(a);
+  return sqrtf(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
 }
 // utils/math.py:329-336
 AGX_DEV float quat_rotate(float q, float v) {

@@ -423,13 +423,13 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
       if (active && r.face >= 0) {
         const float *t = tris + (size_t)r.face * 9;
         const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
-        nrm = wp_normalize(cross(b - a, c - a));  // warp intersect.h out_normal, mesh.h normalize(min_normal)
+        nrm = wp_normalize(cross_plain(b - a, c - a));  // warp intersect.h out_normal, mesh.h normalize(min_normal)
       }
       if (mode == AGX_RAY_NORMAL) {
         if (LIDAR) {
           nrm = wp_normalize(wp_quat_rotate(Q4{-sq.x, -sq.y, -sq.z, sq.w}, nrm));  // quat_inverse(lidar_quaternion)
         } else {
-          nrm = V3{dot(nrm, rdp), dot(nrm, cross(rdp, V3{0.0f, 0.0f, 1.0f})), dot(nrm, cross(rdp, V3{0.0f, 1.0f, 0.0f}))};
+          nrm = V3{dot(nrm, rdp), dot(nrm, cross_plain(rdp, V3{0.0f, 0.0f, 1.0f})), dot(nrm, cross_plain(rdp, V3{0.0f, 1.0f, 0.0f}))};
         }
       }
       if (active) {
@@ -535,9 +535,9 @@ __global__ void __launch_bounds__(256) k_sensor_postprocess_points(size_t count,
       v[c] = p;
     }
     if (limits) {
-      float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      float nrm = norm(V3{v[0], v[1], v[2]});  // Tensor.norm(dim = 4)
       if (nrm > max_range) v[0] = v[1] = v[2] = far_oor;
-      nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      nrm = norm(V3{v[0], v[1], v[2]});
       if (nrm < min_range) v[0] = v[1] = v[2] = near_oor;
       if (normalize) {
 #pragma unroll

@@ -283,7 +283,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       // alone in the low word: hipcc dropped an `& 0xFFFFFF` on the LDS read when the class lived there.)
       if (ppo > 0 && !parked) {
         V3 e1 = V3{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2 = V3{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
-        V3 nrm = cross(e1, e2);
+        V3 nrm = cross_plain(e1, e2);
         float ax = fabsf(nrm.x), ay = fabsf(nrm.y), az = fabsf(nrm.z);
         int d = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
         float comp = d == 0 ? nrm.x : (d == 1 ? nrm.y : nrm.z);

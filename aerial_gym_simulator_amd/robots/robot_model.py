@@ -135,6 +135,7 @@ def pack_robot_params(d):
     P.controller = CTRL_IDS[d["controller"]]
     P.root_link_mode = int(d["root_link_mode"])
     P.dt = d["dt"]
+    P.dt_over_6 = float(d["dt"]) / 6.0  # double arithmetic like the reference's python scalars, rounded once (motor_model.py:198)
     _fill(P.gravity, d["gravity"])
     P.mass = d["mass"]
     _fill(P.inertia, d["inertia"])

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 7
+#define AGX_ABI_VERSION 8
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -73,6 +73,9 @@ typedef struct AgxRobotParams {
   int32_t controller;
   int32_t root_link_mode;               /* force_application_level == "root_link" */
   float dt;
+  float dt_over_6;                      /* float(dt / 6.0) with dt the config's double: the reference forms the RK4 weight
+                                           from python scalars, `(dt / 6.0) * (k1 + ...)` (motor_model.py:198) -- not
+                                           float(dt) / 6.0f, which is 1 ulp away for dt = 0.01                       */
   float gravity[3];
   float mass;
   float inertia[9];                     /* row-major, body frame, about COM       */
@@ -167,6 +170,11 @@ typedef struct AgxEnvBuffers {
 
 const char *agx_last_error(void);
 int agx_abi_version(void);
+/* Identity of the BINARY: the hash (sha256[:16]) of the kernel sources, this header and the compile flags the library
+ * was built from, embedded at compile time (aerial_gym_simulator_amd/_build.py).  Callers compare it with the hash of
+ * the sources they see (`_build.source_hash()`): a stale library shipped next to newer sources is detected whatever its
+ * file times say; bench.py stamps committed counter files with it.                                                     */
+const char *agx_build_id(void);
 
 /* ---- dynamics -------------------------------------------------------------------
  * agx_dynamics_substeps: `k` physics sub-steps of every env, fused in one launch.
@@ -209,6 +217,13 @@ int agx_env_step_kernel(const AgxRobotParams *params, const AgxEnvBuffers *buf, 
 
 /* BaseMultirotor.update_states alone (base_multirotor.py:287-294). */
 int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
+
+/* The elementary functions the kernels evaluate in place of torch.sin / cos / atan2 / asin / exp (utils/math.py:124-172,
+ * base_lee_controller.py:136-215, the reward functions' torch.exp), on device vectors: out[i] = f(x[i]) (atan2:
+ * atan2(x[i], y[i]), x = the "y" argument).  float64 inside, rounded once: correctly rounded in practice.  Diagnostic
+ * entry: the parity tests compare it bit for bit with the CPU restatement.                                          */
+enum { AGX_MATH_SIN = 0, AGX_MATH_COS = 1, AGX_MATH_ATAN2 = 2, AGX_MATH_ASIN = 3, AGX_MATH_EXP = 4 };
+int agx_math_eval(int which, int n, const float *x, const float *y, float *out, void *stream);
 
 /* Controller plug-in entry: BaseLeeController subclasses' update(), returning the wrench
  * [6][N] into buf->wrench_cmd (control/controllers/ *.py).  Uses buf->state/derived as is.

@@ -26,15 +26,23 @@ import os
 import sys
 import xml.etree.ElementTree as ET
 
-import numpy as np
-import torch
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+import cr_torch  # noqa: E402
+
+CR = cr_torch.requested()  # `--cr` / AGX_GOLDEN_CR=1: the reference with correctly rounded elementary functions -> tests/golden/cr/
+if CR:
+    cr_torch.prepare_environment()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+if CR:
+    cr_torch.install()
 import oracle as orc  # noqa: E402
 import ref_shells  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", *(["cr"] if CR else []))
 torch.set_num_threads(1)
 
 
@@ -200,6 +208,16 @@ def make_ref_robot(robot_cfg, controller_name, n, consts, seed):
     return robot, gtd
 
 
+def link_wrench(u, W):
+    """net body wrench of the motor-link forces: sum_j W[:, j] u_j accumulated motor by motor from 0 in float32 -- the order
+    of the oracle (and of the kernels); a BLAS `u @ W.T` rounds differently (blocked, fused multiply-adds)"""
+    u, W = np.asarray(u, np.float32), np.asarray(W, np.float32)
+    acc = np.zeros((u.shape[0], 6), np.float32)
+    for j in range(u.shape[1]):
+        acc = acc + W[None, :, j] * u[:, j:j + 1]
+    return acc
+
+
 def random_state(n, rng, spread=1.0, tilt=0.6):
     m = ref_shells.ref("utils.math")
     s = torch.zeros(n, 13)
@@ -280,7 +298,7 @@ def gen_step(robot_name, robot_cfg, controller_name, ctrl_key, consts, n=64, K=6
         # advance the state with the oracle integrator (input generation only)
         u = gtd["robot_force_tensor"][:, mask, 2].numpy().astype(np.float32)
         W = consts["wrench_map"].astype(np.float32)
-        bw = (u @ W.T).astype(np.float32)
+        bw = link_wrench(u, W)
         bw[:, 0:3] += gtd["robot_force_tensor"][:, 0, :].numpy()
         bw[:, 3:6] += gtd["robot_torque_tensor"][:, 0, :].numpy()
         st = np.ascontiguousarray(gtd["robot_state_tensor"].numpy().astype(np.float32))
@@ -414,7 +432,7 @@ def gen_trace(consts, controller_name="lee_position_control", ctrl_key="position
         # one physics sub-step (empty_env.py:12)
         robot.step(actions.clone())
         u = gtd["robot_force_tensor"][:, mask, 2].numpy().astype(np.float32)
-        bw = (u @ W.T).astype(np.float32)
+        bw = link_wrench(u, W)
         bw[:, 0:3] += gtd["robot_force_tensor"][:, 0, :].numpy()
         bw[:, 3:6] += gtd["robot_torque_tensor"][:, 0, :].numpy()
         st = np.ascontiguousarray(gtd["robot_state_tensor"].numpy().astype(np.float32))
@@ -509,7 +527,8 @@ def main():
     gen_math(rng)
     consts = {"quad": robot_constants("quad", BaseQuadCfg), "octarotor": robot_constants("octarotor", BaseOctarotorCfg)}
     for name, c in consts.items():
-        np.savez(os.path.join(OUT, f"robot_{name}.npz"), **c)
+        if not CR:  # URDF constants: no elementary function involved
+            np.savez(os.path.join(OUT, f"robot_{name}.npz"), **c)
         print(name, "mass", c["mass"], "J diag", np.diag(c["inertia"]), "com", c["com"],
               "| max |W - A| =", np.abs(c["wrench_map"] - c["alloc"]).max())
     for ctrl_name, key in (("lee_position_control", "position"), ("lee_velocity_control", "velocity"),

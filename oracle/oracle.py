@@ -36,6 +36,7 @@ class OrcRobotParams(C.Structure):
         ("controller", C.c_int32),
         ("root_link_mode", C.c_int32),
         ("dt", C.c_float),
+        ("dt_over_6", C.c_float),
         ("gravity", C.c_float * 3),
         ("mass", C.c_float),
         ("inertia", C.c_float * 9),
@@ -108,6 +109,7 @@ def make_params(d):
     P.controller = CTRL[ctrl] if isinstance(ctrl, str) else int(ctrl)
     P.root_link_mode = int(d.get("root_link_mode", 0))
     P.dt = float(d["dt"])
+    P.dt_over_6 = float(d["dt"]) / 6.0  # python double arithmetic, rounded once by ctypes (motor_model.py:198)
     P.gravity[:] = [float(x) for x in d["gravity"]]
     P.mass = float(d["mass"])
     J = np.asarray(d["inertia"], dtype=np.float32).reshape(9)

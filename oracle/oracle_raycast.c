@@ -269,9 +269,10 @@ static int closest_hit(v3 o, v3 d, float max_t, const float *tris, int nt, const
 /* ------------------------------------------------------------------ */
 static void tf_apply(const float q[4], const float t[3], const float v[3], float o[3]) {
   /* utils/math.py:314-320, 375-376 */
-  float c1[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+  /* torch.cross = fma(a_j, b_k, -(a_k b_j)): see cross3 in oracle_dynamics.c */
+  float c1[3] = {fmaf(q[1], v[2], -(q[2] * v[1])), fmaf(q[2], v[0], -(q[0] * v[2])), fmaf(q[0], v[1], -(q[1] * v[0]))};
   float tt[3] = {c1[0] * 2.0f, c1[1] * 2.0f, c1[2] * 2.0f};
-  float c2[3] = {q[1] * tt[2] - q[2] * tt[1], q[2] * tt[0] - q[0] * tt[2], q[0] * tt[1] - q[1] * tt[0]};
+  float c2[3] = {fmaf(q[1], tt[2], -(q[2] * tt[1])), fmaf(q[2], tt[0], -(q[0] * tt[2])), fmaf(q[0], tt[1], -(q[1] * tt[0]))};
   for (int k = 0; k < 3; ++k) o[k] = (v[k] + q[3] * tt[k] + c2[k]) + t[k];
 }
 
@@ -592,9 +593,10 @@ void orc_sensor_postprocess_points(size_t count, float *pixels, const float *z_n
       v[c] = p;
     }
     if (limits) {
-      float nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      /* Tensor.norm(dim) of 3 components: fma chain, see norm3 in oracle_dynamics.c */
+      float nrm = sqrtf(fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
       if (nrm > max_range) v[0] = v[1] = v[2] = far_oor;
-      nrm = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      nrm = sqrtf(fmaf(v[2], v[2], fmaf(v[1], v[1], v[0] * v[0])));
       if (nrm < min_range) v[0] = v[1] = v[2] = near_oor;
       if (normalize)
         for (int c = 0; c < 3; ++c) v[c] = v[c] / max_range;

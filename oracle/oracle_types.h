@@ -41,6 +41,8 @@ typedef struct {
   int32_t controller;     /* ORC_CTRL_*                                       */
   int32_t root_link_mode; /* control_allocator_config.force_application_level == "root_link" */
   float dt;               /* sim.dt, base_sim_config.py:21                    */
+  float dt_over_6;        /* float(dt / 6.0), dt as the python double: motor_model.py:198 forms the RK4 weight
+                             from python scalars (float(dt) / 6.0f is 1 ulp away for dt = 0.01)          */
   float gravity[3];       /* base_sim_config.py:23                            */
   float mass;             /* composite, robot_manager.py:295-435              */
   float inertia[9];       /* composite J about COM, body frame, row-major     */

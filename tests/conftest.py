@@ -17,8 +17,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP GPU (MI355X); run with -m gpu")
 
 
-def load_golden(name):
-    return np.load(os.path.join(GOLDEN, name + ".npz"))
+def load_golden(name, cr=False):
+    """cr=True: the fixture of the same name made by the reference's code with correctly rounded elementary functions
+    (tests/golden/cr/, oracle/cr_torch.py): the oracle and the kernels reproduce those BIT FOR BIT."""
+    return np.load(os.path.join(GOLDEN, *(["cr"] if cr else []), name + ".npz"))
 
 
 def golden_params(g):

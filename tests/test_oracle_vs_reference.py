@@ -232,6 +232,22 @@ def test_imu_matches_reference(orc, frame):
     assert np.abs(g[frame + "_meas"][-1][:8, 0:3]).max() == 100.0  # the clamp was exercised
 
 
+def _compare_fixture_dirs(made_dir, committed_dir, names=None):
+    import os
+
+    made = sorted(os.listdir(made_dir))
+    for name in (made if names is None else names):
+        new, old = np.load(os.path.join(made_dir, name)), np.load(os.path.join(committed_dir, name))
+        assert set(new.files) == set(old.files), name
+        for k in new.files:
+            a, b = new[k], old[k]
+            if a.dtype.kind in "US":
+                assert str(a) == str(b), (name, k)
+            else:
+                assert a.shape == b.shape and np.array_equal(a, b), (name, k)
+    return made
+
+
 def test_goldens_are_reproducible_from_the_reference(tmp_path):
     """Provenance of tests/golden/: running the committed generator scripts against the reference's own code
     (/root/reference, present in the build container only) reproduces every generated fixture bit for bit."""
@@ -253,17 +269,33 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
         "[m.main() for m in (gi, gl, gs, ga, gn, gp) if hasattr(m, 'main')]\n" % (os.path.join(ROOT, "oracle"), str(tmp_path))
     )
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
-    made = sorted(os.listdir(tmp_path))
+    made = _compare_fixture_dirs(str(tmp_path), os.path.join(ROOT, "tests", "golden"))
     assert len(made) >= 25 and "policy_attitude_actor.npz" in made
-    for name in made:
-        new, old = np.load(tmp_path / name), np.load(os.path.join(ROOT, "tests", "golden", name))
-        assert set(new.files) == set(old.files), name
-        for k in new.files:
-            a, b = new[k], old[k]
-            if a.dtype.kind in "US":
-                assert str(a) == str(b), (name, k)
-            else:
-                assert a.shape == b.shape and np.array_equal(a, b), (name, k)
+
+
+def test_cr_goldens_are_reproducible_and_torchscript_changes_no_bit(tmp_path):
+    """tests/golden/cr/ (the reference with correctly rounded elementary functions, oracle/cr_torch.py) is reproduced bit
+    for bit by `gen_golden.py` in CR mode.  CR mode has to switch TorchScript off (PYTORCH_JIT=0) to reach the scripted
+    functions: the ORDINARY fixtures generated with TorchScript off are bit-identical to the committed ones (made with it
+    on), so that switch changes nothing the reference computes."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    if not os.path.isdir("/root/reference/aerial_gym"):
+        pytest.skip("the reference tree is not on this machine")
+    code = ("import sys; sys.path.insert(0, %r)\nimport gen_golden as gg\ngg.OUT = %%r\nimport os; os.makedirs(gg.OUT, exist_ok=True)\n"
+            "gg.main()\n" % os.path.join(ROOT, "oracle"))
+    cr_dir, nojit_dir = str(tmp_path / "cr"), str(tmp_path / "nojit")
+    subprocess.run([sys.executable, "-c", code % cr_dir], check=True, capture_output=True, timeout=600,
+                   env=dict(os.environ, AGX_GOLDEN_CR="1"))
+    made = _compare_fixture_dirs(cr_dir, os.path.join(ROOT, "tests", "golden", "cr"))
+    assert len(made) == 16 and sorted(made) == sorted(os.listdir(os.path.join(ROOT, "tests", "golden", "cr")))
+    subprocess.run([sys.executable, "-c", code % nojit_dir], check=True, capture_output=True, timeout=600,
+                   env=dict(os.environ, PYTORCH_JIT="0"))
+    assert len(_compare_fixture_dirs(nojit_dir, os.path.join(ROOT, "tests", "golden"))) >= 18
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
