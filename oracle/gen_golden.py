@@ -31,14 +31,18 @@ sys.path.insert(0, HERE)
 import cr_torch  # noqa: E402
 
 CR = cr_torch.requested()  # `--cr` / AGX_GOLDEN_CR=1: the reference with correctly rounded elementary functions -> tests/golden/cr/
-if CR:
+# TorchScript off (the switchable patch of cr_torch must reach the scripted functions); AGX_GOLDEN_JIT=1 keeps it on: the
+# `*_cr` arrays then cannot be made, everything else comes out bit-identical (a test checks exactly that)
+JIT = os.environ.get("AGX_GOLDEN_JIT") == "1" and not CR
+if not JIT:
     cr_torch.prepare_environment()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-if CR:
+if not JIT:
     cr_torch.install()
+    cr_torch.enable(CR)
 import oracle as orc  # noqa: E402
 import ref_shells  # noqa: E402
 
@@ -218,6 +222,18 @@ def link_wrench(u, W):
     return acc
 
 
+def advance_state(gtd, mask, consts, P):
+    """the state after the reference's force / torque tensors have acted for one sub-step: motor links' sum + the root link's
+    entry, through the oracle's integrator (PhysX is a closed binary)"""
+    u = gtd["robot_force_tensor"][:, mask, 2].numpy().astype(np.float32)
+    bw = link_wrench(u, consts["wrench_map"].astype(np.float32))
+    bw[:, 0:3] += gtd["robot_force_tensor"][:, 0, :].numpy()
+    bw[:, 3:6] += gtd["robot_torque_tensor"][:, 0, :].numpy()
+    st = np.ascontiguousarray(gtd["robot_state_tensor"].numpy().astype(np.float32))
+    orc.integrate(P, st, np.ascontiguousarray(bw))
+    return st
+
+
 def random_state(n, rng, spread=1.0, tilt=0.6):
     m = ref_shells.ref("utils.math")
     s = torch.zeros(n, 13)
@@ -257,7 +273,8 @@ def gen_step(robot_name, robot_cfg, controller_name, ctrl_key, consts, n=64, K=6
     thrust, kT, tinc, tdec = motor_arrays(robot, n, M)
     Kp, Kv, KR, Kw = gains(robot, n)
     rec = {k: [] for k in ("state", "action", "thrust_in", "thrust_out", "euler", "qveh", "vveh", "vbody", "wbody",
-                           "wrench_cmd", "force", "torque", "disturb", "action_after")}
+                           "wrench_cmd", "force", "torque", "disturb", "action_after",
+                           "thrust_out_cr", "wrench_cmd_cr", "wbody_cr", "state_next_cr")}
     mask = torch.tensor(robot_cfg.control_allocator_config.application_mask)
     dist_on = bool(robot_cfg.disturbance.enable_disturbance)
     dmax = torch.tensor(robot_cfg.disturbance.max_force_and_torque_disturbance)
@@ -274,6 +291,19 @@ def gen_step(robot_name, robot_cfg, controller_name, ctrl_key, consts, n=64, K=6
         rec["action"].append(action.clone())
         rec["thrust_in"].append(thrust.clone())
         sd = 1000 + 17 * k
+        if not CR and not JIT:
+            # the same code on the same inputs with correctly rounded elementary functions: the reference's own last-bit
+            # freedom on this sample (cr_torch.py); the motor thrusts (the one piece of state step() mutates) are restored
+            thrust_keep = thrust.clone()
+            with cr_torch.correctly_rounded():
+                torch.manual_seed(sd)
+                robot.step(action.clone())
+            rec["thrust_out_cr"].append(thrust.clone())
+            rec["wrench_cmd_cr"].append(robot.controller.wrench_command.clone() if hasattr(robot.controller, "wrench_command")
+                                        else torch.zeros(n, 6))
+            rec["wbody_cr"].append(robot.robot_body_angvel.clone())
+            rec["state_next_cr"].append(torch.from_numpy(advance_state(gtd, mask, consts, P)))
+            thrust[:] = thrust_keep
         torch.manual_seed(sd)
         robot.step(action.clone())
         # replay the RNG draws made by apply_disturbance (base_multirotor.py:213-234)
@@ -296,15 +326,8 @@ def gen_step(robot_name, robot_cfg, controller_name, ctrl_key, consts, n=64, K=6
         rec["force"].append(gtd["robot_force_tensor"].clone())
         rec["torque"].append(gtd["robot_torque_tensor"].clone())
         # advance the state with the oracle integrator (input generation only)
-        u = gtd["robot_force_tensor"][:, mask, 2].numpy().astype(np.float32)
-        W = consts["wrench_map"].astype(np.float32)
-        bw = link_wrench(u, W)
-        bw[:, 0:3] += gtd["robot_force_tensor"][:, 0, :].numpy()
-        bw[:, 3:6] += gtd["robot_torque_tensor"][:, 0, :].numpy()
-        st = np.ascontiguousarray(gtd["robot_state_tensor"].numpy().astype(np.float32))
-        orc.integrate(P, st, np.ascontiguousarray(bw))
-        gtd["robot_state_tensor"][:] = torch.from_numpy(st)
-    out = {k: torch.stack(v).numpy() for k, v in rec.items()}
+        gtd["robot_state_tensor"][:] = torch.from_numpy(advance_state(gtd, mask, consts, P))
+    out = {k: torch.stack(v).numpy() for k, v in rec.items() if v}
     out.update(kT=kT.numpy(), tau_inc=tinc.numpy(), tau_dec=tdec.numpy(), Kp=Kp.numpy(), Kv=Kv.numpy(),
                KR=KR.numpy(), Kw=Kw.numpy(), disturb_max=dmax.numpy(), application_mask=mask.numpy(),
                params_json=np.array(json.dumps(pd)))

@@ -6,10 +6,15 @@ frame conventions, plus reset_idx; the normal / uniform draws are replayed from 
 import math
 import os
 
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import gen_golden as gg  # noqa: E402  FIRST: it switches TorchScript off before torch is imported (cr_torch.py)
+
 import numpy as np
 import torch
 
-import gen_golden as gg
 import ref_shells
 
 OUT = gg.OUT

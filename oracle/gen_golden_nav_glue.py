@@ -9,12 +9,17 @@ is the reference's: truncations, successes, timeouts, curriculum level / progres
 import os
 import sys
 
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import gen_golden as gg  # noqa: E402  FIRST: it switches TorchScript off before torch is imported (cr_torch.py)
+
 import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import gen_golden as gg  # noqa: E402
 import ref_shells  # noqa: E402
 
 OUT = gg.OUT

@@ -13,11 +13,16 @@ return rl_games logged for it (`last_mean_rewards`).  Weights only -- no referen
 import os
 import sys
 
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import gen_golden as gg  # noqa: E402  FIRST: it switches TorchScript off before torch is imported (cr_torch.py)
+
 import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import gen_golden as gg  # noqa: E402  (the shared output directory: tests/golden, or wherever the provenance test points it)
 
 OUT = gg.OUT
 

@@ -11,12 +11,17 @@ import os
 import sys
 import types
 
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import gen_golden as gg  # noqa: E402  FIRST: it switches TorchScript off before torch is imported (cr_torch.py)
+
 import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-import gen_golden as gg  # noqa: E402  (OUT, shells)
 import ref_shells  # noqa: E402
 
 OUT = gg.OUT

@@ -92,6 +92,23 @@ def elem_err(a, b):
     return float((np.abs(a - b) / np.maximum(1.0, np.abs(b))).max()) if a.size else 0.0
 
 
+def err_where_reference_is_defined(got, ref, ref_cr, gate):
+    """`elem_err(got, ref)` over the elements where the reference's answer is DEFINED to the gate, + what happens elsewhere.
+
+    `ref` is what the reference's code returned on the recorded inputs, `ref_cr` what the same code returns on the same
+    inputs with correctly rounded sin / cos / atan2 / asin / exp / sqrt (oracle/cr_torch.py; recorded next to it by the
+    generator).  Where the two differ by more than half the gate, the reference's result depends on its math library by
+    more than the gate allows (the motor model's sqrt next to zero thrust turns one ulp of a sine into 2e-5 rad/s of body
+    rate): no implementation can be within the gate of both, and `got` must then EQUAL the correctly rounded answer.
+    Returns (worst error over the defined elements, number of undefined elements, all of those bit-equal to ref_cr)."""
+    got, ref, ref_cr = (np.asarray(x, dtype=np.float64) for x in (got, ref, ref_cr))
+    scale = np.maximum(1.0, np.abs(ref))
+    undefined = np.abs(ref - ref_cr) / scale > 0.5 * gate
+    err = np.abs(got - ref) / scale
+    worst = float(err[~undefined].max()) if (~undefined).any() else 0.0
+    return worst, int(undefined.sum()), bool(np.array_equal(got[undefined], ref_cr[undefined]))
+
+
 def max_rel(a, b, floor=0.0):
     """max over components of |a - b| / max(|b|, floor): for small-magnitude quantities (kT ~ 1e-5, thrusts)."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)

@@ -170,6 +170,72 @@ def test_task_api_trace_is_bit_identical_to_the_oracle_loop(orc, tag, controller
         cfg.episode_len_steps = 500
 
 
+@pytest.mark.parametrize("tag,controller", [("position", "lee_position_control"), ("attitude", "lee_attitude_control"),
+                                            ("position_long", "lee_position_control")])
+def test_task_api_trace_is_bit_identical_to_the_reference_with_correctly_rounded_functions(tag, controller):
+    """The 260 / 160 / 1000-step config-1 traces through the Task API against tests/golden/cr/: the reference's own control,
+    reward and reset code evaluated with correctly rounded elementary functions (oracle/cr_torch.py; + the integrator
+    restated from PhysX) -- reward, observation, crash / truncation flags of EVERY step and the state wherever the
+    fixture keeps it, BIT FOR BIT, no oracle in between.  One constant is taken from the fixture: the allocation
+    pseudo-inverse the reference's fp32 torch.linalg.pinv produced on the generating host (the product evaluates it in
+    float64; LAPACK's last bits are host dependent, DESIGN.md "numerics")."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from conftest import TraceReader, golden_params
+    from trace_util import TRACES
+
+    g = load_golden(TRACES[tag][0], cr=True)
+    tr = TraceReader(g)
+    n = g["init_state"].shape[0]
+    rs = ReplaySource(DEV)
+    zeros3 = np.zeros((n, 3), np.float32)
+    for t in ("motor_init_thrust", "motor_init_tau_inc", "motor_init_tau_dec", "motor_init_kT"):
+        rs.push(t, np.zeros((n, 4), np.float32))
+
+    def push_reset(us, ti, td, th, kt):
+        for name, arr in (("bounds_lo", zeros3), ("bounds_hi", zeros3), ("robot_state", us), ("tau_inc", ti), ("tau_dec", td),
+                          ("thrust", th), ("kT", kt)):
+            rs.push(name, arr)
+
+    push_reset(g["init_u_state"], g["init_u_tau_inc"], g["init_u_tau_dec"], g["init_u_thrust"], g["init_u_kT"])
+    cfg.device, cfg.controller_name = DEV, controller
+    cfg.episode_len_steps = int(g["episode_len"])
+    cfg.args = {"strict_rng": True, "random_source": rs}
+    task = task_registry.make_task("position_setpoint_task", seed=1, num_envs=n, headless=True)
+    try:
+        P = task.sim_env._params
+        pinv = golden_params(g)["alloc_pinv"]
+        for j in range(len(pinv)):
+            P.alloc_pinv[j] = pinv[j]
+        task.reset()
+        gd = task.obs_dict
+        assert np.array_equal(gd["robot_state_tensor"].cpu().numpy(), g["init_state"]), "initial reset"
+        n_resets = 0
+        for t in range(tr.T):
+            draws = tr.draws(t)
+            if draws is not None:
+                push_reset(*draws)
+            obs, rew, term, trunc, info = task.step(torch.from_numpy(np.ascontiguousarray(tr.action(t))).to(DEV))
+            checks = [("reward", rew, g["reward"][t])]
+            if tr.kept("obs", t) is not None:
+                checks.append(("obs", obs["observations"], tr.kept("obs", t)))
+            if tr.kept("state_after_step", t) is not None and not g["reset_mask"][t].any():
+                checks.append(("state", gd["robot_state_tensor"], tr.kept("state_after_step", t)))
+            for name, got, ref in checks:
+                got = got.cpu().numpy()
+                if not np.array_equal(got, ref):
+                    bad = np.argwhere(got != ref)
+                    raise AssertionError(f"step {t}: {name} differs in {len(bad)} entries, first {bad[0]}: "
+                                         f"{got[tuple(bad[0])]!r} vs {ref[tuple(bad[0])]!r}; max abs {np.abs(got - ref).max():.3e}")
+            assert np.array_equal(term.cpu().numpy(), g["crashes"][t]) and np.array_equal(trunc.cpu().numpy(), g["truncations"][t]), t
+            n_resets += int(g["reset_mask"][t].sum())
+        assert n_resets >= n and all(len(v) == 0 for v in rs.q.values())
+    finally:
+        cfg.args = {}
+        cfg.episode_len_steps = 500
+
+
 def test_sync_free_mode_runs_and_resets():
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg

@@ -1,8 +1,9 @@
 """GPU: the library-side step exchange (csrc/agx_exchange.hip through sharding.StepGather, backend "rccl_thread") at WORLD
 SIZE 2 on a one-GPU box: two processes, a test double for RCCL (tests/fakerccl) that gathers through shared memory.  These
-tests run last of the GPU tests (file name) and repeat ONCE when the two processes do not finish in time -- printing what
-each rank said -- because two processes rendezvousing through host functions on one shared, possibly loaded GPU box is the
-one place where the test infrastructure itself can stall; a wrong result fails at once."""
+tests run last of the GPU tests (file name).  A run whose two processes do not finish in time FAILS, with what each rank
+said: a hang is exactly what these tests exist to catch.  Only on a box known to be loaded may it be repeated, by opting
+in with AGX_WORLD2_RETRIES=<n> (two processes rendezvousing through host functions on one shared GPU is the one place
+where the test infrastructure itself can stall); a wrong result fails at once either way."""
 import os
 import socket
 import time
@@ -12,23 +13,27 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run_world2(mode, steps, extra_env=None, timeout=420, attempts=2):
+def _run_world2(mode, steps, extra_env=None, timeout=420):
+    attempts = 1 + max(0, int(os.environ.get("AGX_WORLD2_RETRIES", "0")))
     for attempt in range(attempts):
         try:
             return _run_world2_once(mode, steps, extra_env, timeout)
         except TimeoutError as e:
             if attempt + 1 == attempts:
                 raise AssertionError(str(e))
-            print(f"[world-2 exchange] attempt {attempt + 1} did not finish, repeating once:\n{e}", flush=True)
+            print(f"[world-2 exchange] attempt {attempt + 1} did not finish, repeating (AGX_WORLD2_RETRIES):\n{e}", flush=True)
 
 
 def _run_world2_once(mode, steps, extra_env, timeout):
     import subprocess
     import sys
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fakerccl"))
-    import build as fake_build
+    import importlib.util
 
+    spec = importlib.util.spec_from_file_location(
+        "agx_fakerccl_build", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fakerccl", "build.py"))
+    fake_build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fake_build)
     lib = fake_build.build()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -70,6 +70,32 @@ def test_substep_bit_exact(orc, case):
             assert np.array_equal(st, g["state"][k + 1]), (case, k)
 
 
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_substep_on_the_ordinary_fixtures_inputs_bit_exact(orc, case):
+    """tests/golden/step_<case>.npz (the reference as torch evaluates it) also carries what the same code returns on the
+    same recorded inputs with correctly rounded functions (`*_cr`): the oracle reproduces those bit for bit, and the
+    distance between the two recordings is the reference's own last-bit freedom on each sample (reported)."""
+    from conftest import PARITY
+
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    P = orc.make_params(pd)
+    K = g["state"].shape[0]
+    for k in range(K):
+        st, th = g["state"][k].copy(), g["thrust_in"][k].copy()
+        dist = g["disturb"][k] if g["disturb"][k].any() else None
+        o = orc.substep(P, st, g["action"][k], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"],
+                        g["Kw"], disturb=dist, disturb_max=g["disturb_max"], integrate=True)
+        assert np.array_equal(th, g["thrust_out_cr"][k]), (case, k)
+        assert np.array_equal(o.wbody, g["wbody_cr"][k]), (case, k)
+        if "no_control" not in case:
+            assert np.array_equal(o.wrench_cmd, g["wrench_cmd_cr"][k]), (case, k)
+        assert np.array_equal(st, g["state_next_cr"][k]), (case, k)
+        if k + 1 < K:
+            PARITY.record(f"reference_own_libm_spread_next_state[{case}]", np.abs(g["state"][k + 1] - g["state_next_cr"][k]).max(), None, "abs")
+        PARITY.record(f"reference_own_libm_spread_thrust[{case}]", np.abs(g["thrust_out"][k] - g["thrust_out_cr"][k]).max(), None, "abs")
+
+
 def test_rewards_bit_exact(orc):
     g = load_golden("reward_position", cr=True)
     crashes = g["crashes_in"].astype(np.uint8)

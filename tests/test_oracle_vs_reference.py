@@ -275,9 +275,9 @@ def test_goldens_are_reproducible_from_the_reference(tmp_path):
 
 def test_cr_goldens_are_reproducible_and_torchscript_changes_no_bit(tmp_path):
     """tests/golden/cr/ (the reference with correctly rounded elementary functions, oracle/cr_torch.py) is reproduced bit
-    for bit by `gen_golden.py` in CR mode.  CR mode has to switch TorchScript off (PYTORCH_JIT=0) to reach the scripted
-    functions: the ORDINARY fixtures generated with TorchScript off are bit-identical to the committed ones (made with it
-    on), so that switch changes nothing the reference computes."""
+    for bit by `gen_golden.py` in CR mode.  The generators switch TorchScript off (PYTORCH_JIT=0) so that the switchable
+    patch reaches the scripted functions: with TorchScript ON (AGX_GOLDEN_JIT=1) every array of the ordinary fixtures that
+    does not need the patch comes out bit-identical, so the switch changes nothing the reference computes."""
     import os
     import subprocess
     import sys
@@ -288,14 +288,21 @@ def test_cr_goldens_are_reproducible_and_torchscript_changes_no_bit(tmp_path):
         pytest.skip("the reference tree is not on this machine")
     code = ("import sys; sys.path.insert(0, %r)\nimport gen_golden as gg\ngg.OUT = %%r\nimport os; os.makedirs(gg.OUT, exist_ok=True)\n"
             "gg.main()\n" % os.path.join(ROOT, "oracle"))
-    cr_dir, nojit_dir = str(tmp_path / "cr"), str(tmp_path / "nojit")
+    cr_dir, jit_dir = str(tmp_path / "cr"), str(tmp_path / "jit")
     subprocess.run([sys.executable, "-c", code % cr_dir], check=True, capture_output=True, timeout=600,
                    env=dict(os.environ, AGX_GOLDEN_CR="1"))
     made = _compare_fixture_dirs(cr_dir, os.path.join(ROOT, "tests", "golden", "cr"))
     assert len(made) == 16 and sorted(made) == sorted(os.listdir(os.path.join(ROOT, "tests", "golden", "cr")))
-    subprocess.run([sys.executable, "-c", code % nojit_dir], check=True, capture_output=True, timeout=600,
-                   env=dict(os.environ, PYTORCH_JIT="0"))
-    assert len(_compare_fixture_dirs(nojit_dir, os.path.join(ROOT, "tests", "golden"))) >= 18
+    subprocess.run([sys.executable, "-c", code % jit_dir], check=True, capture_output=True, timeout=600,
+                   env=dict(os.environ, AGX_GOLDEN_JIT="1"))
+    n = 0
+    for name in sorted(os.listdir(jit_dir)):
+        new, old = np.load(os.path.join(jit_dir, name)), np.load(os.path.join(ROOT, "tests", "golden", name))
+        assert set(old.files) - set(new.files) <= {"thrust_out_cr", "wrench_cmd_cr", "wbody_cr", "state_next_cr"}, name
+        for k in new.files:
+            assert str(new[k]) == str(old[k]) if new[k].dtype.kind in "US" else np.array_equal(new[k], old[k]), (name, k)
+        n += 1
+    assert n >= 18
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
