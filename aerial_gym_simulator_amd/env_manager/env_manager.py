@@ -197,6 +197,7 @@ class EnvManager(BaseManager):
         imu = self.robot_manager.imu_sensor
         B.body_force = p(imu.body_force) if imu is not None else None
         self._buffers = B
+        self._zero_wrench = None
         self._params = robot.params
         robot._env_binding = self
         robot.controller._env_binding = self
@@ -448,8 +449,10 @@ class EnvManager(BaseManager):
                     if wrench.shape != (self.num_envs, 6):
                         raise ValueError(f"controller returned {tuple(wrench.shape)}, expected ({self.num_envs}, 6): [fx fy fz tx ty tz]")
                     w = wrench.to(dtype=torch.float32).contiguous()
-                else:
-                    w = a
+                else:  # no physics sub-step: the kernel still reads actions_in as [N][6] (the values are unused)
+                    if self._zero_wrench is None:
+                        self._zero_wrench = torch.zeros(self.num_envs, 6, dtype=torch.float32, device=a.device)
+                    w = self._zero_wrench
                 _lib.check(self._lib.agx_env_step(self._params, B, self.num_envs, _lib.dptr(w), min(k, 1), self.task_args, self._stream()),
                            "agx_env_step")
         finally:

@@ -174,15 +174,31 @@ class NavigationTask(BaseTask):
                                                 p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
         self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = self._successes, self._timeouts, self.terminations
 
-    def _bookkeeping_host(self):
+    def _bookkeeping_host(self, in_step=False):
         """the curriculum (navigation_task.py:229-270): the only host synchronisation of the task, every
-        `curriculum_check_every` steps (the level applies from the next step on)"""
+        `curriculum_check_every` steps.  Eager stepping runs it where the reference does -- after this step's bookkeeping and
+        BEFORE post_reward_calculation_step (navigation_task.py:327-331), so that the resets of the check step already see the
+        new level / num_obstacles_in_env (`in_step`).  A step that is being captured into, or replayed from, a hipGraph cannot
+        synchronise in the middle: there the check runs after the step and the level applies from the next step on (a
+        one-step delay of every level change, INTEGRATION.md "known deviations")."""
         if self.sim_env.strict_rng:
             return
-        if (self.num_task_steps - 1) % self.curriculum_check_every == 0:
-            ns, nc, nt = self._counters.tolist()
-            if self._curriculum_decision(ns, nc, nt):
-                self._counters.zero_()
+        if in_step:
+            if self._in_graph_step or self.num_task_steps % self.curriculum_check_every != 0:
+                return
+            self._curriculum_checked_in_step = True
+        else:
+            if self._curriculum_checked_in_step:
+                self._curriculum_checked_in_step = False
+                return
+            if (self.num_task_steps - 1) % self.curriculum_check_every != 0:
+                return
+        ns, nc, nt = self._counters.tolist()
+        if self._curriculum_decision(ns, nc, nt):
+            self._counters.zero_()
+
+    _in_graph_step = False
+    _curriculum_checked_in_step = False
 
     def _reset_targets(self, reset_envs):
         """reset_idx for the envs that were just reset"""
@@ -204,6 +220,7 @@ class NavigationTask(BaseTask):
     # ------------------------------------------------------------------ stepping
     def step(self, actions):
         transformed_action = self.action_transformation_function(actions)
+        self._in_graph_step = bool(self._graph_mode()) or torch.cuda.is_current_stream_capturing()
         if self._graph_mode():
             return self._step_replayed(transformed_action)
         self._flip_host_state()
@@ -228,6 +245,7 @@ class NavigationTask(BaseTask):
         if self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
         self._bookkeeping_device()
+        self._bookkeeping_host(in_step=True)
         reset_envs = env.post_reward_calculation_step()
         self._reset_targets(reset_envs)
         self.process_image_observation()

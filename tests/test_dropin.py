@@ -160,6 +160,116 @@ def test_reference_cleanrl_script_loads_and_wraps_the_task_unmodified(monkeypatc
     assert ppo.get_args().num_envs == 8
 
 
+def test_per_file_config_module_paths_of_the_reference_resolve(monkeypatch):
+    """The reference keeps one file per config class (aerial_gym/config/<group>/<file>.py); examples and user code import
+    from those paths (examples/imu_data_collection.py:8, sim/__init__.py:3-10, task/__init__.py).  The alias package serves
+    them from the one-module-per-group layout of this repo: same class objects, and the class that shares its name with a
+    per-file module stays a class."""
+    monkeypatch.syspath_prepend(ROOT)
+    import importlib
+
+    import aerial_gym  # noqa: F401
+    from aerial_gym.config.sim_config.base_sim_config import BaseSimConfig
+    from aerial_gym.config.sim_config.base_sim_headless_config import BaseSimHeadlessConfig
+    from aerial_gym.config.sim_config.base_sim_no_gravity_config import BaseSimNoGravityConfig  # examples/imu_data_collection.py:8
+    from aerial_gym.config.sim_config.sim_config_2ms import SimCfg2Ms
+    from aerial_gym.config.task_config.navigation_task_config import task_config as nav_cfg
+    from aerial_gym.config.task_config.position_setpoint_task_config import task_config as pos_cfg  # task/__init__.py
+    from aerial_gym.config.controller_config.lee_controller_config import control as lee_cfg
+    from aerial_gym.config.env_config.env_with_obstacles import EnvWithObstaclesCfg
+    from aerial_gym.config.robot_config.base_quad_config import BaseQuadCfg, BaseQuadWithCameraCfg  # noqa: F401
+    from aerial_gym.config.sensor_config.camera_config.base_depth_camera_config import BaseDepthCameraConfig
+    from aerial_gym.config.sensor_config.lidar_config.base_lidar_config import BaseLidarConfig  # noqa: F401
+
+    import aerial_gym_simulator_amd.config.controller_config as cc
+    import aerial_gym_simulator_amd.config.env_config as ec
+    import aerial_gym_simulator_amd.config.sensor_config as sc
+    import aerial_gym_simulator_amd.config.sim_config as simc
+    import aerial_gym_simulator_amd.config.task_config as tc
+    from aerial_gym_simulator_amd.registry.sim_registry import sim_config_registry
+
+    assert BaseSimConfig is simc.BaseSimConfig and BaseSimNoGravityConfig.sim.gravity == [0.0, 0.0, 0.0] and SimCfg2Ms.sim.dt == 0.002
+    assert issubclass(BaseSimHeadlessConfig, BaseSimConfig) and BaseSimNoGravityConfig.sim.dt == BaseSimConfig.sim.dt
+    assert pos_cfg is tc.position_setpoint_task_config and nav_cfg is tc.navigation_task_config and lee_cfg is cc.lee_controller_config
+    assert EnvWithObstaclesCfg is ec.EnvWithObstaclesCfg and BaseDepthCameraConfig is sc.BaseDepthCameraConfig
+    assert isinstance(tc.position_setpoint_task_config, type)  # not replaced by the per-file module of the same name
+    for name in ("base_sim", "base_sim_headless", "base_sim_2ms", "base_sim_4ms"):  # aerial_gym/sim/__init__.py:13-16
+        assert sim_config_registry.get_sim_config(name) is not None
+    with pytest.raises(ImportError):  # a robot this repo does not build: fails loudly, no empty stand-in
+        from aerial_gym.config.robot_config.lmf2_config import LMF2Cfg  # noqa: F401
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("aerial_gym.config.sim_config.not_a_reference_file")
+    # aliasing leaves the implementation modules' identity alone (importlib.reload / pkgutil / inspect keep working)
+    import aerial_gym.utils.math as alias_math
+
+    import aerial_gym_simulator_amd.utils.math as impl_math
+
+    assert alias_math is impl_math and impl_math.__spec__.name == impl_math.__name__ == "aerial_gym_simulator_amd.utils.math"
+    importlib.reload(impl_math)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine")
+def test_reference_sample_factory_wrapper_loads_and_wraps_the_task_unmodified(monkeypatch):
+    """rl_training/sample_factory/aerialgym_examples/train_aerialgym.py:32-70: AerialGymVecEnv reads env.action_space /
+    env.observation_space through sample-factory's convert_space, env.num_envs, and forwards reset() / step() 5-tuples.
+    gymnasium / sample_factory are the trainer's dependencies and are stood in for here."""
+    _stub_trainer_deps(monkeypatch)
+    seen = []
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        monkeypatch.setitem(sys.modules, name, m)
+        return m
+
+    class Env:
+        pass
+
+    class GymnasiumDict:
+        def __init__(self, spaces):
+            self.spaces = spaces
+
+    import aerial_gym_simulator_amd.utils.spaces  # noqa: F401  (binds ITS gym flavour before the stand-in below exists)
+
+    gspaces = mod("gymnasium.spaces", Dict=GymnasiumDict, Box=object)
+    mod("gymnasium", Env=Env, spaces=gspaces)
+
+    def convert_space(space):
+        seen.append(space)
+        return space
+
+    registered = {}
+    mod("sample_factory")
+    mod("sample_factory.algo")
+    mod("sample_factory.algo.utils")
+    mod("sample_factory.algo.utils.context", global_model_factory=lambda: None)
+    mod("sample_factory.model")
+    mod("sample_factory.model.encoder", Encoder=torch.nn.Module, __all__=["Encoder"])  # `from ... import *` (:19, :248)
+    mod("sample_factory.algo.utils.gymnasium_utils", convert_space=convert_space)
+    mod("sample_factory.cfg")
+    mod("sample_factory.cfg.arguments", parse_full_cfg=None, parse_sf_args=None)
+    mod("sample_factory.envs")
+    mod("sample_factory.envs.env_utils", register_env=lambda name, fn: registered.__setitem__(name, fn))
+    mod("sample_factory.train", run_rl=None)
+    mod("sample_factory.utils")
+    mod("sample_factory.utils.typing", Config=dict, Env=Env)
+    mod("sample_factory.utils.utils", str2bool=bool)
+    mod("sample_factory.enjoy", enjoy=None)
+    mod("sample_factory.model.actor_critic", create_actor_critic=None)  # (:335)
+    sf = _load(os.path.join(REF, "rl_training", "sample_factory", "aerialgym_examples", "train_aerialgym.py"), "ref_sf_train", monkeypatch)
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+
+    monkeypatch.setattr(cfg, "device", "cpu")
+    monkeypatch.setattr(cfg, "num_envs", 8)
+    env = sf.make_aerialgym_env("position_setpoint_task", {})
+    assert isinstance(env, sf.AerialGymVecEnv) and env.num_agents == 8
+    assert env.action_space is env.env.action_space and env.action_space.shape == (4,)
+    assert isinstance(env.observation_space, GymnasiumDict) and "observations" in env.observation_space.spaces.keys()
+    assert len(seen) == 2 and env._truncated.shape == (8,)
+
+
 @pytest.mark.gpu
 def test_trainer_wrappers_step_the_task_on_the_gpu(monkeypatch):
     monkeypatch.syspath_prepend(ROOT)
