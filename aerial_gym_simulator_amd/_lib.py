@@ -192,6 +192,7 @@ _SIGNATURES = {
     "agx_abi_version": (C.c_int, []),
     "agx_build_id": (C.c_char_p, []),
     "agx_math_eval": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
+    "agx_copy_f4": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
     "agx_env_step": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.POINTER(AgxTaskArgs), _P]),
     "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),

@@ -119,6 +119,10 @@ AGX_DEV void store_derived(float *__restrict__ d, int n, int i, const Derived &x
   AGX_AT(d, 10) = x.vbody.x; AGX_AT(d, 11) = x.vbody.y; AGX_AT(d, 12) = x.vbody.z;
   AGX_AT(d, 13) = x.wbody.x; AGX_AT(d, 14) = x.wbody.y; AGX_AT(d, 15) = x.wbody.z;
 }
+AGX_DEV void store_body_velocities(float *__restrict__ d, int n, int i, const Derived &x) {
+  AGX_AT(d, 10) = x.vbody.x; AGX_AT(d, 11) = x.vbody.y; AGX_AT(d, 12) = x.vbody.z;
+  AGX_AT(d, 13) = x.wbody.x; AGX_AT(d, 14) = x.wbody.y; AGX_AT(d, 15) = x.wbody.z;
+}
 AGX_DEV Derived load_derived(const float *__restrict__ d, int n, int i) {
   Derived x;
   x.euler = V3{AGX_AT(d, 0), AGX_AT(d, 1), AGX_AT(d, 2)};
@@ -477,6 +481,10 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
   bool reset = false;
   if (i < n) {
     const int A = P.num_actions;
+    // AGX_LAUNCH_LEAN (launch_flags bit 2): the tensors that only exist to be LOOKED AT through the tensor dict are not
+    // maintained -- Euler angles, vehicle-frame quaternion / velocity, robot_actions / robot_prev_actions (40 + 48 of the
+    // 330 bytes an env moves per step); the body-frame velocities stay (the observation kernel reads them)
+    const bool lean = (B.launch_flags & 4) != 0;
     EnvState s = load_state(B.state, n, i);
     float u[M], kT[M], tinc[M], tdec[M];
 #pragma unroll
@@ -495,7 +503,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
       a_in[c] = EXT ? ((c < 6) ? actions_in[(size_t)i * 6 + c] : 0.0f) : ((c < A) ? actions_in[(size_t)i * A + c] : 0.0f);
-      a_old[c] = (c < A) ? AGX_AT(B.actions, c) : 0.0f;
+      a_old[c] = (c < A && !lean) ? AGX_AT(B.actions, c) : 0.0f;
     }
     Derived d{};
     if (k == 0 && T.kind != AGX_TASK_NONE) d = load_derived(B.derived, n, i);
@@ -597,7 +605,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
     if (B.boxes && k > 0) crashed = collide_trajectory(B.boxes, B.num_boxes, n, i, traj, k, bd, tid, tlo, thi, P.collision_radius) || crashed;
     store_state(B.state, n, i, s);
     if (k > 0) {
-      store_derived(B.derived, n, i, d);
+      if (lean) store_body_velocities(B.derived, n, i, d);
+      else store_derived(B.derived, n, i, d);
 #pragma unroll
       for (int j = 0; j < M; ++j) AGX_AT(B.motor_thrust, j) = u[j];
       if (B.wrench_cmd) {
@@ -610,8 +619,8 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
       a_cur[c] = (k > 0 && !EXT) ? a_in[c] : a_old[c];
-      a_prev[c] = (k >= 2 && !EXT) ? a_in[c] : ((k == 1 && !EXT) ? a_old[c] : ((c < A) ? AGX_AT(B.prev_actions, c) : 0.0f));
-      if (c < A && k > 0 && !EXT) {
+      a_prev[c] = (k >= 2 && !EXT) ? a_in[c] : ((k == 1 && !EXT) ? a_old[c] : ((c < A && !lean) ? AGX_AT(B.prev_actions, c) : 0.0f));
+      if (c < A && k > 0 && !EXT && !lean) {
         AGX_AT(B.prev_actions, c) = a_prev[c];
         AGX_AT(B.actions, c) = a_cur[c];
       }
@@ -1559,7 +1568,7 @@ AGX_DEV void reset_and_observe(const AgxRobotParams &P, const AgxEnvBuffers &B, 
     EnvState s2 = mine ? reset_env<M>(P, B, n, R, i, ep, D) : s;
     // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
     Derived d2 = update_states(s2);
-    store_derived(B.derived, n, i, d2);
+    if ((B.launch_flags & 4) == 0) store_derived(B.derived, n, i, d2);  // lean: nobody reads them before the next env step rewrites them
     if (WITH_OBS) write_obs_position(B, n, i, tgt, obs, s2, d2);
   }
 }
@@ -1793,7 +1802,10 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   AGX_REQUIRE(k >= 0 && k <= AGX_MAX_SUBSTEPS, "k_substeps out of range: %d", k);
   AGX_REQUIRE(P->controller != AGX_CTRL_WRENCH || k <= 1,
               "external controller (AGX_CTRL_WRENCH): one launch per physics sub-step, the host re-evaluates the controller in between");
-  AGX_REQUIRE((B->launch_flags & ~0xFF03) == 0, "launch_flags: bits 0, 1 and the sub-step index in bits 8-15");
+  AGX_REQUIRE((B->launch_flags & ~0xFF07) == 0, "launch_flags: bits 0, 1, 2 and the sub-step index in bits 8-15");
+  AGX_REQUIRE((B->launch_flags & 4) == 0 || ((B->launch_flags & 3) == 0 && P->controller != AGX_CTRL_WRENCH &&
+                                             (!task || task->kind != AGX_TASK_NAVIGATION)),
+              "AGX_LAUNCH_LEAN needs the fused step of a built-in controller without the navigation reward (it reads the action history)");
   AGX_REQUIRE(B->state && B->derived && B->actions && B->prev_actions && B->motor_thrust && B->crashes && B->truncations &&
                   B->sim_steps,
               "null env buffer");

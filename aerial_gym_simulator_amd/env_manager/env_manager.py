@@ -20,7 +20,7 @@ from ..registry.env_registry import env_config_registry
 from ..registry.robot_registry import robot_registry
 from ..registry.sim_registry import sim_config_registry
 from ..robots.robot_manager import RobotManagerHIP
-from ..tensors import aos_view, soa
+from ..tensors import aos_view, soa, TensorDict
 from ..utils.logging import CustomLogger
 from ..utils.random_source import TorchRandomSource
 from .asset_manager import AssetManager
@@ -79,7 +79,7 @@ class EnvManager(BaseManager):
         self._parity = 0
         self.task_args = None   # AgxTaskArgs: reward / flags fused into the env-step launch
         self.post_obs = None    # (target_ptr, obs_ptr): observation fused into the reset launch
-        self.global_tensor_dict = {}
+        self.global_tensor_dict = TensorDict()
         self.keep_in_env = None
         self.step_counter = 0
         self._stream_cache = None
@@ -204,6 +204,8 @@ class EnvManager(BaseManager):
         self._make_reset_args()
         self._disturb_buf = None
         self._reward_fresh = self._obs_fresh = self._mask_fresh = False
+        if self.env_args.get("lean_step") and self.num_envs >= self.LEAN_MIN_ENVS and self._params.controller != 8:  # 8: external
+            self._enable_lean_step()
 
     def _make_reset_args(self):
         N, dev = self.num_envs, self.device
@@ -274,6 +276,36 @@ class EnvManager(BaseManager):
 
     def _new_call(self):
         self._stream_cache = None
+        self._derived_stale = True
+
+    # ---- lean step (args={"lean_step": True}): AGX_LAUNCH_LEAN for batches far above 65 536 envs, where bytes matter ------
+    LEAN_MIN_ENVS = 65537
+    _lean = False
+    _derived_stale = False
+
+    def _enable_lean_step(self):
+        """The fused step stops maintaining the tensors that exist only to be looked at through the dict (Euler angles, vehicle
+        quaternion / velocity, robot_actions, robot_prev_actions: 88 of the ~330 bytes an env moves per step).  Reading a
+        derived key recomputes all of them from the CURRENT state (agx_update_states) -- fresh values, where the eagerly
+        maintained ones are one sub-step stale like the reference's (SURVEY appendix A #1); the action history is refused."""
+        g = self.global_tensor_dict
+        self._lean = True
+        self._buffers.launch_flags = 4
+
+        def refresh(_key):
+            if self._derived_stale and self._lean:
+                self._derived_stale = False
+                self.update_states()
+
+        def refuse(key):
+            if self._lean:
+                raise RuntimeError(f"'{key}' is not maintained by the lean step (args={{'lean_step': True}}); the task keeps the action "
+                                   "tensors it was handed (task.actions / task.prev_actions)")
+
+        for key in ("robot_euler_angles", "robot_vehicle_orientation", "robot_vehicle_linvel", "robot_body_linvel", "robot_body_angvel"):
+            g.on_read(key, refresh)
+        for key in ("robot_actions", "robot_prev_actions"):
+            g.on_read(key, refuse)
 
     def _require_device(self):
         if self._buffers is None:

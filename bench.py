@@ -53,7 +53,10 @@ def parse():
     return args
 
 
-def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all"):
+LEAN_AT_SCALE_ENVS = (1 << 21) + 256  # its own grid size: the PMC file keys kernels by name + grid, and the lean launch is the same kernel
+
+
+def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", lean=False):
     """obstacles: "all" = every obstacle of the scene is in the env (BASELINE configs 3/4: 100 boxes + 6 walls);
     "curriculum" = the task's own curriculum start (navigation_task_config.py: level 15 of 106)."""
     import aerial_gym_simulator_amd  # noqa: F401
@@ -64,7 +67,7 @@ def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all"):
         cfg = position_setpoint_task_config
         cfg.controller_name = "lee_position_control"
         cfg.device = device
-        cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
+        cfg.args = {"strict_rng": strict_rng, "shard_rank": rank, "lean_step": bool(lean)}
         return task_registry.make_task("position_setpoint_task", seed=1 + rank, num_envs=num_envs, headless=True)
     if workload == "lidar_nav":  # the reference's LiDAR-navigation recipe (magpie, 48 x 120 dome LiDAR, 337-D obs)
         from aerial_gym_simulator_amd.config.task_config import lidar_navigation_task_config as lcfg
@@ -132,18 +135,27 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=Tr
 
 
 def hbm_copy_gbs(device, nbytes=1 << 30, reps=10):
-    """Measured HBM bandwidth of a device-to-device copy (read + write bytes / time) on this box:
-    the achievable ceiling next to the 8 TB/s vendor peak."""
+    """Measured HBM bandwidth of a float4 streaming copy (read + write bytes / time; the library's own HIP kernel,
+    agx_copy_f4) on this box: the achievable ceiling next to the 8 TB/s of specification (MI355X_MICROARCH.md: 6.29 TB/s)."""
+    import ctypes as C
+
+    from aerial_gym_simulator_amd import _lib
+
+    lib = _lib.load()
     a = torch.empty(nbytes // 4, device=device)
     b = torch.empty_like(a)
-    b.copy_(a)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(reps):
-        b.copy_(a)
-    stop.record()
-    torch.cuda.synchronize()
-    return 2.0 * nbytes * reps / (start.elapsed_time(stop) * 1e-3) / 1e9
+    best = 0.0
+    for _ in range(3):
+        _lib.check(lib.agx_copy_f4(_lib.dptr(a), _lib.dptr(b), nbytes, stream), "agx_copy_f4")
+        start.record()
+        for _ in range(reps):
+            lib.agx_copy_f4(_lib.dptr(a), _lib.dptr(b), nbytes, stream)
+        stop.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * nbytes * reps / (start.elapsed_time(stop) * 1e-3) / 1e9)
+    return best
 
 
 _PMC = None
@@ -177,25 +189,63 @@ def pmc_stale():
     return bool(_pmc().get("_stale", True))
 
 
+VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2.0  # MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32, 1024 SIMDs, 2.4 GHz: 1.229 T/s
+
+
 def valu_peak():
-    """Plain (non-packed) fp32 VALU issue ceiling in wave64 instructions/s: measured on an MI355X by
-    profiles/src/valu_peak.hip (profiles/r02_valu_peak.json); fallback = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles."""
-    try:
-        return float(json.load(open(os.path.join(ROOT, "profiles", "r02_valu_peak.json")))["wave_instr_per_s"]), "measured (profiles/r02_valu_peak.json)"
-    except Exception:  # noqa: BLE001
-        return 256 * 4 * 2.4e9 / 4.0, "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"
+    """Plain (non-packed) fp32 VALU issue ceiling in wave64 instructions/s, two readings:
+    * measured on an MI355X by profiles/src/valu_peak.hip (profiles/r03_valu_peak.json: 16 independent chains per wave, scalar /
+      inline-constant second and third operands, 8 waves per SIMD) -- what the chip sustains under its power budget (the
+      effective clock of that run, GRBM_GUI_ACTIVE / wall, is recorded next to it);
+    * the hardware guide's 2 cycles per wave64 instruction per SIMD at the 2.4 GHz maximum clock: 1.229 T/s."""
+    for name in ("r03_valu_peak.json", "r02_valu_peak.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return float(d["wave_instr_per_s"]), f"measured (profiles/{name})", d.get("effective_clock_ghz")
+        except Exception:  # noqa: BLE001
+            continue
+    return VALU_PEAK_GUIDE, "guide: 2 cycles per wave64 instruction per SIMD at 2.4 GHz", None
 
 
 def valu_roofline(kernel_key, launch_s):
-    """`bound: "valu"`: vector instructions the kernel issues per launch (SQ_INSTS_VALU, committed PMC pass) over the
-    launch duration measured live, against the VALU issue ceiling."""
+    """Vector instructions the kernel issues per launch (SQ_INSTS_VALU, committed PMC pass) over the launch duration
+    measured live, against both VALU issue ceilings."""
     n_valu = _pmc().get("valu_wave_instructions", {}).get(kernel_key)
+    peak, how, clk = valu_peak()
+    out = {"unit": "G wave64-instr/s", "peak_measured": peak / 1e9, "peak_measured_source": how, "peak_measured_effective_clock_ghz": clk,
+           "peak_guide": VALU_PEAK_GUIDE / 1e9, "peak_guide_source": "MI355X_MICROARCH.md: 2 cycles per wave64 v_fma_f32 per SIMD-32, 1024 SIMDs, 2.4 GHz"}
     if n_valu is None:
-        return None
-    peak, how = valu_peak()
+        return dict(out, achieved=None, frac_of_measured=None, frac_of_guide=None)
     ach = n_valu / launch_s
-    return {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave64-instr/s", "frac": ach / peak,
-            "valu_wave_instructions_per_launch": n_valu, "peak_source": how, "stale": pmc_stale()}
+    return dict(out, achieved=ach / 1e9, frac_of_measured=ach / peak, frac_of_guide=ach / VALU_PEAK_GUIDE,
+                valu_wave_instructions_per_launch=n_valu, stale=pmc_stale())
+
+
+def roofline_block(kernel, launch_s, algorithmic_bytes, key, copy_gbs=None, timing=None, note=None, **extra):
+    """The contract's `roofline` object for one kernel: bound "hbm" -- achieved = algorithmic bytes per launch / average launch
+    duration measured live with HIP events on the launch stream, peak = 8 TB/s (specification), traffic = HBM bytes per launch
+    from the committed PMC passes -- with the achievable copy rate of this box and the kernel's vector-instruction issue rate
+    against both VALU ceilings next to it (`valu`): none of these kernels is HBM bound, and that object says what bounds them."""
+    ach = algorithmic_bytes / launch_s / 1e9
+    tr = pmc_traffic(key)
+    blk = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr,
+           "traffic_stale": pmc_stale(), "kernel": kernel, "launch_us": launch_s * 1e6,
+           "algorithmic_bytes_per_launch": algorithmic_bytes}
+    if tr:
+        blk["traffic_over_algorithmic"] = tr / algorithmic_bytes
+        blk["traffic_rate_gbs"] = tr / launch_s / 1e9
+    if copy_gbs:
+        blk["peak_measured_copy"] = copy_gbs
+        blk["frac_of_measured_copy"] = ach / copy_gbs
+        if tr:
+            blk["traffic_rate_over_measured_copy"] = blk["traffic_rate_gbs"] / copy_gbs
+    if timing:
+        blk["launch_us_detail"] = {k: (v * 1e6 if isinstance(v, float) else v) for k, v in timing.items()}
+    blk["valu"] = valu_roofline(key, launch_s)
+    if note:
+        blk["note"] = note
+    blk.update(extra)
+    return blk
 
 
 def env_step_key(task, k):
@@ -279,9 +329,17 @@ def live_parity(device):
 
 
 def kernel_time_dynamics(task, actions, reps=400):
-    """Average duration of one agx_dynamics_substeps launch, HIP events on torch's current
-    stream (the stream the kernel is launched on).  The queue is pre-filled behind a long
-    blocker kernel so the launches run back-to-back and host launch latency is excluded."""
+    """Duration of the env-step kernel, HIP events on the stream it is launched on, three ways (all reported; rocprofv3's
+    per-kernel average over the same command lies between the first two, profiles/r03_*_kernel_stats.csv):
+
+    * `in_step`  -- the launch bracketed by two events INSIDE real task steps (env-step launch, then the reset / observation
+      launch, exactly the sequence of the timed region), the queue pre-filled behind a blocker so that the host is out of
+      the picture: from the completion of the preceding kernel to the completion of this one.  This is the figure the
+      roofline is priced with: it is what the kernel costs the step.
+    * `back_to_back` -- the same launch repeated `reps` times in a row, total / reps (round 2's figure: it depends on how
+      well consecutive dispatches of the SAME kernel overlap, and did not reproduce between runs).
+    * `isolated` -- one launch on an idle device between two events (cold L2, dispatch latency in full).
+    `event_pair` is what two events with nothing in between measure (their own cost)."""
     from aerial_gym_simulator_amd import _lib
 
     env = task.sim_env
@@ -290,6 +348,7 @@ def kernel_time_dynamics(task, actions, reps=400):
     lib, P, B, n, ptr = env._lib, env._params, env._buffers, env.num_envs, _lib.dptr(a)
     blocker = torch.randn(4096, 4096, device=a.device)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {}
     best = None
     for _ in range(3):
         torch.cuda.synchronize()
@@ -303,7 +362,61 @@ def kernel_time_dynamics(task, actions, reps=400):
         torch.cuda.synchronize()
         ms = start.elapsed_time(stop) / reps
         best = ms if best is None else min(best, ms)
-    return best * 1e-3, k
+    out["back_to_back"] = best * 1e-3
+    # isolated launches and the cost of an event pair
+    iso, pair = [], []
+    for _ in range(40):
+        torch.cuda.synchronize()
+        start.record()
+        lib.agx_env_step(P, B, n, ptr, k, env.task_args, env._stream())
+        stop.record()
+        torch.cuda.synchronize()
+        iso.append(start.elapsed_time(stop))
+        start.record()
+        stop.record()
+        torch.cuda.synchronize()
+        pair.append(start.elapsed_time(stop))
+    iso.sort(), pair.sort()
+    out["isolated"] = iso[len(iso) // 2] * 1e-3
+    out["event_pair"] = pair[len(pair) // 2] * 1e-3
+    # inside real steps: the general (two host calls) path of task.step() issues the same two launches as the fast path;
+    # its env-step call is wrapped so that every launch sits between two events
+    m = min(reps, 300)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
+    real_env_step = lib.agx_env_step
+    idx = [0]
+
+    class _Timed:
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def agx_env_step(self, *args):
+            e0, e1 = evs[idx[0]]
+            e0.record()
+            rc = real_env_step(*args)
+            e1.record()
+            idx[0] += 1
+            return rc
+
+    plan, task._plan = getattr(task, "_plan", None), None  # general path: env.step + reward + post_reward_calculation_step
+    env._lib = _Timed()
+    try:
+        torch.cuda.synchronize()
+        for _ in range(6):
+            blocker @ blocker
+        for i in range(m):
+            task.step(actions[i % len(actions)])
+        torch.cuda.synchronize()
+    finally:
+        env._lib = lib
+        task._plan = plan
+    d = sorted(e0.elapsed_time(e1) for e0, e1 in evs[: idx[0]])
+    if d:
+        out["in_step"] = sum(d) / len(d) * 1e-3
+        out["in_step_min"], out["in_step_median"], out["in_step_max"] = d[0] * 1e-3, d[len(d) // 2] * 1e-3, d[-1] * 1e-3
+        out["in_step_samples"] = len(d)
+    out["primary"] = out.get("in_step", out["back_to_back"])
+    return out, k
 
 
 def kernel_time_raycast(task, reps=20):
@@ -610,39 +723,25 @@ def main():
             "rng": "strict (reference torch stream, host sync/step)" if args.strict_rng else "sync-free (device Philox4x32-10)",
         },
     }
+    copy_gbs = hbm_copy_gbs(device) if rank == 0 else None
     if rank == 0 and args.workload == "dynamics":
-        kt, k = kernel_time_dynamics(task, actions)
-        achieved = BYTES_DYNAMICS_KERNEL * k * N / kt / 1e9
+        timing, k = kernel_time_dynamics(task, actions)
         ekey = env_step_key(task, k)
-        vr = valu_roofline(ekey, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9,
-                                         "unit": "G wave64-instr/s", "frac": None}
-        out["roofline"] = dict(vr, **{
-            "kernel": ekey.rsplit("_", 1)[0] + " (sub-step(s) + reward epilogue)",
-            "launch_us": kt * 1e6,
-            "traffic": pmc_traffic(ekey),
-            "traffic_stale": pmc_stale(),
-            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k * N, "peak_measured_copy": hbm_copy_gbs(device)},
-            "note": "8192 envs = 128 one-wave workgroups on 256 CUs (1 wave on 1 of every 8 SIMDs), 1.3 MB per launch: neither the vector "
-                    "ALUs nor HBM can be filled, the launch is latency bound; roofline_at_scale prices the same kernel at 2^21 envs",
-        })
+        out["roofline"] = roofline_block(
+            ekey.rsplit("_", 1)[0] + " (sub-step(s) + reward epilogue)", timing["primary"], BYTES_DYNAMICS_KERNEL * k * N, ekey, copy_gbs, timing,
+            note="8192 envs = 512 one-wave workgroups on 1024 SIMDs, 1.3 MB per launch: neither HBM nor the vector ALUs can be filled, the "
+                 "launch is latency bound (one wave's instruction stream + two memory round trips); roofline_at_scale prices the "
+                 "one-lane-per-env kernel at 2^21 envs")
     if exchange is not None:
         exchange["communicator_ranks"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
         out["exchange"] = exchange
     if rank == 0 and args.workload != "dynamics":
         kt = kernel_time_raycast(task)
-        per_env = raycast_bytes_per_env(task)
-        achieved = per_env * N / kt / 1e9
         cfgs = task.sim_env.robot_manager.warp_sensor.cfg
-        key = raycast_key(task)
-        vr = valu_roofline(key, kt) or {"bound": "valu", "achieved": None, "peak": valu_peak()[0] / 1e9, "unit": "G wave64-instr/s", "frac": None}
-        out["roofline"] = dict(vr, **{
-            "kernel": "k_raycast (one frame, all envs)", "launch_us": kt * 1e6, "traffic": pmc_traffic(key), "traffic_stale": pmc_stale(),
-            "rays_per_s": N * cfgs.num_sensors * cfgs.height * cfgs.width / kt,
-            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": per_env * N},
-            "note": "packet traversal is bound by vector-instruction issue, not by HBM: the scene (127 KB/env) is read once per frame",
-        })
+        out["roofline"] = roofline_block(
+            "k_raycast (one frame, all envs)", kt, raycast_bytes_per_env(task) * N, raycast_key(task), copy_gbs,
+            note="packet traversal is bound by vector-instruction issue, not by HBM: the scene (127 KB/env) is read once per frame",
+            rays_per_s=N * cfgs.num_sensors * cfgs.height * cfgs.width / kt)
     if rank == 0 and args.workload == "dynamics" and world == 1:
         # same kernel where the roofline is meaningful (N = 2^21 envs, 319 MB per launch)
         try:
@@ -652,25 +751,31 @@ def main():
             ab = [torch.rand(1 << 21, A, device=device, generator=gb) * 2 - 1]
             for _ in range(3):
                 big.step(ab[0])
-            kt2, k2 = kernel_time_dynamics(big, ab, reps=30)
-            ach2 = BYTES_DYNAMICS_KERNEL * k2 * (1 << 21) / kt2 / 1e9
+            timing2, k2 = kernel_time_dynamics(big, ab, reps=30)
             ekey2 = env_step_key(big, k2)
-            vr2 = valu_roofline(ekey2, kt2) or {"bound": "valu", "frac": None}
-            tr2 = pmc_traffic(ekey2)
-            copy_gbs = (out.get("roofline", {}).get("hbm", {}) or {}).get("peak_measured_copy")
-            hbm2 = {"achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": BYTES_DYNAMICS_KERNEL * k2 * (1 << 21)}
-            if tr2:
-                hbm2["traffic_rate"] = tr2 / kt2 / 1e9  # the bytes the counters saw, per second
-                hbm2["traffic_over_algorithmic"] = tr2 / hbm2["algorithmic_bytes_per_launch"]
-                if copy_gbs:
-                    hbm2["traffic_rate_over_measured_copy"] = hbm2["traffic_rate"] / copy_gbs
-            out["roofline_at_scale"] = dict(vr2, **{
-                "num_envs": 1 << 21, "launch_us": kt2 * 1e6, "env_steps_per_s_kernel_only": (1 << 21) / kt2,
-                "traffic": tr2, "traffic_stale": pmc_stale(), "hbm": hbm2,
-                "note": "vector issue is at ~0.6 of its ceiling and the launch's REAL traffic (2.2x the algorithmic bytes: the derived "
-                        "tensors, actions / prev_actions and per-env parameters the tensor-dict API exposes) moves at about the rate a "
-                        "device-to-device copy reaches on this box: at scale the kernel sits on both limits; the lever is the traffic ratio"})
+            out["roofline_at_scale"] = roofline_block(
+                ekey2.rsplit("_", 1)[0], timing2["primary"], BYTES_DYNAMICS_KERNEL * k2 * (1 << 21), ekey2, copy_gbs, timing2,
+                note="at scale the kernel is limited by vector-instruction issue and by the HBM traffic it really moves (`traffic`: the "
+                     "derived tensors, actions / prev_actions and per-env parameters the tensor-dict API exposes, on top of the "
+                     "algorithmic bytes)",
+                num_envs=1 << 21, env_steps_per_s_kernel_only=(1 << 21) / timing2["primary"])
+            del big
+            torch.cuda.empty_cache()
+            # the same kernel with AGX_LAUNCH_LEAN (args={"lean_step": True}): the tensors that exist only to be looked at through
+            # the dict are not stored every step (recomputed when a key is read)
+            nl = LEAN_AT_SCALE_ENVS
+            big = make_task("dynamics", nl, device, False, lean=True)
+            big.reset()
+            ab = [torch.rand(nl, A, device=device, generator=gb) * 2 - 1]
+            for _ in range(3):
+                big.step(ab[0])
+            timing3, k3 = kernel_time_dynamics(big, ab, reps=30)
+            ekey3 = env_step_key(big, k3)
+            out["roofline_at_scale_lean"] = roofline_block(
+                ekey3.rsplit("_", 1)[0] + " with AGX_LAUNCH_LEAN", timing3["primary"], BYTES_DYNAMICS_KERNEL * k3 * nl, ekey3, copy_gbs, timing3,
+                num_envs=nl, env_steps_per_s_kernel_only=nl / timing3["primary"],
+                note="opt-in (args={'lean_step': True}, > 65 536 envs): same kernel, same results; Euler angles / vehicle-frame tensors / "
+                     "action history are not maintained per step (88 of the ~330 B an env moves)")
             del big
         except Exception as e:  # noqa: BLE001
             out["roofline_at_scale"] = {"error": str(e)}
@@ -715,10 +820,7 @@ def main():
             per_env = raycast_bytes_per_env(t2)
             out["plus_depth"].update({
                 "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                "raycast_roofline": dict(valu_roofline(raycast_key(t2), kt2) or {"bound": "valu", "frac": None}, **{
-                    "traffic": pmc_traffic(raycast_key(t2)), "traffic_stale": pmc_stale(),
-                    "hbm": {"achieved": per_env * N / kt2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": per_env * N / kt2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": per_env * N}})})
+                "raycast_roofline": roofline_block("k_raycast (one frame, all envs)", kt2, per_env * N, raycast_key(t2), copy_gbs)})
             if not args.no_cpu_baseline:
                 out["plus_depth"]["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
                 out["plus_depth"]["gpu_frames_per_s_kernel"] = N / kt2

@@ -165,7 +165,13 @@ typedef struct AgxEnvBuffers {
   int32_t launch_flags;  /* 0 for the fused step.  An env step split over several agx_env_step launches (AGX_CTRL_WRENCH:
                             one per physics sub-step): bit 0 = not the first launch (crash flags accumulate, env_manager.py:
                             426-428), bit 1 = not the last launch (no sim_steps += 1, truncation or task epilogue yet),
-                            bits 8-15 = index of the first physics sub-step of this launch (disturbance draws / rows).     */
+                            bits 8-15 = index of the first physics sub-step of this launch (disturbance draws / rows).
+                            bit 2 (AGX_LAUNCH_LEAN, fused step of a built-in controller, no navigation reward) = the tensors
+                            that exist only to be looked at through the tensor dict are not maintained: derived[0..9]
+                            (Euler angles, vehicle quaternion, vehicle-frame velocity), actions, prev_actions -- 88 of the
+                            ~330 bytes an env moves per step; agx_update_states recomputes the derived tensors from the
+                            current state on demand (the host mirror does that when a dict key is read).  The one-lane
+                            kernels implement it (it is meant for batches far above 65 536 envs, where bytes matter).      */
 } AgxEnvBuffers;
 
 const char *agx_last_error(void);
@@ -224,6 +230,10 @@ int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
  * entry: the parity tests compare it bit for bit with the CPU restatement.                                          */
 enum { AGX_MATH_SIN = 0, AGX_MATH_COS = 1, AGX_MATH_ATAN2 = 2, AGX_MATH_ASIN = 3, AGX_MATH_EXP = 4 };
 int agx_math_eval(int which, int n, const float *x, const float *y, float *out, void *stream);
+
+/* Diagnostic: float4 streaming copy of `bytes` (multiple of 16) from src to dst -- the HBM rate a kernel of this library
+ * reaches on the device at hand (bench.py's "achievable" HBM line next to the 8 TB/s of specification).            */
+int agx_copy_f4(const void *src, void *dst, size_t bytes, void *stream);
 
 /* Controller plug-in entry: BaseLeeController subclasses' update(), returning the wrench
  * [6][N] into buf->wrench_cmd (control/controllers/ *.py).  Uses buf->state/derived as is.

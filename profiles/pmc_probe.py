@@ -27,6 +27,14 @@ for n in (8192, 1 << 21):
         env.update_states()
     torch.cuda.synchronize()
     del task
+# the lean launch of the same kernel (its own env count: the counters are keyed by kernel name + grid size)
+task = bench.make_task("dynamics", bench.LEAN_AT_SCALE_ENVS, dev, False, lean=True)
+task.reset()
+a = torch.rand(bench.LEAN_AT_SCALE_ENVS, 4, device=dev) * 2 - 1
+for _ in range(5):
+    task.step(a)
+torch.cuda.synchronize()
+del task
 if "--nav" in sys.argv:
     t = bench.make_task("depth", 8192, dev, False)
     t.reset()
@@ -42,3 +50,7 @@ if "--nav" in sys.argv:
         t.step(a)
     torch.cuda.synchronize()
 print("pmc probe done")
+from aerial_gym_simulator_amd import _lib  # noqa: E402
+
+with open(os.environ.get("AGX_BUILD_ID_OUT", os.path.join(ROOT, "gpurun_out", "pmc_build_id.txt")), "w") as f:
+    f.write(_lib.build_id())  # which binary the counters belong to (collect_pmc.py stamps pmc_traffic.json with it)

@@ -1,67 +1,85 @@
-// Measured VALU issue ceiling of this GPU for plain (non-packed) fp32 vector instructions, in wave64
-// instructions per second: the roofline the ray-cast and env-step kernels are priced against (bench.py
-// `roofline.bound = "valu"`).  Build + run on the GPU box:
+// Measured VALU issue ceiling of this GPU for plain (non-packed) fp32 vector instructions, in wave64 instructions per
+// second: what the env-step and ray-cast kernels' SQ_INSTS_VALU rates are compared with (bench.py `roofline.valu`), next to
+// the hardware guide's 2 cycles per wave64 v_fma_f32 per SIMD-32 at 2.4 GHz (1.229 T/s).
+//
+// Round 3: 16 INDEPENDENT chains per wave (a dependent v_fma chain issues every ~4 cycles, so 8
+// chains at 2 cycles per instruction were exactly on the edge), the second and third operands a scalar register / an
+// inline constant (one VGPR read port per instruction instead of three), long launches (~25 ms).  Every launch prints
+// its wall time; run once more under `rocprofv3 --pmc GRBM_GUI_ACTIVE` and profiles/collect_valu_peak.py divides that
+// counter by the wall time: the EFFECTIVE clock of the launch (the chip clocks to its power budget).
 //   hipcc --offload-arch=gfx950 -O3 profiles/src/valu_peak.hip -o gpurun_out/valu_peak && gpurun_out/valu_peak
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 
+#define CHAINS16(OP)                                                                                                       \
+  OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
+
 template <int KIND>
-__global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a, float b) {
-  float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
-  for (int i = 0; i < iters; ++i) {
-    if (KIND == 0) {
-      asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
-                   "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
-                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
-                   : "v"(a), "v"(b));
-    } else if (KIND == 1) {
-      asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n"
-                   "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9\n"
-                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
-                   : "v"(a), "v"(b));
-    } else {
-      asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cmp_lt_f32 vcc, %1, %9\n v_cndmask_b32 %2, %2, %8, vcc\n v_cmp_gt_f32 vcc, %3, %9\n"
-                   "v_cndmask_b32 %4, %4, %8, vcc\n v_cmp_lt_f32 vcc, %5, %9\n v_cndmask_b32 %6, %6, %8, vcc\n v_cmp_gt_f32 vcc, %7, %9\n"
-                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
-                   : "v"(a), "v"(b)
-                   : "vcc");
+__global__ void __launch_bounds__(256) k_valu(float *out, int iters, float a) {
+  float x[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) x[c] = (float)threadIdx.x + (float)c;
+#pragma unroll 4
+  for (int i = 0; i < iters; ++i) {  // 64 vector instructions per scalar loop-control triple
+    if (KIND == 0) {  // v_fma_f32 v, v, s, 0.5
+#define OP(c) asm volatile("v_fma_f32 %0, %0, %1, 0.5" : "+v"(x[c]) : "s"(a));
+      CHAINS16(OP)
+#undef OP
+    } else if (KIND == 1) {  // VOP2 mix: v_mul_f32 v, s, v / v_add_f32 v, 1.0, v / v_max_f32 v, s, v / v_min_f32 v, s, v
+#define OP(c)                                                                                               \
+  if ((c & 3) == 0) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a));                              \
+  else if ((c & 3) == 1) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x[c]));                                 \
+  else if ((c & 3) == 2) asm volatile("v_max_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a));                         \
+  else asm volatile("v_min_f32 %0, %1, %0" : "+v"(x[c]) : "s"(a));
+      CHAINS16(OP)
+#undef OP
+    } else {  // three VGPR sources (round 2's probe): v_fma_f32 v, v, v, v
+#define OP(c) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(x[(c + 1) & 15]), "v"(x[(c + 2) & 15]));
+      CHAINS16(OP)
+#undef OP
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) s += x[c];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
 template <int KIND>
-static double run(const char *name, int waves_per_simd) {
+static void run(const char *name, int waves_per_simd, int &launch_index) {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
-  const int cus = p.multiProcessorCount, iters = 20000;
+  const int cus = p.multiProcessorCount;
   const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+  const int iters = 400000 / waves_per_simd;  // ~equal wall time per launch (tens of ms)
   float *out;
   hipMalloc(&out, (size_t)blocks * 256 * 4);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0001f, 0.5f);
+  hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, out, 1000, 1.0001f);  // warm-up (dispatch launch_index)
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0001f, 0.5f);
+  hipLaunchKernelGGL(k_valu<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0001f);  // timed (dispatch launch_index + 1)
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  const double winst = (double)blocks * 4 * iters * 8;
+  const double winst = (double)blocks * 4 * iters * 16;
   const double rate = winst / (ms * 1e-3);
-  const double per_simd_clk = rate / ((double)cus * 4 * p.clockRate * 1e3);
-  printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"cus\": %d, \"clock_khz\": %d, \"wave_instr_per_s\": %.4e, \"cycles_per_wave_instr\": %.3f}\n",
-         name, waves_per_simd, cus, p.clockRate, rate, 1.0 / per_simd_clk);
+  const double cyc_at_max = ((double)cus * 4 * p.clockRate * 1e3) / rate;
+  printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"cus\": %d, \"max_clock_khz\": %d, \"ms\": %.4f, \"timed_dispatch_index\": %d, "
+         "\"wave_instr\": %.0f, \"wave_instr_per_s\": %.4e, \"cycles_per_wave_instr_at_max_clock\": %.3f}\n",
+         name, waves_per_simd, cus, p.clockRate, ms, launch_index + 1, winst, rate, cyc_at_max);
+  launch_index += 2;
   hipFree(out);
-  return rate;
 }
 
 int main() {
-  for (int w : {1, 2, 4, 8}) run<0>("v_fma_f32", w);
-  for (int w : {4, 8}) run<1>("v_mul/add/min/max_f32", w);
-  for (int w : {4, 8}) run<2>("v_cndmask/v_cmp", w);
+  int li = 0;
+  for (int w : {1, 2, 4, 8}) run<0>("v_fma_f32 v,v,s,const", w, li);
+  for (int w : {4, 8}) run<1>("v_mul/add/max/min_f32 (VOP2, scalar or inline operand)", w, li);
+  for (int w : {4, 8}) run<2>("v_fma_f32 v,v,v,v (three vector sources)", w, li);
   return 0;
 }
