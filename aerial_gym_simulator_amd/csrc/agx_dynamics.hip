@@ -1010,8 +1010,10 @@ AGX_DEV void quad_controller(const AgxRobotParams &P, const QuadConsts<M> &C, fl
 template <int M, int CTRL>
 __global__ void __launch_bounds__(64, 1)
     k_env_step_quad_loop(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k, AgxTaskArgs T) {
-  static_assert((M == 4 && CTRL >= AGX_CTRL_POSITION && CTRL <= AGX_CTRL_VEL_STEERING) || (M == 8 && CTRL == AGX_CTRL_FULLY_ACTUATED),
-                "the six Lee laws of the quadrotor; the fully actuated octarotor (two motors per lane)");
+  static_assert((M == 4 && CTRL >= AGX_CTRL_POSITION && CTRL <= AGX_CTRL_VEL_STEERING) ||
+                    (M == 8 && (CTRL == AGX_CTRL_FULLY_ACTUATED || CTRL == AGX_CTRL_POSITION || CTRL == AGX_CTRL_VELOCITY)),
+                "the six Lee laws of the quadrotor; the octarotor (two motors per lane) under its three laws: fully actuated, Lee "
+                "position, Lee velocity (control/__init__.py:94-96)");
   constexpr bool FA = CTRL == AGX_CTRL_FULLY_ACTUATED;  // 7 actions: position set-point (3) + orientation set-point xyzw (4)
   constexpr int A = FA ? 7 : 4;
   constexpr int MH = M / 4;
@@ -1777,7 +1779,8 @@ static bool quad_loop_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers
   const bool lee_quad = P->num_motors == 4 && P->num_actions == 4 && P->controller >= AGX_CTRL_POSITION &&
                         P->controller <= AGX_CTRL_VEL_STEERING;
   const bool fa_octa = P->num_motors == 8 && P->num_actions == 7 && P->controller == AGX_CTRL_FULLY_ACTUATED;
-  if (!lee_quad && !fa_octa) return false;
+  const bool lee_octa = P->num_motors == 8 && P->num_actions == 4 && (P->controller == AGX_CTRL_POSITION || P->controller == AGX_CTRL_VELOCITY);
+  if (!lee_quad && !fa_octa && !lee_octa) return false;
   for (int c = 0; c < 3; ++c)
     if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
         P->ang_drag_quadratic[c] != 0.0f)
@@ -1826,6 +1829,16 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   }
   if (quad_loop_kernel_usable(P, B, n, k)) {
     const size_t lds4 = B->boxes ? (size_t)k * 3 * 16 * sizeof(float) : 0;
+    if (P->num_motors == 8 && P->controller == AGX_CTRL_POSITION) {
+      hipLaunchKernelGGL((k_env_step_quad_loop<8, AGX_CTRL_POSITION>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P, *B, n,
+                         actions_in, k, T);
+      return check_launch("agx_env_step");
+    }
+    if (P->num_motors == 8 && P->controller == AGX_CTRL_VELOCITY) {
+      hipLaunchKernelGGL((k_env_step_quad_loop<8, AGX_CTRL_VELOCITY>), dim3(blocks_for(n, 16)), dim3(64), lds4, (hipStream_t)stream, *P, *B, n,
+                         actions_in, k, T);
+      return check_launch("agx_env_step");
+    }
     switch (P->controller) {
 #define AGX_QUAD_LOOP(C_)                                                                                                        \
   case C_:                                                                                                                       \

@@ -21,9 +21,11 @@ __global__ void k_math_eval(int which, int n, const float *__restrict__ x, const
 }
 // float4 streaming copy: the HBM rate a kernel of this library can reach on this device (the "achievable" line of the
 // roofline; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy against 8 TB/s of specification)
+// One float4 per thread, no loop: the shape that reaches the guide's figure on this box (6.2 TB/s; grid-stride loops with 8-64
+// workgroups per CU stay at 4.4-5.2 TB/s, hipMemcpyDtoD at 4.8: profiles/src/hbm_copy.hip, profiles/r03_hbm_copy.jsonl).
 __global__ void __launch_bounds__(256) k_copy_f4(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) dst[i] = src[i];
 }
 }  // namespace
 
@@ -31,8 +33,8 @@ extern "C" int agx_copy_f4(const void *src, void *dst, size_t bytes, void *strea
   AGX_REQUIRE(src && dst && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "16-byte aligned buffers required");
   const size_t n4 = bytes / 16;
   if (n4 == 0) return AGX_OK;
-  size_t blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;  // 32 workgroups per CU, grid-stride
+  const size_t blocks = (n4 + 255) / 256;
+  AGX_REQUIRE(blocks <= 0x7FFFFFFFull, "at most 2^31 - 1 workgroups (512 GiB)");
   hipLaunchKernelGGL(k_copy_f4, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst, n4);
   return agx::check_launch("agx_copy_f4");
 }

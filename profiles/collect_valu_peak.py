@@ -10,6 +10,9 @@ import os
 import sys
 
 
+XCDS = 8
+
+
 def main(plain, pmc_csv=None, pmc_jsonl=None):
     rows = [json.loads(l) for l in open(plain) if l.strip().startswith("{")]
     if pmc_csv and pmc_jsonl and os.path.exists(pmc_csv):
@@ -23,8 +26,8 @@ def main(plain, pmc_csv=None, pmc_jsonl=None):
         for row, p in zip(rows, prof):
             i = p["timed_dispatch_index"]
             if i < len(order):
-                cycles = gui[order[i]]
-                row["profiled_run"] = {"ms": p["ms"], "GRBM_GUI_ACTIVE": cycles, "effective_clock_ghz": cycles / (p["ms"] * 1e-3) / 1e9,
+                cycles = gui[order[i]] / XCDS  # the counter is reported summed over the 8 XCDs (18.2 "GHz" otherwise)
+                row["profiled_run"] = {"ms": p["ms"], "GRBM_GUI_ACTIVE_per_xcd": cycles, "effective_clock_ghz": cycles / (p["ms"] * 1e-3) / 1e9,
                                        "wave_instr_per_s": p["wave_instr_per_s"],
                                        "cycles_per_wave_instr_at_effective_clock": cycles * p["cus"] * 4 / p["wave_instr"]}
     best = max(rows, key=lambda r: r["wave_instr_per_s"])

@@ -66,7 +66,7 @@ def test_four_lanes_per_env_kernel(meta):
     assert r["group_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64 and r["vgpr_count"] <= 128, r
     # the sub-step loop (the six Lee laws of the quadrotor, the fully actuated octarotor) and the reset / observation launch
     loops = {n: r for n, r in meta.items() if "k_env_step_quad_loop<" in n or "k_reset_masked_quad_obs" in n}
-    assert len(loops) == 8
+    assert len(loops) == 10
     for name, r in loops.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64, (name, r)
         # one-wave workgroups, at most 65 536 envs = 4096 waves: two waves per SIMD keep 32 768 envs resident in one round

@@ -421,10 +421,11 @@ def test_device_disturbance_stream(orc):
 
 
 @pytest.mark.parametrize("case", ["quad_position", "quad_velocity", "quad_attitude", "quad_rates", "quad_acceleration",
-                                  "quad_velocity_steering", "octarotor_fully_actuated"])
+                                  "quad_velocity_steering", "octarotor_fully_actuated", "octarotor_position", "octarotor_velocity"])
 @pytest.mark.parametrize("k", [1, 4])
 def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch):
-    """Every Lee law of the quadrotor and the fully actuated octarotor (BASELINE configs[3]: two motors per lane) have a
+    """Every Lee law of the quadrotor and the three laws of the octarotor (fully actuated = BASELINE configs[3], Lee position,
+    Lee velocity, control/__init__.py:94-96: two motors per lane; recorded disturbance draws included) have a
     four-lanes-per-env kernel (k_env_step_quad_position for one position-control sub-step, k_env_step_quad_loop<M, CTRL>
     otherwise): agx_env_step_kernel names it, and k sub-steps from the golden case's recorded states / actions / gains give
     bit for bit the buffers of the one-lane kernel (AGX_ENV_STEP_QUAD=0)."""
@@ -451,6 +452,8 @@ def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch)
         got = []
         for s in range(g["state"].shape[0]):
             H.set(state=g["state"][s], thrust=g["thrust_in"][s])
+            if g["disturb"].any():  # the octarotor's recorded disturbance draws, the same in each of the k sub-steps
+                H.set_disturb(np.repeat(g["disturb"][s][None], k, axis=0), g["disturb_max"])
             H.substeps(g["action"][s], k)
             got.append([H.get(x).copy() for x in ("state", "thrust", "derived", "wrench")])
         outs[quad] = got
