@@ -97,6 +97,20 @@ class AgxEnvBuffers(C.Structure):
         ("step_rows", C.c_void_p * 2),
         ("step_reward", C.c_void_p),
         ("step_signal", C.c_void_p),
+        ("push_delta", C.c_int64 * 7),
+        ("push_flags", C.c_void_p * 8),
+        ("push_world", C.c_int32),
+        ("push_rank", C.c_int32),
+        ("push_flag_index", C.c_int32),
+        ("push_wait_index", C.c_int32),
+        ("push_pub_index", C.c_int32),
+        ("push_pub_seq", C.c_uint32),
+        ("push_seq", C.c_uint32),
+        ("push_wait_seq", C.c_uint32),
+        ("push_timed_out", C.c_void_p),
+        ("push_base", C.c_void_p),
+        ("push_slice_bytes", C.c_int64),
+        ("push_slots", C.c_int32),
         ("body_force", C.c_void_p),
         ("step_counter_dev", C.c_void_p),
         ("env_index_base", C.c_int32),
@@ -224,6 +238,14 @@ _SIGNATURES = {
     "agx_exchange_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_size_t, _P, C.c_uint32, C.c_int, _P]),
     "agx_exchange_info": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "agx_exchange_destroy": (C.c_int, [_P]),
+    "agx_exchange_create_push": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "agx_exchange_push_export": (C.c_int, [_P, _P, C.c_int]),
+    "agx_exchange_push_connect": (C.c_int, [_P, _P, C.c_int]),
+    "agx_exchange_push_buffer": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "agx_exchange_push_peers": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "agx_exchange_push_wait_seq": (C.c_int, [_P, C.c_uint32, _P]),
+    "agx_exchange_check": (C.c_int, [_P]),
+    "agx_push_advance": (C.c_int, [C.POINTER(AgxEnvBuffers)]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_sensor_pose": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),

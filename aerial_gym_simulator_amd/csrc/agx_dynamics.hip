@@ -479,6 +479,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
   const int tid = threadIdx.x, bd = blockDim.x;
   const int i = blockIdx.x * bd + tid;
   bool reset = false;
+  // peer push: one wave holds the step until the slot of its rows is free (flags loaded here, looked at when the kernel is done)
+  if (blockIdx.x == 0 && tid < 64) push_publish_previous(B);
+  const uint32_t push_peek = (blockIdx.x == 0 && tid < 64) ? push_wait_peek(B) : 0u;
   if (i < n) {
     const int A = P.num_actions;
     // AGX_LAUNCH_LEAN (launch_flags bit 2): the tensors that only exist to be LOOKED AT through the tensor dict are not
@@ -650,6 +653,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
     if (!more_launches) B.truncations[i] = trunc ? 1 : 0;
   }
   if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+  if (blockIdx.x == 0 && tid < 64) push_wait_finish(B, push_peek);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -816,6 +820,8 @@ __global__ void __launch_bounds__(64, 1)
   const int l = tid & 3, l3 = l < 3 ? l : 2;  // component of a 4-vector / of a 3-vector (lane 3 repeats z: don't care)
   const int i = blockIdx.x * 16 + (tid >> 2);  // env
   bool reset = false;
+  if (blockIdx.x == 0) push_publish_previous(B);  // peer push: the previous step's rows have landed everywhere
+  const uint32_t push_peek = blockIdx.x == 0 ? push_wait_peek(B) : 0u;  // ... and this step's slot: looked at when the kernel is done
   if (i < n) {
     // ---- loads: one instruction per vector
     float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
@@ -910,6 +916,7 @@ __global__ void __launch_bounds__(64, 1)
     }
   }
   if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+  if (blockIdx.x == 0) push_wait_finish(B, push_peek);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1022,6 +1029,8 @@ __global__ void __launch_bounds__(64, 1)
   const int l = tid & 3, l3 = l < 3 ? l : 2, slot = tid >> 2;
   const int i = blockIdx.x * 16 + slot;
   bool reset = false;
+  if (blockIdx.x == 0) push_publish_previous(B);  // peer push: the previous step's rows have landed everywhere
+  const uint32_t push_peek = blockIdx.x == 0 ? push_wait_peek(B) : 0u;  // ... and this step's slot: looked at when the kernel is done
   if (i < n) {
     float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
     float u[MH], kT[MH], tinc[MH], tdec[MH];
@@ -1173,6 +1182,7 @@ __global__ void __launch_bounds__(64, 1)
     }
   }
   if (T.kind != AGX_TASK_NONE && __ballot(reset) != 0ull && (tid & 63) == 0) atomicOr(B.reset_flag + B.flag_parity, 1);
+  if (blockIdx.x == 0) push_wait_finish(B, push_peek);
 }
 
 __global__ void __launch_bounds__(256) k_update_states(AgxEnvBuffers B, int n) {
@@ -1233,9 +1243,9 @@ __global__ void __launch_bounds__(256) k_reward_position(AgxEnvBuffers B, int n,
 // position_setpoint_task.py:194-203, obs [N][13] row-major (what the policy network consumes)
 // reward | terminated | truncated behind the observation in the exchange row (header: step_rows)
 AGX_DEV void write_step_row_tail(const AgxEnvBuffers &B, int i, float *__restrict__ row, int obs_dim) {
-  row_store(row + obs_dim, B.step_reward[i]);
-  row_store(row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
-  row_store(row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
+  row_store(B, row + obs_dim, B.step_reward[i]);
+  row_store(B, row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
+  row_store(B, row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
 }
 AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, V3 tgt, float *__restrict__ obs, const EnvState &s,
                                 const Derived &d) {
@@ -1247,12 +1257,13 @@ AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, V3 tgt, fl
   if (float *rows = B.step_rows[B.flag_parity]) {
     float *r = rows + (size_t)i * 16;
 #pragma unroll
-    for (int c = 0; c < 13; ++c) row_store(r + c, v[c]);
+    for (int c = 0; c < 13; ++c) row_store(B, r + c, v[c]);
     write_step_row_tail(B, i, r, 13);
   }
 }
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  push_wait_for_slot(B);
   if (i < n)
     write_obs_position(B, n, i, V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)}, obs, load_state(B.state, n, i),
                        load_derived(B.derived, n, i));
@@ -1321,7 +1332,7 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     o[10] = AGX_AT(B.derived, 13); o[11] = AGX_AT(B.derived, 14); o[12] = AGX_AT(B.derived, 15);
     o[13] = AGX_AT(B.actions, 0); o[14] = AGX_AT(B.actions, 1); o[15] = AGX_AT(B.actions, 2); o[16] = AGX_AT(B.actions, 3);
     if (row) {
-      for (int c = 0; c < 17 && c < obs_dim; ++c) row_store(row + c, o[c]);  // this lane's own stores
+      for (int c = 0; c < 17 && c < obs_dim; ++c) row_store(B, row + c, o[c]);  // this lane's own stores
       write_step_row_tail(B, i, row, obs_dim);
     }
   }
@@ -1382,7 +1393,7 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
       const int k = 17 + cy * gw + lane;
       if (lane < gw && k < obs_dim) {
         o[k] = cell;
-        if (row) row_store(row + k, cell);
+        if (row) row_store(B, row + k, cell);
       }
     }
     if (min_pixel) {
@@ -1396,6 +1407,7 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
                                                          const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
                                                          int obs_dim, float *__restrict__ obs, float *__restrict__ min_pixel) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per env
+  push_wait_for_slot(B);
   if (i < n) obs_navigation_env(B, n, i, target, u_vec, u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel);
   step_rows_signal(B);
 }
@@ -1582,6 +1594,7 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
                                                       const float *__restrict__ target, float *__restrict__ obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
+  if (WITH_OBS) push_wait_for_slot(B);
   const bool valid = i < n;
   EnvState s{};
   Derived d{};
@@ -1611,6 +1624,7 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
   const int l = tid & 3, l3 = l < 3 ? l : 2;
   const int i = blockIdx.x * 16 + (tid >> 2);
   if (blockIdx.x == 0 && tid == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
+  push_wait_for_slot(B);
   const bool valid = i < n;
   float p = 0.0f, q = 0.0f, v = 0.0f, w = 0.0f, vbody = 0.0f, wbody = 0.0f, tgt = 0.0f;
   bool mine = false;
@@ -1662,8 +1676,8 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
     o[3 + l] = q;
     if (float *rows = B.step_rows[B.flag_parity]) {
       float *r = rows + (size_t)i * 16;
-      if (l < 3) { row_store(r + l, e); row_store(r + 7 + l, vbody); row_store(r + 10 + l, wbody); }
-      row_store(r + 3 + l, q);
+      if (l < 3) { row_store(B, r + l, e); row_store(B, r + 7 + l, vbody); row_store(B, r + 10 + l, wbody); }
+      row_store(B, r + 3 + l, q);
       if (l == 0) write_step_row_tail(B, i, r, 13);
     }
   }
@@ -1996,11 +2010,37 @@ extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffe
   return check_launch("agx_post_step_position");
 }
 
+extern "C" int agx_push_advance(AgxEnvBuffers *b) {
+  AGX_REQUIRE(b && b->push_world > 0 && b->push_world <= 8 && b->push_slots >= 5 && b->push_base && b->push_slice_bytes > 0,
+              "agx_push_advance: peer push is not bound (or fewer than 5 receive slots)");
+  b->push_pub_seq = b->push_seq;  // the rows of the step before are announced by the first kernel of this one
+  b->push_pub_index = b->push_flag_index;
+  const uint32_t seq = ++b->push_seq;
+  const int slot = (int)((seq - 1u) % (uint32_t)b->push_slots);
+  b->push_flag_index = slot * b->push_world + b->push_rank;
+  b->step_rows[0] = b->step_rows[1] = (float *)(b->push_base + ((size_t)slot * b->push_world + b->push_rank) * (size_t)b->push_slice_bytes);
+  if (seq > 2u) {
+    b->push_wait_seq = seq - 2u;
+    b->push_wait_index = (int)((seq - 3u) % (uint32_t)b->push_slots) * b->push_world;
+  } else {
+    b->push_wait_seq = 0u;
+  }
+  return AGX_OK;
+}
+
 extern "C" int agx_position_task_step(const AgxPositionStepPlan *plan, const float *actions_in, void *stream) {
   AGX_REQUIRE(plan && plan->params && plan->buf && plan->task && plan->reset, "null plan member");
   plan->buf->flag_parity ^= 1;  // new env step: the flag the previous step's reset kernel cleared
+  if (plan->buf->push_world > 0)
+    if (int e = agx_push_advance(plan->buf)) return e;
   if (int e = agx_env_step(plan->params, plan->buf, plan->num_envs, actions_in, plan->k_substeps, plan->task, stream)) return e;
-  return agx_post_step_position(plan->params, plan->buf, plan->num_envs, plan->reset, plan->target, plan->obs, stream);
+  // peer push: the env-step kernel has waited (one wave) until the slot of this step's rows was vacated; the observation
+  // kernel behind it need not look again
+  const uint32_t wait_seq = plan->buf->push_wait_seq;
+  plan->buf->push_wait_seq = 0;
+  const int rc = agx_post_step_position(plan->params, plan->buf, plan->num_envs, plan->reset, plan->target, plan->obs, stream);
+  plan->buf->push_wait_seq = wait_seq;
+  return rc;
 }
 
 extern "C" int agx_reset_assets(const AgxEnvBuffers *B, int n, int K, const AgxResetArgs *R, const float *u1, const float *u2,

@@ -87,6 +87,7 @@ struct Job {
   int parity;
   const uint32_t *signal;  // AgxEnvBuffers.step_signal, or NULL: the ready[parity] event orders the gather
   uint32_t seq;
+  uint32_t push_seq;       // peer push: sequence number of this post (slot = (push_seq - 1) % kPushSlots)
 };
 
 // 10 s of the 100 MHz wall clock: a producer that never signals (or a communication stream that ended up
@@ -115,12 +116,105 @@ __global__ void k_wait_signal(const uint32_t *flag, uint32_t seq, uint32_t *time
   }
 }
 
+// ---- peer push (round 3): no collective kernel per step ---------------------------------------------------------------------
+// The RCCL all-gather costs 12.5 us per launch back to back in a world of one and more over xGMI -- as long as the 13 us
+// dynamics-only step itself, and the gathers of consecutive steps serialise on the communication stream (VERDICT r2 "missing" 1).
+// Instead every rank PUSHES its rows straight into every peer's receive buffer (peer memory mapped through hipIpcMemHandle;
+// xGMI is point to point, so the seven destinations are seven independent links) and raises a per-sender arrival flag there:
+//   k_push_rows (communication stream, one launch per step): wait for step_signal (the rows of this step are written) ->
+//     workgroup b copies chunk b / world of the rows to destination b % world -> system-scope release -> the last workgroup to
+//     arrive stores flags[slot][rank] = seq at every destination.
+//   k_wait_flags (consumer's stream): one lane per sender spins until flags[slot][sender] >= seq, acquire at system scope.
+// Receive buffers have kPushSlots = 8 slots (slot = (seq - 1) % 8).  No acknowledgement travels back.  A rank reads the rows
+// of step t - L after its kernels of step t and before those of step t + 1 (L = 1 behind the flag wait of this file, L = 2 when
+// the observation kernels push the rows themselves); that slot is overwritten by the pushes of step t - L + S, and a push of
+// step s is ordered behind the arrival, at the pushing rank, of EVERY rank's rows of step s - 2 (the stream wait of step s - 1
+// / the one-wave wait at the head of the env-step kernel).  The reader's own push of step t + 1 comes after its reads, so the
+// overwrite is safe when t - L + S - 2 >= t + 1, i.e. S >= L + 3: five slots would do, eight are used.
+constexpr int kPushSlots = 8;
+constexpr int kMaxWorld = 64;
+
+template <typename V>
+__global__ void __launch_bounds__(256) k_push_rows(const V *__restrict__ send, size_t nv, V *const *__restrict__ peer_recv,
+                                                   uint32_t *const *__restrict__ peer_flags, int world, int rank, int slot,
+                                                   const uint32_t *signal, uint32_t signal_seq, uint32_t flag_seq,
+                                                   uint32_t *arrive, uint32_t *timed_out, uint64_t limit_ticks) {
+  __shared__ int give_up;
+  if (threadIdx.x == 0) {
+    give_up = 0;
+    if (signal) {
+      const uint64_t t0 = wall_clock64();
+      uint32_t polls = 0;
+      while ((int32_t)(__hip_atomic_load(signal, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - signal_seq) < 0) {
+        if (++polls < 128) __builtin_amdgcn_s_sleep(8);
+        else __builtin_amdgcn_s_sleep(127);
+        if (wall_clock64() - t0 > limit_ticks) {
+          __hip_atomic_store(timed_out, signal_seq ? signal_seq : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          give_up = 1;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (give_up) return;  // (every workgroup times out on its own: nobody publishes)
+  const int w = blockIdx.x % world, chunk = blockIdx.x / world, chunks = gridDim.x / world;
+  V *dst = peer_recv[w] + ((size_t)slot * world + rank) * nv;
+  const size_t per = (nv + chunks - 1) / chunks, lo = (size_t)chunk * per, hi = lo + per < nv ? lo + per : nv;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) dst[i] = send[i];
+  __threadfence_system();  // this thread's stores have reached their destinations
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t arrived = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (arrived == gridDim.x) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (same stream)
+      for (int d = 0; d < world; ++d)
+        __hip_atomic_store(peer_flags[d] + (size_t)slot * world + rank, flag_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// rows stored by the observation kernels themselves are announced by the first kernel of the NEXT step; a consumer that wants
+// the latest step's rows (synchronous exchange, flush) announces them here, behind the kernel that stored them
+__global__ void k_publish_flags(uint32_t *const *peer_flags, int world, int index, uint32_t seq) {
+  const int w = threadIdx.x;
+  if (w < world) __hip_atomic_store(peer_flags[w] + index, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_wait_flags(const uint32_t *flags, int world, uint32_t seq, uint32_t *timed_out, uint64_t limit_ticks) {
+  const int w = threadIdx.x;
+  if (w >= world) return;
+  const uint64_t t0 = wall_clock64();
+  uint32_t polls = 0;
+  while ((int32_t)(__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    if (++polls < 128) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(127);
+    if (wall_clock64() - t0 > limit_ticks) {
+      __hip_atomic_store(timed_out, seq ? seq : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // once: the readers are later kernels of this stream (which start with an invalidate of their own)
+}
+
 }  // namespace
 
 struct AgxExchange {
   Rccl *rccl = nullptr;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
+  // peer push (mode_push): this rank's receive buffer + arrival flags, the peers' mapped through hipIpcMemHandle
+  bool mode_push = false, connected = false, flags_uncached = false;
+  size_t push_count = 0;             // floats per rank and step
+  float *push_recv = nullptr;        // [kPushSlots][world][push_count]
+  uint32_t *push_flags = nullptr;    // [kPushSlots][world]
+  uint32_t *push_arrive = nullptr;   // workgroup counter of k_push_rows
+  void **peer_recv_dev = nullptr;    // device arrays [world]
+  uint32_t **peer_flags_dev = nullptr;
+  void *opened[2 * kMaxWorld] = {};
+  int num_opened = 0;
+  uint64_t push_posts = 0;           // posts so far = sequence number of the latest
+  uint64_t push_seq_of_parity[2] = {0, 0};
   bool concurrent = false;  // agx_exchange_probe found the comm stream independent of the producer's queue
   uint32_t *probe_flag = nullptr;
   hipStream_t retired[8] = {};
@@ -165,7 +259,27 @@ struct AgxExchange {
         continue;
       }
       const Job j = ring[done_n % kRing];
-      if (!failed.load(std::memory_order_relaxed)) {
+      if (!failed.load(std::memory_order_relaxed) && mode_push) {
+        hipError_t e = hipSuccess;
+        if (!j.signal) {
+          e = hipStreamWaitEvent(comm_stream, ready[j.parity], 0);
+          if (e != hipSuccess) fail_worker("hipStreamWaitEvent", hipGetErrorString(e));
+        }
+        const int slot = (int)((j.push_seq - 1) % kPushSlots);
+        const uint32_t *sig = j.signal ? j.signal + j.parity : nullptr;
+        // 8 chunks per destination: 64 workgroups at world 8 (0.5 MB of rows per destination: 64 KB per workgroup)
+        const int chunks = j.count >= (size_t)1 << 16 ? 8 : 1;
+        if (j.count % 4 == 0 && ((uintptr_t)j.send % 16) == 0)
+          hipLaunchKernelGGL(k_push_rows<float4>, dim3(world * chunks), dim3(256), 0, comm_stream, (const float4 *)j.send, j.count / 4,
+                             (float4 *const *)peer_recv_dev, (uint32_t *const *)peer_flags_dev, world, rank, slot, sig, j.seq, j.push_seq,
+                             push_arrive, timed_out_dev, kSpinLimitTicks);
+        else
+          hipLaunchKernelGGL(k_push_rows<float>, dim3(world * chunks), dim3(256), 0, comm_stream, j.send, j.count,
+                             (float *const *)peer_recv_dev, (uint32_t *const *)peer_flags_dev, world, rank, slot, sig, j.seq, j.push_seq,
+                             push_arrive, timed_out_dev, kSpinLimitTicks);
+        e = hipGetLastError();
+        if (e != hipSuccess) fail_worker("k_push_rows", hipGetErrorString(e));
+      } else if (!failed.load(std::memory_order_relaxed)) {
         hipError_t e;
         if (j.signal) {  // producer = a simulator kernel: spin on its flag, no cross-queue event
           hipLaunchKernelGGL(k_wait_signal, dim3(1), dim3(64), 0, comm_stream, j.signal + j.parity, j.seq, timed_out_dev,
@@ -246,6 +360,138 @@ extern "C" int agx_exchange_create(const char *rccl_path, const void *id, int id
   return AGX_OK;
 }
 
+// ---- peer push: construction ----------------------------------------------------------------------------------------------
+extern "C" int agx_exchange_create_push(int rank, int world, int device, size_t count_per_rank, AgxExchange **out) {
+  AGX_REQUIRE(out && world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world && count_per_rank > 0,
+              "agx_exchange_create_push: rank %d of %d, %zu floats per rank", rank, world, count_per_rank);
+  *out = nullptr;
+  hipError_t he = hipSetDevice(device);
+  if (he != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipSetDevice(%d): %s", device, hipGetErrorString(he));
+  AgxExchange *x = new AgxExchange();
+  x->mode_push = true;
+  x->rank = rank;
+  x->world = world;
+  x->device = device;
+  x->push_count = count_per_rank;
+  const size_t recv_bytes = (size_t)kPushSlots * world * count_per_rank * sizeof(float);
+  const size_t flag_bytes = (size_t)kPushSlots * world * sizeof(uint32_t);
+  bool ok = hipMalloc((void **)&x->push_recv, recv_bytes) == hipSuccess && hipMemset(x->push_recv, 0, recv_bytes) == hipSuccess;
+  // the flags are polled by a running kernel while a PEER device writes them: uncached (fine-grained) memory, like RCCL's own
+  // flags; a runtime that refuses it gets ordinary device memory (the accesses are system-scope atomics either way)
+  if (ok) {
+    x->flags_uncached = hipExtMallocWithFlags((void **)&x->push_flags, flag_bytes, hipDeviceMallocUncached) == hipSuccess;
+    if (!x->flags_uncached) {
+      (void)hipGetLastError();
+      ok = hipMalloc((void **)&x->push_flags, flag_bytes) == hipSuccess;
+    }
+  }
+  ok = ok && hipMemset(x->push_flags, 0, flag_bytes) == hipSuccess;
+  ok = ok && hipMalloc((void **)&x->push_arrive, sizeof(uint32_t)) == hipSuccess && hipMemset(x->push_arrive, 0, sizeof(uint32_t)) == hipSuccess;
+  ok = ok && hipMalloc((void **)&x->peer_recv_dev, world * sizeof(void *)) == hipSuccess &&
+       hipMalloc((void **)&x->peer_flags_dev, world * sizeof(void *)) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&x->comm_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&x->timed_out_host, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+  if (ok) {
+    x->timed_out_host[0] = x->timed_out_host[1] = 0;
+    ok = hipHostGetDevicePointer((void **)&x->timed_out_dev, x->timed_out_host, 0) == hipSuccess;
+  }
+  ok = ok && hipMalloc((void **)&x->probe_flag, sizeof(uint32_t)) == hipSuccess && hipMemset(x->probe_flag, 0, sizeof(uint32_t)) == hipSuccess;
+  for (int p = 0; p < 2 && ok; ++p)
+    ok = hipEventCreateWithFlags(&x->ready[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&x->done[p], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
+  if (!ok) {
+    const char *why = hipGetErrorString(hipGetLastError());
+    agx_exchange_destroy(x);
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange_create_push: allocation failed (%s)", why);
+  }
+  x->worker = std::thread([x] { x->run(); });
+  *out = x;
+  return AGX_OK;
+}
+
+// 2 x 64 bytes: the hipIpcMemHandle of this rank's receive buffer and of its flags; they travel to the peers out of band
+extern "C" int agx_exchange_push_export(AgxExchange *x, void *handles_out, int bytes) {
+  AGX_REQUIRE(x && x->mode_push && handles_out && bytes == 2 * (int)sizeof(hipIpcMemHandle_t), "agx_exchange_push_export: %d bytes expected",
+              2 * (int)sizeof(hipIpcMemHandle_t));
+  hipIpcMemHandle_t h[2];
+  hipError_t e = hipIpcGetMemHandle(&h[0], x->push_recv);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h[1], x->push_flags);
+  if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+  memcpy(handles_out, h, sizeof(h));
+  return AGX_OK;
+}
+
+// all_handles: world x (2 x 64) bytes, rank-major, as gathered from agx_exchange_push_export of every rank
+extern "C" int agx_exchange_push_connect(AgxExchange *x, const void *all_handles, int bytes) {
+  AGX_REQUIRE(x && x->mode_push && !x->connected && all_handles && bytes == x->world * 2 * (int)sizeof(hipIpcMemHandle_t),
+              "agx_exchange_push_connect: %d x %d bytes expected", x ? x->world : 0, 2 * (int)sizeof(hipIpcMemHandle_t));
+  (void)hipSetDevice(x->device);
+  void *recv[kMaxWorld];
+  uint32_t *flags[kMaxWorld];
+  const hipIpcMemHandle_t *h = (const hipIpcMemHandle_t *)all_handles;
+  for (int w = 0; w < x->world; ++w) {
+    if (w == x->rank) {
+      recv[w] = x->push_recv;
+      flags[w] = x->push_flags;
+      continue;
+    }
+    void *pr = nullptr, *pf = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&pr, h[2 * w], hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) {
+      x->opened[x->num_opened++] = pr;
+      e = hipIpcOpenMemHandle(&pf, h[2 * w + 1], hipIpcMemLazyEnablePeerAccess);
+      if (e == hipSuccess) x->opened[x->num_opened++] = pf;
+    }
+    if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipIpcOpenMemHandle (rank %d's buffers): %s", w, hipGetErrorString(e));
+    recv[w] = pr;
+    flags[w] = (uint32_t *)pf;
+  }
+  if (hipMemcpy(x->peer_recv_dev, recv, x->world * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(x->peer_flags_dev, flags, x->world * sizeof(void *), hipMemcpyHostToDevice) != hipSuccess)
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange_push_connect: hipMemcpy failed");
+  x->connected = true;
+  return AGX_OK;
+}
+
+// this rank's receive buffer [slots][world][count_per_rank] (device pointer) and its slot count; the gathered rows of the
+// post with sequence number s (1-based, counted per exchange) are slot (s - 1) % slots
+extern "C" int agx_exchange_push_buffer(AgxExchange *x, void **recv, int *slots, int *flags_uncached) {
+  AGX_REQUIRE(x && x->mode_push && recv && slots, "agx_exchange_push_buffer: null argument");
+  *recv = x->push_recv;
+  *slots = kPushSlots;
+  if (flags_uncached) *flags_uncached = x->flags_uncached ? 1 : 0;
+  return AGX_OK;
+}
+
+// the addresses, IN THIS PROCESS, of every rank's receive buffer and flag array (own included): what a kernel of this rank
+// stores through when it writes its rows at all destinations itself (AgxEnvBuffers.push_delta / push_flags) -- and the
+// device-visible word a bounded wait reports its time-out in
+extern "C" int agx_exchange_push_peers(AgxExchange *x, void **recv_out, void **flags_out, void **timed_out) {
+  AGX_REQUIRE(x && x->mode_push && x->connected && recv_out && flags_out, "agx_exchange_push_peers: connect first");
+  (void)hipSetDevice(x->device);
+  if (hipMemcpy(recv_out, x->peer_recv_dev, x->world * sizeof(void *), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(flags_out, x->peer_flags_dev, x->world * sizeof(void *), hipMemcpyDeviceToHost) != hipSuccess)
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange_push_peers: hipMemcpy failed");
+  if (timed_out) *timed_out = x->timed_out_dev;
+  return AGX_OK;
+}
+
+static int check_failed(AgxExchange *x);
+// `stream` waits (one wave, bounded) until the rows with sequence number `seq` of EVERY rank have arrived in this rank's
+// receive buffer: for rows pushed by the observation kernels themselves, where the host keeps the sequence numbers
+extern "C" int agx_exchange_push_wait_seq(AgxExchange *x, uint32_t seq, void *stream) {
+  AGX_REQUIRE(x && x->mode_push && x->connected && seq != 0u, "agx_exchange_push_wait_seq: bad argument");
+  if (int e = check_failed(x)) return e;
+  const int slot = (int)((seq - 1) % kPushSlots);
+  // (announcing a step twice is harmless; announcing it HERE is right because `stream` has run the kernel that stored its rows)
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint32_t *const *)x->peer_flags_dev, x->world,
+                     slot * x->world + x->rank, seq);
+  hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, (hipStream_t)stream, x->push_flags + (size_t)slot * x->world, x->world, seq,
+                     x->timed_out_dev, kSpinLimitTicks);
+  return agx::check_launch("agx_exchange_push_wait_seq");
+}
+
 static int check_failed(AgxExchange *x) {
   if (x->failed.load(std::memory_order_acquire)) return agx::fail(AGX_E_LAUNCH, "agx_exchange worker: %s", x->error);
   if (*(volatile uint32_t *)x->timed_out_host)
@@ -285,8 +531,10 @@ extern "C" int agx_exchange_probe(AgxExchange *x, void *producer_stream) {
 
 extern "C" int agx_exchange_post(AgxExchange *x, int parity, const float *send, float *recv, size_t count_per_rank,
                                  const uint32_t *signal, uint32_t seq, void *producer_stream) {
-  AGX_REQUIRE(x && send && recv && (parity == 0 || parity == 1) && count_per_rank > 0, "agx_exchange_post: bad argument");
+  AGX_REQUIRE(x && send && (recv || x->mode_push) && (parity == 0 || parity == 1) && count_per_rank > 0, "agx_exchange_post: bad argument");
   AGX_REQUIRE(!signal || x->concurrent, "agx_exchange_post: step_signal mode needs a successful agx_exchange_probe first");
+  AGX_REQUIRE(!x->mode_push || (x->connected && count_per_rank == x->push_count),
+              "agx_exchange_post (peer push): connect first; %zu floats per rank expected", x->push_count);
   if (int e = check_failed(x)) return e;
   const uint64_t n = x->pushed.load(std::memory_order_relaxed);
   // the ring slot and the two events of this parity are free once the previous job of this parity was issued
@@ -296,7 +544,12 @@ extern "C" int agx_exchange_post(AgxExchange *x, int parity, const float *send, 
     hipError_t e = hipEventRecord(x->ready[parity], (hipStream_t)producer_stream);
     if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipEventRecord: %s", hipGetErrorString(e));
   }
-  x->ring[n % kRing] = Job{send, recv, count_per_rank, parity, signal, seq};
+  uint32_t push_seq = 0;
+  if (x->mode_push) {
+    push_seq = (uint32_t)(++x->push_posts);
+    x->push_seq_of_parity[parity] = x->push_posts;
+  }
+  x->ring[n % kRing] = Job{send, recv, count_per_rank, parity, signal, seq, push_seq};
   x->last_job[parity] = n + 1;
   x->pushed.store(n + 1, std::memory_order_seq_cst);
   if (x->sleeping.load(std::memory_order_seq_cst)) {
@@ -309,6 +562,16 @@ extern "C" int agx_exchange_post(AgxExchange *x, int parity, const float *send, 
 extern "C" int agx_exchange_wait(AgxExchange *x, int parity, void *consumer_stream) {
   AGX_REQUIRE(x && (parity == 0 || parity == 1), "agx_exchange_wait: bad argument");
   if (x->last_job[parity] == 0) return AGX_OK;  // nothing was ever posted for this parity
+  if (x->mode_push) {
+    // no hand-off with the worker and no cross-queue event: the arrival flags of that post's slot say when every rank's rows
+    // have landed (this rank's own included: after it the send rows may be overwritten)
+    if (int e = check_failed(x)) return e;
+    const uint64_t seq = x->push_seq_of_parity[parity];
+    const int slot = (int)((seq - 1) % kPushSlots);
+    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, (hipStream_t)consumer_stream, x->push_flags + (size_t)slot * x->world, x->world,
+                       (uint32_t)seq, x->timed_out_dev, kSpinLimitTicks);
+    return agx::check_launch("agx_exchange_wait (k_wait_flags)");
+  }
   x->wait_issued(x->last_job[parity]);
   if (int e = check_failed(x)) return e;
   // (measured and dropped, profiles/r01_exchange_probe.txt: eliding this wait with a host-side hipEventQuery
@@ -325,8 +588,19 @@ extern "C" int agx_exchange_step(AgxExchange *x, int parity, const float *send, 
   return AGX_OK;
 }
 
+// anything gone wrong so far (worker thread, a device-side wait that gave up)?  Cheap: two host reads.
+extern "C" int agx_exchange_check(AgxExchange *x) {
+  AGX_REQUIRE(x, "agx_exchange_check: null exchange");
+  return check_failed(x);
+}
+
 extern "C" int agx_exchange_info(AgxExchange *x, int *rank, int *world) {
   AGX_REQUIRE(x && rank && world, "agx_exchange_info: null argument");
+  if (x->mode_push) {  // the ranks whose buffers were mapped (agx_exchange_push_connect), not a communicator
+    *rank = x->rank;
+    *world = x->connected ? x->world : 0;
+    return AGX_OK;
+  }
   ncclResult_t a = x->rccl->CommUserRank(x->comm, rank), b = x->rccl->CommCount(x->comm, world);
   if (a != ncclSuccess || b != ncclSuccess)
     return agx::fail(AGX_E_LAUNCH, "ncclCommUserRank / ncclCommCount: %s", x->rccl->GetErrorString(a != ncclSuccess ? a : b));
@@ -344,6 +618,12 @@ extern "C" int agx_exchange_destroy(AgxExchange *x) {
   (void)hipSetDevice(x->device);
   if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
   if (x->comm) x->rccl->CommDestroy(x->comm);
+  for (int i = 0; i < x->num_opened; ++i) (void)hipIpcCloseMemHandle(x->opened[i]);
+  if (x->push_recv) (void)hipFree(x->push_recv);
+  if (x->push_flags) (void)hipFree(x->push_flags);
+  if (x->push_arrive) (void)hipFree(x->push_arrive);
+  if (x->peer_recv_dev) (void)hipFree(x->peer_recv_dev);
+  if (x->peer_flags_dev) (void)hipFree(x->peer_flags_dev);
   for (int p = 0; p < 2; ++p) {
     if (x->ready[p]) (void)hipEventDestroy(x->ready[p]);
     if (x->done[p]) (void)hipEventDestroy(x->done[p]);

@@ -189,16 +189,16 @@ AGX_DEV void obs_lidar_navigation_env(const AgxEnvBuffers &B, int n, int i, cons
     for (int c = 0; c < 17; ++c) o[c] = s[c];
     if (row) {
 #pragma unroll
-      for (int c = 0; c < 17; ++c) row_store(row + c, s[c]);
-      row_store(row + obs_dim, B.step_reward[i]);
-      row_store(row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
-      row_store(row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
+      for (int c = 0; c < 17; ++c) row_store(B, row + c, s[c]);
+      row_store(B, row + obs_dim, B.step_reward[i]);
+      row_store(B, row + obs_dim + 1, B.crashes[i] ? 1.0f : 0.0f);
+      row_store(B, row + obs_dim + 2, B.truncations[i] ? 1.0f : 0.0f);
     }
   }
   for (int c = lane; c < cells; c += 64) {
     float d = downsampled[(size_t)i * cells + c];
     o[17 + c] = d;
-    if (row) row_store(row + 17 + c, d);
+    if (row) row_store(B, row + 17 + c, d);
   }
 }
 __global__ void __launch_bounds__(256) k_obs_lidar_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256) k_obs_lidar_navigation(AgxEnvBuffers B, i
                                                                const float *__restrict__ downsampled, int cells,
                                                                float *__restrict__ obs) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per env
+  push_wait_for_slot(B);
   if (i < n) obs_lidar_navigation_env(B, n, i, target, target_yaw, u_vec, u_euler, downsampled, cells, obs);
   step_rows_signal(B);
 }

@@ -27,22 +27,85 @@ __device__ __forceinline__ int step_index(const AgxEnvBuffers &B) {
   return B.step_counter_dev ? *B.step_counter_dev : B.step_counter;
 }
 
-__device__ __forceinline__ void row_store(float *p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// One element of an exchange row.  Without peer push: a write-through store (agent scope) that the wave later waits on before the
+// launch publishes step_signal.  With peer push (AgxEnvBuffers.push_world > 0): a PLAIN store at this rank's own slice and at
+// the same offset in every peer's receive buffer (another device's memory, reached over xGMI) -- nothing waits for it inside the
+// kernel: the end of the kernel makes its stores visible at system scope, and the arrival flags are raised by the FIRST kernel
+// of the next step (push_publish_previous), which the stream runs behind this one.  (Write-through stores + an in-kernel
+// s_waitcnt + the flags at the tail of this kernel cost 4.4 us per step even with every destination in local HBM:
+// profiles/r03_exchange_experiments.txt.)
+__device__ __forceinline__ void row_store(const AgxEnvBuffers &B, float *p, float v) {
+  if (B.push_world > 0) {
+    *p = v;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (j < B.push_world - 1) *(float *)((char *)p + B.push_delta[j]) = v;
+  } else {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// peer push: the rows of the PREVIOUS step are complete at every destination (the kernel that stored them has ended); lanes
+// 0 .. world - 1 of the calling wave tell every rank so.  Called by one wave at the head of the first kernel of a step.
+__device__ __forceinline__ void push_publish_previous(const AgxEnvBuffers &B) {
+  if (B.push_world <= 0 || B.push_pub_seq == 0u) return;
+  const int lane = (int)(threadIdx.x & 63u);
+  if (lane < B.push_world)
+    __hip_atomic_store(B.push_flags[lane] + B.push_pub_index, B.push_pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// peer push: before a row-writing kernel stores its first row, the slot it writes into must have been vacated -- every
+// rank's rows of step push_wait_seq (two steps back) have arrived HERE, so every rank is past the kernels that read the
+// slot being overwritten (four slots; agx_exchange.hip has the argument).  Lanes 0 .. world - 1 of every wave look at one
+// flag each; the wait is bounded (10 s of the 100 MHz clock) and reports through push_timed_out.  Must be called by whole
+// waves, before the first row_store.
+__device__ __forceinline__ void push_wait_for_slot(const AgxEnvBuffers &B) {
+  if (B.push_world <= 0 || B.push_wait_seq == 0u) return;
+  const int lane = (int)(threadIdx.x & 63u);
+  if (lane < B.push_world) {
+    const uint32_t *f = B.push_flags[B.push_rank] + B.push_wait_index + lane;
+    const uint64_t t0 = wall_clock64();
+    uint32_t polls = 0;
+    // relaxed: nothing the flag guards is READ by this kernel (it only must not overwrite too early), and an acquire at system
+    // scope would invalidate the caches on every poll
+    while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - B.push_wait_seq) < 0) {
+      if (++polls < 128) __builtin_amdgcn_s_sleep(8);
+      else __builtin_amdgcn_s_sleep(127);
+      if (wall_clock64() - t0 > 1000000000ull) {
+        if (B.push_timed_out) __hip_atomic_store(B.push_timed_out, B.push_wait_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+}
+
+// The same wait split in two, for the env-step kernels: the flags are LOADED at the head of the kernel (lanes 0 .. world - 1 of
+// the calling wave) and LOOKED AT at its end, so that the round trip to the (uncached) flag words overlaps the kernel's own
+// work instead of delaying one of its waves; only if some rank's rows of two steps ago have still not arrived does the wave
+// spin.  What it holds back is the row-writing kernel queued behind this one.
+__device__ __forceinline__ uint32_t push_wait_peek(const AgxEnvBuffers &B) {
+  if (B.push_world <= 0 || B.push_wait_seq == 0u) return 0u;
+  const int lane = (int)(threadIdx.x & 63u);
+  if (lane >= B.push_world) return B.push_wait_seq;
+  return __hip_atomic_load(B.push_flags[B.push_rank] + B.push_wait_index + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void push_wait_finish(const AgxEnvBuffers &B, uint32_t peeked) {
+  if (B.push_world <= 0 || B.push_wait_seq == 0u) return;
+  if ((int32_t)(peeked - B.push_wait_seq) < 0) push_wait_for_slot(B);  // (lanes whose flag had arrived pass straight through)
 }
 
 __device__ __forceinline__ void step_rows_signal(const AgxEnvBuffers &B) {
-  if (B.step_signal == nullptr) return;
+  if (B.step_signal == nullptr || B.push_world > 0) return;  // (peer push: nothing to wait for or publish inside this kernel)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the row stores above
   __builtin_amdgcn_s_waitcnt(0);                          // hardware: all of this wave's stores acknowledged
   __syncthreads();                                        // ... and those of the other waves of the workgroup
   if (threadIdx.x == 0) {
+    uint32_t *counter = B.step_signal + 2;
     const uint32_t groups = gridDim.x * gridDim.y * gridDim.z;
-    const uint32_t arrived = __hip_atomic_fetch_add(B.step_signal + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t arrived = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     if (arrived == groups) {
-      __hip_atomic_store(B.step_signal + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (same stream)
-      __hip_atomic_store(B.step_signal + B.flag_parity, (uint32_t)agx::step_index(B) + 1u, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch (same stream)
+      __hip_atomic_store(B.step_signal + B.flag_parity, (uint32_t)agx::step_index(B) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -265,6 +265,49 @@ class EnvManager(BaseManager):
         B.step_signal = _lib.dptr(signal) if signal is not None else None
         self._step_rows = (rows, reward, signal)  # keep alive
 
+    # ---- peer push of the exchange rows by the observation kernels themselves (sharding.StepGather, backend "peer_push") ----
+    _push = None
+
+    def bind_peer_push(self, recv_ptrs, flag_ptrs, rank, world, slots, row_len, reward, signal, timed_out_ptr):
+        """recv_ptrs / flag_ptrs: the addresses IN THIS PROCESS of every rank's receive buffer [slots][world][N][row_len] and
+        flag array [slots][world] (agx_exchange_push_peers).  From now on every step's rows are stored by the row-writing
+        kernels into slot (seq - 1) % slots of EVERY rank's buffer (AgxEnvBuffers.push_*): no launch and no host call per
+        step for the exchange; `_advance_push()` moves the sequence number once per env step."""
+        self._require_device()
+        if world > 8:
+            raise ValueError("peer push from the kernels covers one node (at most 8 ranks)")
+        B = self._buffers
+        peers = [w for w in range(world) if w != rank]
+        for j in range(7):
+            B.push_delta[j] = (recv_ptrs[peers[j]] - recv_ptrs[rank]) if j < len(peers) else 0
+        for w in range(8):
+            B.push_flags[w] = flag_ptrs[w] if w < world else None
+        B.push_world, B.push_rank = world, rank
+        B.push_seq = B.push_wait_seq = 0
+        B.push_flag_index = B.push_wait_index = 0
+        B.push_timed_out = timed_out_ptr
+        B.step_reward = _lib.dptr(reward)
+        B.step_signal = _lib.dptr(signal)  # word [2]: the row-writing kernels' workgroup arrival counter
+        B.push_base, B.push_slice_bytes, B.push_slots = recv_ptrs[rank], self.num_envs * row_len * 4, slots
+        self._push = dict(rank=rank, world=world, slots=slots)
+        B.step_rows[0] = B.step_rows[1] = recv_ptrs[rank] + rank * B.push_slice_bytes  # slot 0 until the first step
+        self._step_rows = (None, reward, signal)  # keep alive
+
+    def unbind_peer_push(self):
+        if self._push is not None:
+            B = self._buffers
+            B.push_world = 0
+            B.push_seq = B.push_wait_seq = 0
+            B.step_rows[0] = B.step_rows[1] = None
+            B.step_signal = None
+            self._push = None
+
+    def _advance_push(self):
+        """new env step: the slot its rows go to, the sequence number that will announce them, and the step (two back) whose
+        arrival from every rank the step waits for before anything is overwritten (agx_push_advance; the position task's
+        one-call step does this inside the library)"""
+        _lib.check(self._lib.agx_push_advance(self._buffers), "agx_push_advance")
+
     # ------------------------------------------------------------------ helpers
     def _stream(self):
         """torch's current stream on this device.  Looked up once per public call (step / reset / render ...):
@@ -510,7 +553,11 @@ class EnvManager(BaseManager):
         self._buffers.flag_parity = self._parity
         # counter word of the per-step device RNG streams (disturbance, observation / LiDAR noise, IMU)
         self._buffers.step_counter = self.step_counter & 0x7FFFFFFF
+        if self._push is not None:
+            self._advance_push()
         self.simulate(actions, env_actions, k)
+        if self._push is not None:
+            self._buffers.push_wait_seq = 0  # the env-step kernel has waited for the row slot; the kernels behind it need not
         self.step_counter += 1
 
     def compute_observations(self):

@@ -14,7 +14,13 @@ latency bound on a fully connected xGMI node -- hence
     communicator of its own (csrc/agx_exchange.hip, `backend="rccl_thread"`): the stepping thread
     pays one event record + one stream wait per step.  Going through torch's process group
     (`backend="process_group"`, the only choice on CPU/gloo) costs 27 us of host time per step --
-    more than the 18 us dynamics-only step itself (profiles/r01_exchange_probe.txt).
+    more than the 18 us dynamics-only step itself (profiles/r01_exchange_probe.txt);
+  * `backend="peer_push"` (round 3, what "auto" picks on HIP devices) runs NO collective kernel per step: every rank
+    stores its rows straight into every peer's receive buffer (mapped through hipIpcMemHandle, one xGMI link per
+    destination) and raises an arrival flag there; the consumer's stream waits on its own flags.  An RCCL all-gather
+    costs 12.5 us per launch even in a world of one -- as long as the dynamics-only step -- and consecutive gathers
+    serialise on the communication stream; the push kernel moves 0.5 MB per destination and nothing else.  RCCL /
+    torch.distributed carry only the set-up (the 128 handle bytes per rank).
 """
 import ctypes as C
 import os
@@ -83,14 +89,35 @@ class StepGather:
         self.signal = None
         if ready not in ("signal", "event"):
             raise ValueError(f"unknown ready mode {ready!r}")
-        if backend not in ("auto", "process_group", "rccl_thread"):
+        if backend not in ("auto", "process_group", "rccl_thread", "peer_push"):
             raise ValueError(f"unknown exchange backend {backend!r}")
-        if backend == "rccl_thread" and not (self.collective and self.device.type == "cuda"):
-            raise RuntimeError("backend='rccl_thread' needs an initialised process group and a HIP device")
-        if self.collective and self.device.type == "cuda" and backend != "process_group" and (
+        if backend in ("rccl_thread", "peer_push") and not (self.collective and self.device.type == "cuda"):
+            raise RuntimeError(f"backend={backend!r} needs an initialised process group and a HIP device")
+        self._push = False
+        self._posts = 0
+        self._slot_of_parity = [0, 0]
+        if self.collective and self.device.type == "cuda" and backend in ("auto", "peer_push") and (
+                backend == "peer_push" or "nccl" in str(dist.get_backend(group))):
+            self._native = self._create_push(required=backend == "peer_push")
+            self._push = self._native is not None
+        if self._native is None and self.collective and self.device.type == "cuda" and backend in ("auto", "rccl_thread") and (
                 backend == "rccl_thread" or "nccl" in str(dist.get_backend(group))):  # "auto" never picks it over gloo
             self._native = self._create_native(required=backend == "rccl_thread")
-        self.backend = "rccl_thread" if self._native is not None else ("process_group" if self.collective else "none")
+        self.backend = ("peer_push" if self._push else "rccl_thread") if self._native is not None else ("process_group" if self.collective else "none")
+        self.lag = 1            # exchange(overlap=True) returns the rows of `lag` steps ago
+        self._kernel_push = False
+        if env is not None and self._push and not getattr(env, "rows_written_twice_per_step", False):
+            # the observation kernels store their rows at every destination themselves: nothing per step on the host, no
+            # launch, no worker thread; the buffer of TWO steps ago is complete by construction when a step's kernels ran
+            recv, flags, tout = (C.c_void_p * self.world)(), (C.c_void_p * self.world)(), C.c_void_p()
+            from . import _lib
+
+            _lib.check(self._lib.agx_exchange_push_peers(self._native, recv, flags, C.byref(tout)), "agx_exchange_push_peers")
+            self.signal = torch.zeros(4, dtype=torch.int32, device=device)
+            env.bind_peer_push([int(x) for x in recv], [int(x) for x in flags], dist.get_rank(self.group), self.world, self.push_slots,
+                               self.obs_dim + 3, reward, self.signal, tout.value)
+            self._kernel_push, self.lag = True, 2
+            return
         if env is not None:
             if getattr(env, "rows_written_twice_per_step", False):
                 # return_state_before_reset: the observation kernel runs before AND after the reset, each publishing the
@@ -140,6 +167,58 @@ class StepGather:
         self._ptr = [(self.rows[p].data_ptr(), self.gathered[p].data_ptr()) for p in (0, 1)]  # tensor indexing costs microseconds
         return handle
 
+    def _agree(self, ok):
+        """all ranks learn whether every rank got this far (control traffic on whatever the process group runs on)"""
+        ctl = self.device if "nccl" in str(dist.get_backend(self.group)) else torch.device("cpu")
+        t = torch.tensor([1 if ok else 0], device=ctl, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1, ctl
+
+    def _create_push(self, required):
+        """peer push: allocate this rank's receive buffer, trade the IPC handles, map the peers' buffers"""
+        from . import _lib
+
+        lib = _lib.load()
+        self._lib = lib
+        self._count = self.n * (self.obs_dim + 3)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        handle = C.c_void_p()
+        rc = lib.agx_exchange_create_push(dist.get_rank(self.group), self.world, index, self._count, C.byref(handle))
+        err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
+        mine = (C.c_char * 128)()
+        if rc == 0:
+            rc = lib.agx_exchange_push_export(handle, mine, 128)
+            err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
+        ok, ctl = self._agree(rc == 0)
+        if ok:
+            all_h = torch.zeros(self.world * 128, dtype=torch.uint8, device=ctl)
+            dist.all_gather_into_tensor(all_h, torch.tensor(list(mine.raw), dtype=torch.uint8, device=ctl), group=self.group)
+            if ctl.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            raw = bytes(all_h.cpu().tolist())
+            rc = lib.agx_exchange_push_connect(handle, raw, len(raw))
+            err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
+            ok, _ = self._agree(rc == 0)
+        if not ok:
+            if handle.value:
+                lib.agx_exchange_destroy(handle)
+            if required:
+                raise RuntimeError(f"peer_push exchange unavailable on some rank ({err or 'see the other ranks'})")
+            return None
+        recv, slots, unc = C.c_void_p(), C.c_int(), C.c_int()
+        _lib.check(lib.agx_exchange_push_buffer(handle, C.byref(recv), C.byref(slots), C.byref(unc)), "agx_exchange_push_buffer")
+        self.push_slots, self.push_flags_uncached = slots.value, bool(unc.value)
+
+        class _Mem:  # the library's allocation as a tensor (no copy): [slots, world * N, obs_dim + 3]
+            __cuda_array_interface__ = {"shape": (slots.value, self.world * self.n, self.obs_dim + 3), "typestr": "<f4",
+                                        "data": (recv.value, False), "version": 2, "strides": None}
+
+        self._push_mem = _Mem()
+        self.gathered = torch.as_tensor(self._push_mem, device=self.device)
+        self._ptr = [(self.rows[p].data_ptr(), None) for p in (0, 1)]
+        dist.barrier(group=self.group)  # nobody posts before every rank has mapped every buffer
+        return handle
+
     def comm_info(self):
         """(rank, world size) as the exchange's communicator reports them (ncclCommUserRank / ncclCommCount) for
         `rccl_thread`, the process group's for `process_group`, (0, 1) without a collective."""
@@ -156,6 +235,15 @@ class StepGather:
     def close(self):
         """Drains and frees the library-side communicator (collective-free, but call it on every rank)."""
         h, self._native = self._native, None
+        if h is not None and self._kernel_push:
+            torch.cuda.synchronize(self.device)
+            if dist.is_initialized():
+                try:
+                    dist.barrier(group=self.group)  # no rank unmaps a buffer a peer's kernels may still be storing into
+                except Exception:  # noqa: BLE001  (a peer that is already gone)
+                    pass
+            self._env.unbind_peer_push()
+            self._kernel_push = False
         if h is not None:
             self._lib.agx_exchange_destroy(h)  # drains the communication stream
             if self.signal is not None and self._env is not None:
@@ -177,6 +265,8 @@ class StepGather:
         return p
 
     def exchange(self, parity, overlap=False):
+        if self._kernel_push:
+            return self._exchange_kernel_push(parity, overlap)
         if self._native is not None:
             return self._exchange_native(parity, overlap)
         if self.collective:
@@ -192,6 +282,22 @@ class StepGather:
         self.wait(prev)
         return self.gathered[prev]
 
+    def _exchange_kernel_push(self, parity, overlap):
+        """rows pushed by the observation kernels (env.bind_peer_push): `overlap` returns the rows of TWO steps ago -- complete
+        once the stream has run this step's kernels, which waited for exactly that -- at no cost; the synchronous form puts a
+        one-wave flag wait for THIS step's rows on the stream"""
+        seq = self._env._buffers.push_seq
+        if (seq & 255) == 0:  # a device-side wait that gave up (10 s) says so through a host-visible word
+            from . import _lib
+
+            _lib.check(self._lib.agx_exchange_check(self._native), "agx_exchange_check")
+        if not overlap:
+            from . import _lib
+
+            _lib.check(self._lib.agx_exchange_push_wait_seq(self._native, seq & 0xFFFFFFFF, self._env._stream()), "agx_exchange_push_wait_seq")
+            return self.gathered[(seq - 1) % self.push_slots]
+        return self.gathered[(seq - 3) % self.push_slots] if seq > 2 else None
+
     def _exchange_native(self, parity, overlap):
         from . import _lib
 
@@ -203,6 +309,13 @@ class StepGather:
         else:
             prev = wait_parity = parity
         send, recv = self._ptr[parity]
+        if os.environ.get("AGX_EXCHANGE_NO_WAIT") == "1":  # experiment: what the per-step wait on the stepping stream costs
+            wait_parity = -1
+        if self._push:  # the rows gathered by the s-th post lie in slot (s - 1) % slots of the exchange's own buffer
+            self._posts += 1
+            new_slot = (self._posts - 1) % self.push_slots
+            prev_slot = new_slot if not overlap else (self._slot_of_parity[prev] if prev is not None else None)
+            self._slot_of_parity[parity] = new_slot
         if self.signal is not None:  # the kernels of the step just enqueued publish signal[parity] = step_counter
             rc = self._lib.agx_exchange_step(self._native, parity, send, recv, self._count, self._signal_ptr,
                                              self._env.step_counter & 0x7FFFFFFF, wait_parity, stream)
@@ -210,9 +323,19 @@ class StepGather:
             rc = self._lib.agx_exchange_step(self._native, parity, send, recv, self._count, None, 0, wait_parity, stream)
         if rc:
             _lib.check(rc, "agx_exchange_step")
-        return None if prev is None else self.gathered[prev]
+        if prev is None:
+            return None
+        return self.gathered[prev_slot] if self._push else self.gathered[prev]
 
     def wait(self, parity):
+        if self._kernel_push:  # everything pushed so far has arrived (parity has no meaning here: the slots are sequence numbers)
+            seq = self._env._buffers.push_seq
+            if seq > 0:
+                from . import _lib
+
+                _lib.check(self._lib.agx_exchange_push_wait_seq(self._native, seq & 0xFFFFFFFF, torch.cuda.current_stream(self.device).cuda_stream),
+                           "agx_exchange_push_wait_seq")
+            return
         if self._native is not None:
             from . import _lib
 

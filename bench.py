@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "process_group", "rccl_thread"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "process_group", "rccl_thread", "peer_push"],
                     help="N > 1: who enqueues the per-step all-gather. auto = time both (torch's process group first, then the "
                          "library's RCCL worker thread under a watchdog) and report the faster one as `value`")
     ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
@@ -482,11 +482,12 @@ def exchange_diagnostics(task, actions, args, world, gather_buf, dt_with):
             "note": "rank 0's clock; the exchange of step t runs on RCCL's stream while step t+1 computes"}
 
 
-def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
-    """Second pass of the N > 1 job with the all-gather enqueued by the library's worker thread on its own
-    RCCL communicator (csrc/agx_exchange.hip) instead of torch's process group: same tasks, same K and W.
-    The faster of the two becomes `value`; both are reported.  A watchdog prints the line measured so far
-    and ends the process if this leg does not finish (a second communicator cannot be recovered in-process)."""
+def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0):
+    """Another pass of the N > 1 job with the per-step exchange run by the simulator library (csrc/agx_exchange.hip) instead
+    of torch's process group: `peer_push` (rows stored straight into the peers' receive buffers, no collective kernel per
+    step) or `rccl_thread` (an RCCL all-gather enqueued by the library's worker thread on its own communicator): same tasks,
+    same K and W.  The fastest leg becomes `value`; all are reported.  A watchdog prints the line measured so far and ends
+    the process if the leg does not finish (a half-built exchange cannot be recovered in-process)."""
     import threading
 
     import torch.distributed as dist
@@ -494,14 +495,14 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
 
     n_gpus = max(world, 1)
     report = out.setdefault("exchange", {})
-    report["process_group"] = {"value": out["value"], "ms_per_step": out["ms_per_step"],
-                               "plus_depth_value": out.get("plus_depth", {}).get("value"),
-                               "plus_depth_ms_per_step": out.get("plus_depth", {}).get("ms_per_step")}
+    report.setdefault("process_group", {"value": out["value"], "ms_per_step": out["ms_per_step"],
+                                        "plus_depth_value": out.get("plus_depth", {}).get("value"),
+                                        "plus_depth_ms_per_step": out.get("plus_depth", {}).get("ms_per_step")})
 
     res = {}
 
     def give_up():
-        report["rccl_thread"] = dict(res, error=res.get("error", "") + f" [no agreement of the ranks within {limit_s:.0f} s]")
+        report[backend] = dict(res, error=res.get("error", "") + f" [no agreement of the ranks within {limit_s:.0f} s]")
         if rank == 0:
             emit_line(out, _JSON_FD[0])
         os._exit(0)
@@ -516,11 +517,12 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
         N, A = task.num_envs, task.task_config.action_space_dim
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
-        gb = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards, backend="auto")
+        gb = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards, backend=backend)
         res["backend"] = gb.backend
-        if gb.backend != "rccl_thread":
-            raise RuntimeError("the library-side exchange could not be set up on every rank")
-        res["communicator"] = dict(zip(("rank", "ranks"), gb.comm_info()))  # as ncclCommUserRank / ncclCommCount report them
+        res["producer_hand_off"] = "device flag (step_signal)" if gb.signal is not None else "event"
+        if backend == "peer_push":
+            res["flags_in_uncached_memory"] = gb.push_flags_uncached
+        res["communicator"] = dict(zip(("rank", "ranks"), gb.comm_info()))  # ncclCommUserRank / ncclCommCount, or the ranks whose buffers were mapped
         if res["communicator"]["ranks"] != max(world, 1):
             raise RuntimeError(f"the exchange communicator spans {res['communicator']['ranks']} ranks, the job has {world}")
         if os.environ.get("AGX_BENCH_INJECT_EXCHANGE_FAILURE") == str(rank):  # exercises the abandon path below
@@ -535,7 +537,7 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
             t2.reset()
             a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
             s2 = min(max(args.steps // 10, 20), 300)
-            gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards, backend="rccl_thread")
+            gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards, backend=backend)
             dt2 = timed_steps(t2, a2, s2, max(args.warmup // 10, 5), world, gb2, overlap=not args.sync_gather)
             res.update(plus_depth_value=n_gpus * N * s2 / dt2, plus_depth_ms_per_step=1e3 * dt2 / s2)
             gb2.close()
@@ -549,19 +551,22 @@ def rccl_thread_leg(args, world, rank, device, out, limit_s=240.0):
     dog.cancel()
     if not all_ok and "error" not in res:
         res["error"] = "another rank failed"
-    report["rccl_thread"] = res
+    report[backend] = res
     if not all_ok:
         # whatever is left of this leg (a communicator some rank never joined, a device-side wait nobody will
         # release) must not get a chance to block a destructor before rank 0 has printed: keep it alive and let
         # main() leave through os._exit right after the line
         _ABANDONED.append(dict(locals()))
         return False
+    how = {"peer_push": "peer push (rows stored into the peers' receive buffers over xGMI, no collective kernel per step)",
+           "rccl_thread": "1 RCCL all_gather/step enqueued by the library's worker thread"}[backend]
     if "value" in res and res["value"] > out["value"]:
         out["value"], out["ms_per_step"] = res["value"], res["ms_per_step"]
-        out["config"]["sharding"] = out["config"]["sharding"].replace("enqueued by process_group", "enqueued by rccl_thread (library worker thread)")
+        out["config"]["sharding"] = f"envs x{n_gpus}, [N, obs_dim+3] rows per step: {how}, " + ("synchronous" if args.sync_gather else "overlapped with the next step")
+        out["config"]["exchange_backend"] = backend
     if "plus_depth_value" in res and "plus_depth" in out and res["plus_depth_value"] > out["plus_depth"]["value"]:
         out["plus_depth"]["value"], out["plus_depth"]["ms_per_step"] = res["plus_depth_value"], res["plus_depth_ms_per_step"]
-        out["plus_depth"]["exchange"] = "rccl_thread"
+        out["plus_depth"]["exchange"] = backend
     return True
 
 
@@ -685,7 +690,7 @@ def main():
     gather_buf = None
     from aerial_gym_simulator_amd.sharding import StepGather
 
-    primary_backend = "rccl_thread" if args.exchange == "rccl_thread" else "process_group"
+    primary_backend = args.exchange if args.exchange in ("rccl_thread", "peer_push") else "process_group"
     if use_dist:
         gather_buf = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards,
                                 backend=primary_backend)
@@ -829,7 +834,8 @@ def main():
             del t2, gb2
         except NameError:
             pass
-        rccl_thread_leg(args, world, rank, device, out)
+        if library_exchange_leg(args, world, rank, device, out, "peer_push"):
+            library_exchange_leg(args, world, rank, device, out, "rccl_thread")
     if rank == 0:
         emit_line(out, json_fd)
     if _ABANDONED:  # every rank took the same decision (all-reduced): no teardown of a half-built exchange

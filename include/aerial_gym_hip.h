@@ -154,6 +154,29 @@ typedef struct AgxEnvBuffers {
      counter).  The exchange's communication stream spins on it (agx_exchange_post, signal != NULL)
      instead of a cross-queue event: no host call per step for the producer side.                   */
   uint32_t *step_signal;
+  /* optional PEER PUSH of the exchange rows (agx_exchange_create_push): step_rows[flag_parity] then points at THIS rank's own
+     slice of a slot of its receive buffer, and every row store is repeated at the same offset in each peer's buffer
+     (address + push_delta[j]: the peers' buffers are mapped into this process through hipIpcMemHandle) -- the rows of all
+     ranks meet in every rank's buffer with no collective and no extra launch.  The last workgroup of a row-writing kernel
+     then stores push_seq into entry push_flag_index of every rank's flag array (system-scope release).  Before its first
+     row store such a kernel waits (device side, bounded) until entries push_wait_index .. + push_world of its OWN flag array
+     have reached push_wait_seq: the slot it is about to overwrite has been vacated by every rank (0 = no wait).          */
+  int64_t push_delta[7];       /* byte offsets own receive buffer -> peer j's, j < push_world - 1                           */
+  uint32_t *push_flags[8];     /* flag arrays of ranks 0 .. push_world - 1 (own included), [slots][world] each             */
+  int32_t push_world;          /* 0 = no peer push                                                                        */
+  int32_t push_rank;
+  int32_t push_flag_index;     /* slot * world + rank of this step                                                        */
+  int32_t push_wait_index;     /* wait_slot * world                                                                       */
+  int32_t push_pub_index;      /* flag entry of the PREVIOUS step's rows (published by the head of this step's first kernel) */
+  uint32_t push_pub_seq;       /* ... and their sequence number (0 = nothing to publish)                                  */
+  uint32_t push_seq;           /* sequence number of this step's rows (1, 2, ...)                                         */
+  uint32_t push_wait_seq;
+  uint32_t *push_timed_out;    /* device-visible host word: a wait that gave up stores the sequence number it waited for  */
+  char *push_base;             /* this rank's receive buffer [push_slots][push_world][N][row]; with push_slice_bytes = N * row * 4
+                                  and push_slots it lets agx_push_advance (called by agx_position_task_step) move to the next
+                                  step without the host touching a field                                                  */
+  int64_t push_slice_bytes;
+  int32_t push_slots;
   float *body_force;     /* optional [3][N]: net applied (non-gravitational) force of the LAST sub-step in
                             the body frame = allocator output + drag + disturbance; read by agx_imu_update */
   const int32_t *step_counter_dev; /* optional, device memory: when set the kernels read the env-step index from here
@@ -585,6 +608,33 @@ int agx_exchange_step(AgxExchange *x, int parity, const float *send, float *recv
                       void *stream);
 int agx_exchange_info(AgxExchange *x, int *rank, int *world);
 int agx_exchange_destroy(AgxExchange *x);
+
+/* Peer push (round 3): the same exchange WITHOUT a collective kernel per step.  Every rank stores its rows straight into
+ * every peer's receive buffer (peer memory mapped through hipIpcMemHandle: one xGMI link per destination) and raises a
+ * per-sender arrival flag there; the consumer's stream waits on its own flags.  post / wait / step / probe / info / destroy
+ * are the entry points above (post ignores `recv`: the receive buffer belongs to the exchange; wait launches a one-wave flag
+ * wait on `stream` instead of a cross-queue event wait).
+ *   agx_exchange_create_push:  allocates this rank's receive buffer [slots][world][count_per_rank] and flags; not collective.
+ *   agx_exchange_push_export:  2 x 64 bytes (hipIpcMemHandle of buffer and flags) for the peers; the host mirror all-gathers
+ *                              them through torch.distributed.
+ *   agx_exchange_push_connect: maps the peers' buffers (world x 128 bytes, rank-major); after it posts are allowed.
+ *   agx_exchange_push_buffer:  this rank's receive buffer and slot count: the rows gathered by the s-th post (s = 1, 2, ...)
+ *                              lie in slot (s - 1) % slots once agx_exchange_wait for that post's parity has passed.       */
+int agx_exchange_create_push(int rank, int world, int device, size_t count_per_rank, AgxExchange **out);
+int agx_exchange_push_export(AgxExchange *x, void *handles_out, int bytes);
+int agx_exchange_push_connect(AgxExchange *x, const void *all_handles, int bytes);
+int agx_exchange_push_buffer(AgxExchange *x, void **recv, int *slots, int *flags_uncached);
+/* Rows pushed by the observation kernels THEMSELVES (AgxEnvBuffers.push_*: no launch and no host call per step for the
+ * exchange): agx_exchange_push_peers hands out the addresses, in this process, of every rank's receive buffer and flag array
+ * ([world] each, own included) and the device-visible time-out word; agx_exchange_push_wait_seq makes `stream` wait until
+ * the rows with sequence number `seq` of every rank have arrived here.                                                   */
+/* Peer push by the kernels: a new env step -- next sequence number, its slot (step_rows), the step (two back) to wait for.
+ * agx_position_task_step calls it itself; callers of agx_env_step call it once per env step before the launch.           */
+int agx_push_advance(AgxEnvBuffers *buf);
+int agx_exchange_push_peers(AgxExchange *x, void **recv_out, void **flags_out, void **timed_out);
+int agx_exchange_push_wait_seq(AgxExchange *x, uint32_t seq, void *stream);
+/* Has anything gone wrong so far (worker thread; a bounded device-side wait that gave up)?  Two host reads.            */
+int agx_exchange_check(AgxExchange *x);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_world2_exchange.py::test_rccl_thread_exchange_world2_*: one of TWO processes sharing the box's
-single GPU.  torch.distributed runs on gloo (control traffic only); the library-side exchange (csrc/agx_exchange.hip:
+"""Worker of tests/test_gpu_world2_exchange.py::test_{rccl_thread,peer_push}_exchange_world2_*: one of TWO processes sharing the box's
+single GPU (AGX_TEST_EXCHANGE_BACKEND=peer_push: the rows travel through peer-mapped memory, no RCCL and no double involved).  torch.distributed runs on gloo (control traffic only); the library-side exchange (csrc/agx_exchange.hip:
 worker thread, communication stream, device-flag hand-off, done events) binds tests/fakerccl/libfakerccl.so through
 AGX_RCCL_PATH, a stream-ordered shared-memory all-gather, because RCCL refuses two ranks on one device.
 
@@ -35,8 +35,9 @@ task = task_registry.make_task("position_setpoint_task", seed=10 + rank, num_env
 task.reset()
 d = task.task_obs["observations"].shape[1]
 ready = "event" if mode == "event" else "signal"
-sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend="rccl_thread", ready=ready)
-assert sg.backend == "rccl_thread"
+BACKEND = os.environ.get("AGX_TEST_EXCHANGE_BACKEND", "rccl_thread")  # "peer_push": real hipIpcMemHandle mapping between the two processes
+sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready)
+assert sg.backend == BACKEND
 assert sg.comm_info() == (rank, world), sg.comm_info()  # what the communicator itself reports
 if ready == "signal":
     assert sg.signal is not None, "the device-flag hand-off was not available (probe failed)"
@@ -47,7 +48,8 @@ W = d + 3
 own_sum = torch.zeros(steps, dtype=torch.int64, device=DEV)       # checksum of the rows THIS rank sent at step t
 got_sum = torch.zeros(steps, world, dtype=torch.int64, device=DEV)  # checksum of every rank's slice received for step t
 own_ok = torch.ones((), dtype=torch.bool, device=DEV)
-sent_prev = None
+lag = sg.lag if overlap else 0  # the overlapped form hands back the rows of `lag` steps ago (2 when the kernels push the rows themselves)
+history = []
 try:
     for t in range(steps):
         obs, rew, term, trunc, _ = task.step(actions[t % 8])
@@ -56,12 +58,15 @@ try:
         # stream-ordered bookkeeping, no host synchronisation inside the loop
         mine = torch.cat([obs["observations"], rew[:, None], term[:, None].float(), trunc[:, None].float()], dim=1)
         own_sum[t] = mine.view(torch.int32).long().sum()  # bit patterns, exact and order-independent
-        ref_t = t - 1 if overlap else t
+        ref_t = t - lag
+        history.append(mine)
         if out is not None:
+            assert ref_t >= 0
             got_sum[ref_t] = out.view(torch.int32).view(world, n, W).long().sum(dim=(1, 2))
-            expect = sent_prev if overlap else mine
-            own_ok &= torch.equal(out.view(world, n, W)[rank], expect)
-        sent_prev = mine
+            own_ok &= torch.equal(out.view(world, n, W)[rank], history[ref_t - t - 1])
+        elif overlap:
+            assert t < lag
+        history = history[-3:]
         if mode == "fail" and t % 16 == 0:
             torch.cuda.synchronize()
     sg.flush()
@@ -75,7 +80,7 @@ if mode == "fail":
     print(f"rank {rank}: no failure surfaced", flush=True)
     os._exit(4)
 assert bool(own_ok), "own slice of the gathered buffer differs from the rows this rank sent"
-last = steps - 1 if overlap else steps
+last = steps - lag
 # every rank's checksum of what it SENT, exchanged over gloo, against what each rank RECEIVED
 sent = [torch.zeros(steps, dtype=torch.int64) for _ in range(world)]
 dist.all_gather(sent, own_sum.cpu())

@@ -28,15 +28,16 @@ def world_of_one():
     dist.destroy_process_group()
 
 
-def test_rccl_thread_exchange_matches_process_group(world_of_one):
+@pytest.mark.parametrize("library_backend", ["rccl_thread", "peer_push"])
+def test_library_exchange_matches_process_group(world_of_one, library_backend):
     from aerial_gym_simulator_amd.sharding import StepGather
 
     dev = torch.device("cuda:0")
     n, d = 1000, 13
-    a = StepGather(n, d, dev, backend="rccl_thread")
+    a = StepGather(n, d, dev, backend=library_backend)
     b = StepGather(n, d, dev, backend="process_group")
-    assert a.backend == "rccl_thread" and b.backend == "process_group"
-    assert StepGather(n, d, dev).backend == "rccl_thread"  # what "auto" picks on RCCL
+    assert a.backend == library_backend and b.backend == "process_group"
+    assert StepGather(n, d, dev).backend == "peer_push"  # what "auto" picks on a HIP device (rccl_thread if it cannot be set up)
     g = torch.Generator(device=dev).manual_seed(3)
     # synchronous form: this step's rows
     for step in range(6):
@@ -68,12 +69,14 @@ def test_rccl_thread_exchange_matches_process_group(world_of_one):
     a.flush()
     b.flush()
     torch.cuda.synchronize()
-    assert torch.equal(a.gathered[1], sent[-1]) and torch.equal(b.gathered[1], sent[-1])
+    last_a = a.gathered[a._slot_of_parity[1]] if a.backend == "peer_push" else a.gathered[1]  # (peer push: four receive slots)
+    assert torch.equal(last_a, sent[-1]) and torch.equal(b.gathered[1], sent[-1])
     a.close()
     a.close()  # idempotent
 
 
-def test_rccl_thread_exchange_orders_against_the_stepping_stream(world_of_one):
+@pytest.mark.parametrize("library_backend", ["rccl_thread", "peer_push"])
+def test_library_exchange_orders_against_the_stepping_stream(world_of_one, library_backend):
     """2000 back-to-back steps on a side stream: every gathered buffer must hold exactly the rows of its step
     (the rows are rewritten by the very next-but-one step, so a missing stream dependency shows up as a
     newer or older counter)."""
@@ -81,7 +84,7 @@ def test_rccl_thread_exchange_orders_against_the_stepping_stream(world_of_one):
 
     dev = torch.device("cuda:0")
     n, d = 8192, 13
-    x = StepGather(n, d, dev, backend="rccl_thread")
+    x = StepGather(n, d, dev, backend=library_backend)
     side = torch.cuda.Stream(device=dev)
     seen = torch.zeros(2000, device=dev)
     with torch.cuda.stream(side):
@@ -92,7 +95,7 @@ def test_rccl_thread_exchange_orders_against_the_stepping_stream(world_of_one):
             if buf is not None:
                 seen[step - 1] = buf[::97].max() + buf[::89].min()  # both == step - 1
         x.flush()
-        last = x.gathered[1].clone()
+        last = (x.gathered[x._slot_of_parity[1]] if x.backend == "peer_push" else x.gathered[1]).clone()
     side.synchronize()
     assert torch.equal(seen[:-1].cpu(), 2.0 * torch.arange(1999, dtype=torch.float32))
     assert float(last.min()) == float(last.max()) == 1999.0
@@ -119,7 +122,8 @@ def test_exchange_argument_errors(world_of_one):
 
 @pytest.mark.parametrize("which", ["position", "navigation"])
 @pytest.mark.parametrize("ready", ["signal", "event"])
-def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
+@pytest.mark.parametrize("library_backend", ["rccl_thread", "peer_push"])
+def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library_backend):
     """The rows the observation kernels write travel through the library-side exchange, ordered by the
     kernels' own step_signal flag (or by an event): every gathered buffer is exactly the step's
     obs | reward | terminated | truncated, in the synchronous and in the overlapped form, across resets."""
@@ -139,8 +143,8 @@ def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
         task = task_registry.make_task(which + ("_setpoint_task" if which == "position" else "_task"), seed=5, num_envs=n, headless=True)
         task.reset()
         d = task.task_obs["observations"].shape[1]
-        sg = StepGather(n, d, dev, env=task.sim_env, reward=task.rewards, backend="rccl_thread", ready=ready)
-        assert ready == "signal" or sg.signal is None  # "signal" may fall back to events (agx_exchange_probe)
+        sg = StepGather(n, d, dev, env=task.sim_env, reward=task.rewards, backend=library_backend, ready=ready)
+        assert ready == "signal" or sg.signal is None or sg._kernel_push  # "signal" may fall back to events (agx_exchange_probe)
         g = torch.Generator(device=dev).manual_seed(9)
         acts = [torch.rand(n, 4, device=dev, generator=g) * 2 - 1 for _ in range(4)]
 
@@ -155,41 +159,41 @@ def test_rccl_thread_exchange_of_a_stepping_task(world_of_one, which, ready):
             assert torch.equal(got, want), (which, ready, step)
         sg.flush()
         sg._last = None
-        prev, checks, truncs = None, [], 0
+        hist, checks, truncs = [], [], 0  # (sg.lag: the overlapped form returns the rows of 1 step ago, 2 when the kernels push them)
         for step in range(steps):  # overlapped form, no host synchronisation inside the loop
             ret = task.step(acts[step & 3])
-            cur = snapshot(ret)
+            hist.append(snapshot(ret))
             truncs += int(ret[3].sum()) if step % 5 == 0 else 0
             buf = sg.exchange(task.sim_env._parity, overlap=True)
-            if prev is not None:
-                checks.append((buf.clone(), prev))
-            prev = cur
+            if len(hist) > sg.lag:
+                checks.append((buf.clone(), hist[-1 - sg.lag]))
         sg.flush()
         torch.cuda.synchronize()
-        assert len(checks) == steps - 1
+        assert len(checks) == steps - sg.lag
         for step, (got, want) in enumerate(checks):
             assert torch.equal(got, want), (which, ready, step)
         if which == "position":
             # long run without any host synchronisation: a row read before it was visible device-wide (the flag
             # protocol of agx_step_signal.h) would show up as a mismatch counted on the device
             bad = torch.zeros((), device=dev, dtype=torch.int64)
-            prev = None
+            hist = []
             sg.flush()
             sg._last = None
             for step in range(2000):
-                cur = snapshot(task.step(acts[step & 3]))
+                hist.append(snapshot(task.step(acts[step & 3])))
                 buf = sg.exchange(task.sim_env._parity, overlap=True)
-                if prev is not None:
-                    bad += (buf != prev).sum()
-                prev = cur
+                if len(hist) > sg.lag:
+                    bad += (buf != hist[-1 - sg.lag]).sum()
+                hist = hist[-3:]
             sg.flush()
             torch.cuda.synchronize()
             assert int(bad) == 0
-        if sg.signal is not None:
+        if sg.signal is not None and not sg._kernel_push:  # (rows pushed by the kernels: flags are raised by the next step's first kernel)
             assert int(sg.signal[2]) == 0  # the arrival counter is back at zero after every launch
             assert int(sg.signal[:2].max()) == task.sim_env.step_counter
+        assert sg._kernel_push == (library_backend == "peer_push")  # the observation kernels push the rows themselves
         sg.close()
-        assert task.sim_env._buffers.step_signal is None
+        assert task.sim_env._buffers.step_signal is None and task.sim_env._buffers.push_world == 0
         task.step(acts[0])  # stepping goes on without the exchange
         torch.cuda.synchronize()
     finally:

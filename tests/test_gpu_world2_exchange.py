@@ -79,6 +79,20 @@ def test_rccl_thread_exchange_world2(mode):
     assert all("ok %d steps" % steps in o for o in outs)
 
 
+@pytest.mark.parametrize("mode", ["signal", "event", "sync", "close_skew"])
+def test_peer_push_exchange_world2(mode):
+    """StepGather(backend="peer_push") at WORLD SIZE 2, two processes on the one GPU, NO test double: each rank's receive
+    buffer and arrival flags are mapped into the other process through hipIpcMemHandle (the path the 8-GPU job takes, there
+    over xGMI), the rows are stored there by k_push_rows and the consumer's stream waits on its own flags -- no collective
+    kernel per step.  Same checks as the RCCL path: 2000 steps, overlapped and synchronous, flag and event hand-off for the
+    producer side; every rank's own slice bit-identical to what it sent; per-step checksums of what rank r sent equal those
+    of rank r's slice in what every rank received (ordering, the four receive slots, the double-buffered rows)."""
+    steps = 2000 if mode in ("signal", "event") else 400
+    codes, outs = _run_world2(mode, steps, extra_env={"AGX_TEST_EXCHANGE_BACKEND": "peer_push"})
+    assert codes == [0, 0], "\n".join(o[-1500:] for o in outs)
+    assert all("ok %d steps" % steps in o for o in outs)
+
+
 def test_rccl_thread_exchange_world2_peer_failure_is_an_error_not_a_hang():
     """Rank 1's 50th collective fails (injected): rank 1 raises from the exchange; rank 0's rendezvous ends with an
     error as well (the double marks the segment failed; a silent peer would hit the 5 s bound) -- both processes end."""
