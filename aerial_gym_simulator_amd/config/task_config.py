@@ -200,3 +200,10 @@ class lidar_navigation_task_config:  # lidar_navigation_task_config.py:5-108
         torch.mul(a[:, 0:3], 2, out=out[:, 0:3])
         torch.mul(a[:, 3], torch.pi / 3, out=out[:, 3])
         return out
+
+
+# the built-in transformations have a one-launch device form (agx_action_transform); a task uses it when the config still
+# carries THE function object below (anything a user puts there instead runs as the torch code it is)
+navigation_task_config.action_transformation_function.agx_kind = (1, 4)
+fully_actuated_lidar_navigation_task_config.action_transformation_function.agx_kind = (3, 7)
+lidar_navigation_task_config.action_transformation_function.agx_kind = (2, 4)

@@ -117,6 +117,47 @@ static Ratio3 ratio3(const float *lo, const float *hi) {
   return r;
 }
 
+// The action transformations the reference's task configs ship (navigation_task_config.py:87-117,
+// lidar_navigation_task_config.py:98-108; the fully actuated set-point map of configs[3]): policy action [N][4] in [-1, 1] ->
+// controller command [N][A_out].  The same arithmetic as the torch functions in config/task_config.py, one launch instead of
+// nine; sine / cosine through sincos_bounded (correctly rounded, like the kernels behind it).
+__global__ void __launch_bounds__(256) k_action_transform(int kind, int n, const float *__restrict__ a_in, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) a[c] = fminf(fmaxf(a_in[(size_t)i * 4 + c], -1.0f), 1.0f);  // torch.clamp(action, -1, 1)
+  if (kind == AGX_ACTION_NAV_VELOCITY) {  // (speed, inclination, yaw rate) -> vehicle-frame velocity command
+    const float speed = a[0] + 1.0f;
+    const float inclination = 0.785398185253143310546875f * a[1];  // float(pi / 4) * a1
+    float sn, cs;
+    sincos_bounded(inclination, sn, cs);
+    float *o = out + (size_t)i * 4;
+    o[0] = speed * cs;
+    o[1] = 0.0f;
+    o[2] = speed * sn;
+    o[3] = a[2] * 1.04719758033752441406f;  // a2 * float(pi / 3)
+  } else if (kind == AGX_ACTION_LIDAR_ACCELERATION) {  // +-2 m/s^2, +-pi/3 rad/s
+    float *o = out + (size_t)i * 4;
+    o[0] = a[0] * 2.0f; o[1] = a[1] * 2.0f; o[2] = a[2] * 2.0f;
+    o[3] = a[3] * 1.04719758033752441406f;
+  } else {  // AGX_ACTION_FULLY_ACTUATED_POSE: position set-point within +-(5, 5, 2.5) m, level attitude at yaw * pi
+    float *o = out + (size_t)i * 7;
+    const float half = (0.5f * 3.14159274101257324f) * a[3];  // (0.5 * torch.pi) as a python float, rounded once, times a3
+    float sn, cs;
+    sincos_bounded(half, sn, cs);
+    o[0] = a[0] * 5.0f; o[1] = a[1] * 5.0f; o[2] = a[2] * 2.5f;
+    o[3] = 0.0f; o[4] = 0.0f; o[5] = sn; o[6] = cs;
+  }
+}
+
+extern "C" int agx_action_transform(int kind, int n, const float *actions_in, float *out, void *stream) {
+  AGX_REQUIRE(kind >= AGX_ACTION_NAV_VELOCITY && kind <= AGX_ACTION_FULLY_ACTUATED_POSE, "agx_action_transform: kind %d", kind);
+  AGX_REQUIRE(n > 0 && actions_in && out, "agx_action_transform: null buffer");
+  hipLaunchKernelGGL(k_action_transform, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, kind, n, actions_in, out);
+  return check_launch("agx_action_transform");
+}
+
 extern "C" int agx_step_counter_advance(const AgxEnvBuffers *B, void *stream) {
   AGX_REQUIRE(B && B->step_counter_dev, "agx_step_counter_advance: buf->step_counter_dev is not set");
   hipLaunchKernelGGL(k_step_counter_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, const_cast<int32_t *>(B->step_counter_dev));

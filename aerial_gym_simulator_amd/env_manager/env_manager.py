@@ -21,6 +21,7 @@ from ..registry.robot_registry import robot_registry
 from ..registry.sim_registry import sim_config_registry
 from ..robots.robot_manager import RobotManagerHIP
 from ..tensors import aos_view, soa, TensorDict
+from ..utils import roctx
 from ..utils.logging import CustomLogger
 from ..utils.random_source import TorchRandomSource
 from .asset_manager import AssetManager
@@ -412,6 +413,7 @@ class EnvManager(BaseManager):
                        "agx_reset_masked")
         self.robot_manager.reset_sensors_masked()
 
+    @roctx.ranged("EnvManager.reset_idx")
     def reset_idx(self, env_ids=None):
         self._require_device()
         self._new_call()
@@ -533,6 +535,7 @@ class EnvManager(BaseManager):
         finally:
             B.launch_flags = 0
 
+    @roctx.ranged("EnvManager.step")
     def step(self, actions, env_actions=None):
         """env_actions: [N, num_assets, 6] obstacle twists (world-frame linear + angular velocity), the
         reference's dynamic-environment interface (env_manager.py:399-416, obstacle_manager.py:40-44)."""
@@ -563,11 +566,13 @@ class EnvManager(BaseManager):
     def compute_observations(self):
         pass  # the collision flag is accumulated inside agx_dynamics_substeps
 
+    @roctx.ranged("EnvManager.post_reward_calculation_step")
     def post_reward_calculation_step(self):
         envs_to_reset = self.reset_terminated_and_truncated_envs()
         self.render(render_components="sensors")
         return envs_to_reset
 
+    @roctx.ranged("EnvManager.render")
     def render(self, render_components="sensors"):
         if render_components == "sensors":
             self.render_sensors()

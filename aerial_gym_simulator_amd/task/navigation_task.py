@@ -16,6 +16,7 @@ from ..sim.sim_builder import SimBuilder
 from ..tensors import aos_view, soa
 from ..utils.logging import CustomLogger
 from ..utils.spaces import Box, Dict
+from ..utils import roctx
 from .base_task import BaseTask
 
 logger = CustomLogger("navigation_task")
@@ -65,6 +66,8 @@ class NavigationTask(BaseTask):
         )
         self.action_space = Box(low=-1.0, high=1.0, shape=(4,), dtype=np.float32)
         self.action_transformation_function = cfg.action_transformation_function
+        self._action_kind = getattr(cfg.action_transformation_function, "agx_kind", None)  # built-in: one launch (agx_action_transform)
+        self._action_out = None
         self.task_obs = {"observations": torch.zeros((N, cfg.observation_space_dim), device=dev)}
         self.num_task_steps = 0
         self.infos = {}
@@ -218,8 +221,9 @@ class NavigationTask(BaseTask):
         return None
 
     # ------------------------------------------------------------------ stepping
+    @roctx.ranged("NavigationTask.step")
     def step(self, actions):
-        transformed_action = self.action_transformation_function(actions)
+        transformed_action = self._transform_action(actions)
         self._in_graph_step = bool(self._graph_mode()) or torch.cuda.is_current_stream_capturing()
         if self._graph_mode():
             return self._step_replayed(transformed_action)
@@ -227,6 +231,17 @@ class NavigationTask(BaseTask):
         ret = self._device_step(transformed_action)
         self._finish_step_host()
         return ret
+
+    def _transform_action(self, actions):
+        kind, env = self._action_kind, self.sim_env
+        if (kind is None or env._buffers is None or not actions.is_cuda or actions.dtype is not torch.float32 or not actions.is_contiguous()
+                or actions.shape != (self.num_envs, 4)):
+            return self.action_transformation_function(actions)
+        env._new_call()
+        out = torch.empty((self.num_envs, kind[1]), device=actions.device)  # a fresh tensor per step, like the torch form (callers keep references)
+        _lib.check(env._lib.agx_action_transform(kind[0], self.num_envs, _lib.dptr(actions), _lib.dptr(out), env._stream()),
+                   "agx_action_transform")
+        return out
 
     def _flip_host_state(self):
         """host-side state that alternates per step and decides which buffers the step's kernels are handed (none here;

@@ -9,6 +9,7 @@ from ..sim.sim_builder import SimBuilder
 from ..tensors import aos_view, soa
 from ..utils.logging import CustomLogger
 from ..utils.spaces import Box, Dict
+from ..utils import roctx
 from .base_task import BaseTask
 
 logger = CustomLogger("position_setpoint_task")
@@ -106,6 +107,7 @@ class PositionSetpointTask(BaseTask):
     def render(self):
         return None
 
+    @roctx.ranged("PositionSetpointTask.step")
     def step(self, actions):
         self.counter += 1
         if (self._plan is not None and actions.dtype is torch.float32 and actions.is_contiguous() and actions.is_cuda

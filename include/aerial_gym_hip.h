@@ -335,6 +335,13 @@ int agx_obs_lidar_navigation(const AgxEnvBuffers *buf, int num_envs, const float
  * captured into a hipGraph and replayed (small batches are launch bound: ~15 launches per navigation step).           */
 int agx_step_counter_advance(const AgxEnvBuffers *buf, void *stream);
 
+/* task_config.action_transformation_function of the reference's task configs as one launch: policy action [N][4] (clamped
+ * to +-1) -> controller command.  NAV_VELOCITY: navigation_task_config.py:87-117 (speed, inclination, yaw rate -> [N][4]);
+ * LIDAR_ACCELERATION: lidar_navigation_task_config.py:98-108 ([N][4]); FULLY_ACTUATED_POSE: the 7-D position + attitude
+ * set-point of BASELINE configs[3] ([N][7]).  A user-supplied function (any other callable in the config) stays torch.   */
+enum { AGX_ACTION_NAV_VELOCITY = 1, AGX_ACTION_LIDAR_ACCELERATION = 2, AGX_ACTION_FULLY_ACTUATED_POSE = 3 };
+int agx_action_transform(int kind, int num_envs, const float *actions_in, float *out, void *stream);
+
 /* The reset set of EnvManager.reset_terminated_and_truncated_envs (env_manager.py:364-371) from the flags as they are:
  * reset_mask = crashes * reset_on_collision | truncations, reset_flag[flag_parity] |= any.  For callers that did not
  * run one of the task reward kernels above this step (stand-alone EnvManager; tasks that set truncations in torch). */

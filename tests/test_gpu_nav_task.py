@@ -134,7 +134,7 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             torch.cuda.synchronize()
             post = snapshot()
             # ---------------- oracle: one env step from the product's pre-step buffers
-            a_tr = npy(cfg.action_transformation_function(action))
+            a_tr = npy(task._transform_action(action))  # what the task hands its controller (the built-in function as one launch)
             st, th = pre["state"].copy(), pre["thrust"].copy()
             crashes = np.zeros(n, np.uint8)
             boxes = boxes_of(pre["asset"])
@@ -364,6 +364,42 @@ def test_replayed_step_graph_equals_eager_stepping(task_name, cfg_name):
         assert int(graphed.sim_env._step_counter_dev[0]) == 80
     finally:
         cfg.episode_len_steps, cfg.args, cfg.device = old
+
+
+def test_builtin_action_transformations_as_one_launch():
+    """agx_action_transform (what the tasks use when the config carries the built-in function) against the torch functions of
+    config/task_config.py evaluated in float64-backed numpy: the linear columns bit for bit, sine / cosine correctly rounded
+    (torch's device sin / cos are 1-2 ulp implementations; the kernels' are float64 inside, rounded once)."""
+    import ctypes as C
+
+    from aerial_gym_simulator_amd import _lib
+    from aerial_gym_simulator_amd.config import task_config as tc
+
+    lib = _lib.load()
+    n = 1 << 16
+    a = torch.rand(n, 4, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8)) * 3.0 - 1.5
+    an = np.clip(a.cpu().numpy(), -1.0, 1.0).astype(np.float32)
+    f32 = np.float32
+    for cfg, width in ((tc.navigation_task_config, 4), (tc.lidar_navigation_task_config, 4), (tc.fully_actuated_lidar_navigation_task_config, 7)):
+        kind = cfg.action_transformation_function.agx_kind
+        assert kind[1] == width
+        out = torch.empty(n, width, device=DEV)
+        _lib.check(lib.agx_action_transform(kind[0], n, _lib.dptr(a), _lib.dptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        got = out.cpu().numpy()
+        ref_torch = cfg.action_transformation_function(a).cpu().numpy()
+        assert np.abs(got - ref_torch).max() < 3e-7  # torch's own device sin / cos
+        if kind[0] == 1:
+            incl = (f32(np.pi / 4) * an[:, 1]).astype(f32)
+            speed = (an[:, 0] + f32(1.0)).astype(f32)
+            want = np.stack([speed * np.cos(incl.astype(np.float64)).astype(f32), np.zeros(n, f32),
+                             speed * np.sin(incl.astype(np.float64)).astype(f32), an[:, 2] * f32(np.pi / 3)], axis=1)
+        elif kind[0] == 2:
+            want = np.concatenate([an[:, 0:3] * f32(2.0), (an[:, 3] * f32(np.pi / 3))[:, None]], axis=1)
+        else:
+            half = (f32(0.5 * np.pi) * an[:, 3]).astype(f32)
+            want = np.stack([an[:, 0] * f32(5), an[:, 1] * f32(5), an[:, 2] * f32(2.5), np.zeros(n, f32), np.zeros(n, f32),
+                             np.sin(half.astype(np.float64)).astype(f32), np.cos(half.astype(np.float64)).astype(f32)], axis=1)
+        assert np.array_equal(got, want.astype(f32)), (kind, np.abs(got - want).max())
 
 
 def test_action_transformation_forms_agree_on_the_device():
