@@ -279,7 +279,10 @@ def raycast_key(task):
 def cpu_baseline_reference():
     """The reference's own torch CPU path (oracle/time_reference_cpu.py), timed where the reference tree exists."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_reference.json")))
+        path = os.path.join(ROOT, "profiles", "r03_cpu_baseline_reference.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r02_cpu_baseline_reference.json")
+        d = json.load(open(path))
         return {k: d[k] for k in ("value", "unit", "cores", "kind", "sample", "host", "cpu_model", "what")}
     except Exception:  # noqa: BLE001
         return None

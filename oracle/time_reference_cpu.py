@@ -5,7 +5,7 @@ BaseMultirotor.step (update_states, clip, Lee position controller, allocation, m
 robots/base_multirotor.py:296-307 + control/**), the oracle's rigid-body integrator in place of Isaac Gym's CPU
 PhysX (not installable), and the reference's compute_reward (position_setpoint_task.py:245-282) for BASELINE
 configs[0] (64 envs) and configs[1] (8192 envs), torch.set_num_threads(nproc).  /root/reference exists only here, so the
-result is written to profiles/r02_cpu_baseline_reference.json and echoed by bench.py (`cpu_baseline_reference`).
+result is written to profiles/r03_cpu_baseline_reference.json and echoed by bench.py (`cpu_baseline_reference`).
 
     python oracle/time_reference_cpu.py
 """
@@ -14,8 +14,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ["AGX_GOLDEN_JIT"] = "1"  # the reference as it ships: TorchScript ON (the golden generators switch it off, cr_torch.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -88,7 +90,7 @@ def main():
     out["value"] = out["configs"]["configs[1] 8192 envs"]["value"]
     out["sample"] = "%d env steps of 8192 envs (%.1f s)" % (out["configs"]["configs[1] 8192 envs"]["steps"],
                                                            out["configs"]["configs[1] 8192 envs"]["seconds"])
-    dst = os.path.join(os.path.dirname(HERE), "profiles", "r02_cpu_baseline_reference.json")
+    dst = os.path.join(os.path.dirname(HERE), "profiles", "r03_cpu_baseline_reference.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
