@@ -39,19 +39,19 @@ def source_hash():
 
 
 def binary_build_id(path=None):
-    """the build id embedded in a built library (None: no library, or one from before ABI 8)"""
-    import ctypes
-
+    """the build id embedded in a built library (None: no library, or one from before the id existed).  Read from the file's
+    bytes: dlopen would pin a stale library in this process, and the rebuilt one of the same path could not be loaded after it"""
     path = path or LIB_PATH
     if not os.path.exists(path):
         return None
-    try:
-        lib = ctypes.CDLL(path)
-        fn = lib.agx_build_id
-    except (OSError, AttributeError):
+    tag = b"agx-build-id:"
+    with open(path, "rb") as f:
+        data = f.read()
+    at = data.find(tag)
+    if at < 0:
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    end = data.find(b"\0", at)
+    return data[at + len(tag):end].decode("ascii", "replace")
 
 
 def binary_is_current():

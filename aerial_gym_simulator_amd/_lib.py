@@ -245,6 +245,7 @@ _SIGNATURES = {
     "agx_exchange_push_peers": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "agx_exchange_push_wait_seq": (C.c_int, [_P, C.c_uint32, _P]),
     "agx_exchange_check": (C.c_int, [_P]),
+    "agx_exchange_push_selftest": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _P]),
     "agx_action_transform": (C.c_int, [C.c_int, C.c_int, _P, _P, _P]),
     "agx_push_advance": (C.c_int, [C.POINTER(AgxEnvBuffers)]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

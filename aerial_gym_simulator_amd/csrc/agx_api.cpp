@@ -20,4 +20,7 @@ extern "C" int agx_abi_version(void) { return AGX_ABI_VERSION; }
 #ifndef AGX_BUILD_ID
 #error "AGX_BUILD_ID must be defined by the build (aerial_gym_simulator_amd/_build.py: hash of the sources and flags)"
 #endif
-extern "C" const char *agx_build_id(void) { return AGX_BUILD_ID; }
+// (tagged, so that the id can be read out of the FILE without mapping a possibly stale library into the process that is about
+// to rebuild and load it: _build.binary_build_id)
+static const char kBuildTag[] = "agx-build-id:" AGX_BUILD_ID;
+extern "C" const char *agx_build_id(void) { return kBuildTag + 13; }

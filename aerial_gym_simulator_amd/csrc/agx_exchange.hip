@@ -197,6 +197,19 @@ __global__ void k_wait_flags(const uint32_t *flags, int world, uint32_t seq, uin
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // once: the readers are later kernels of this stream (which start with an invalidate of their own)
 }
 
+// connection self-test (agx_exchange_push_selftest): one word per destination, stored the way the observation kernels store
+// rows (plain store through the mapped address), and the comparison on the receiving side by a kernel that starts after the
+// arrival flags were seen -- the path a consumer's kernels take
+__global__ void k_selftest_store(float *const *peer_recv, int world, size_t offset, float token) {
+  const int w = threadIdx.x;
+  if (w < world) peer_recv[w][offset] = token;
+}
+__global__ void k_selftest_check(const float *recv, int world, size_t slot_base, size_t count, float token_base, uint32_t *bad) {
+  const int w = threadIdx.x;
+  if (w < world && recv[slot_base + (size_t)w * count] != token_base + (float)w)
+    __hip_atomic_fetch_add(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 struct AgxExchange {
@@ -374,7 +387,7 @@ extern "C" int agx_exchange_create_push(int rank, int world, int device, size_t 
   x->device = device;
   x->push_count = count_per_rank;
   const size_t recv_bytes = (size_t)kPushSlots * world * count_per_rank * sizeof(float);
-  const size_t flag_bytes = (size_t)kPushSlots * world * sizeof(uint32_t);
+  const size_t flag_bytes = (size_t)(kPushSlots + 1) * world * sizeof(uint32_t);  // (+ one row of flags for the self-test)
   bool ok = hipMalloc((void **)&x->push_recv, recv_bytes) == hipSuccess && hipMemset(x->push_recv, 0, recv_bytes) == hipSuccess;
   // the flags are polled by a running kernel while a PEER device writes them: uncached (fine-grained) memory, like RCCL's own
   // flags; a runtime that refuses it gets ordinary device memory (the accesses are system-scope atomics either way)
@@ -478,6 +491,53 @@ extern "C" int agx_exchange_push_peers(AgxExchange *x, void **recv_out, void **f
 }
 
 static int check_failed(AgxExchange *x);
+// Connection self-test, to be called by EVERY rank after agx_exchange_push_connect and before the first post: each rank stores
+// one word into every rank's receive buffer through the mapped addresses, raises a flag there, waits (bounded: timeout_ms)
+// for every rank's flag and compares what has arrived.  *passed = 1 when this rank received every rank's word.  Leaves the
+// buffers as it found them; the callers synchronise (a barrier of their own) before the first post.  Exists because the
+// data path is plain device stores into another device's memory: if a platform maps the buffers but does not deliver such
+// stores, this says so before a step depends on it.
+extern "C" int agx_exchange_push_selftest(AgxExchange *x, int timeout_ms, int *passed, void *stream) {
+  AGX_REQUIRE(x && x->mode_push && x->connected && passed && timeout_ms > 0, "agx_exchange_push_selftest: connect first");
+  (void)hipSetDevice(x->device);
+  *passed = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t slot_base = (size_t)(kPushSlots - 1) * x->world * x->push_count;
+  const float token_base = 12345.0f;
+  uint32_t *test_flags = x->push_flags + (size_t)kPushSlots * x->world;
+  x->timed_out_host[1] = 0;
+  uint32_t *bad_host = nullptr, *bad_dev = nullptr;
+  if (hipHostMalloc((void **)&bad_host, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void **)&bad_dev, bad_host, 0) != hipSuccess)
+    return agx::fail(AGX_E_LAUNCH, "agx_exchange_push_selftest: hipHostMalloc failed");
+  *bad_host = 0;
+  hipLaunchKernelGGL(k_selftest_store, dim3(1), dim3(64), 0, st, (float *const *)x->peer_recv_dev, x->world,
+                     slot_base + (size_t)x->rank * x->push_count, token_base + (float)x->rank);
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, st, (uint32_t *const *)x->peer_flags_dev, x->world,
+                     kPushSlots * x->world + x->rank, 1u);
+  hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, st, test_flags, x->world, 1u, x->timed_out_dev + 1,
+                     (uint64_t)timeout_ms * 100000ull);
+  hipLaunchKernelGGL(k_selftest_check, dim3(1), dim3(64), 0, st, x->push_recv, x->world, slot_base, x->push_count, token_base, bad_dev);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  const uint32_t bad = *bad_host, late = x->timed_out_host[1];
+  const bool ok = e == hipSuccess && late == 0 && bad == 0;
+  x->timed_out_host[1] = 0;
+  (void)hipHostFree(bad_host);
+  if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "agx_exchange_push_selftest: %s", hipGetErrorString(e));
+  // every rank's word has arrived here (or the test failed and the exchange is about to be destroyed): clear what was written
+  for (int w = 0; w < x->world && e == hipSuccess; ++w)
+    e = hipMemsetAsync(x->push_recv + slot_base + (size_t)w * x->push_count, 0, sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(test_flags, 0, (size_t)x->world * sizeof(uint32_t), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return agx::fail(AGX_E_LAUNCH, "agx_exchange_push_selftest (clean-up): %s", hipGetErrorString(e));
+  if (!ok)  // (the message only: the call itself succeeded)
+    (void)agx::fail(AGX_E_LAUNCH, "peer-push self-test, rank %d: %u of %d words wrong, flags %s", x->rank, bad, x->world,
+                    late ? "timed out" : "arrived");
+  *passed = ok ? 1 : 0;
+  return AGX_OK;
+}
+
 // `stream` waits (one wave, bounded) until the rows with sequence number `seq` of EVERY rank have arrived in this rank's
 // receive buffer: for rows pushed by the observation kernels themselves, where the host keeps the sequence numbers
 extern "C" int agx_exchange_push_wait_seq(AgxExchange *x, uint32_t seq, void *stream) {

@@ -174,6 +174,9 @@ class StepGather:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return int(t.item()) == 1, ctl
 
+    PUSH_SELFTEST_MS = 5000
+    push_selftest = None
+
     def _create_push(self, required):
         """peer push: allocate this rank's receive buffer, trade the IPC handles, map the peers' buffers"""
         from . import _lib
@@ -199,6 +202,14 @@ class StepGather:
             rc = lib.agx_exchange_push_connect(handle, raw, len(raw))
             err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
             ok, _ = self._agree(rc == 0)
+            if ok:  # mapped everywhere: do stores through the mappings arrive?  (one word and one flag per pair of ranks)
+                passed = C.c_int(0)
+                rc = lib.agx_exchange_push_selftest(handle, self.PUSH_SELFTEST_MS, C.byref(passed),
+                                                    torch.cuda.current_stream(self.device).cuda_stream)
+                if rc or not passed.value:
+                    err = lib.agx_last_error().decode("utf-8", "replace")
+                ok, _ = self._agree(rc == 0 and passed.value == 1)
+                self.push_selftest = "passed" if ok else f"failed ({err or 'on another rank'})"
         if not ok:
             if handle.value:
                 lib.agx_exchange_destroy(handle)

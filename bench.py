@@ -525,6 +525,7 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
         res["producer_hand_off"] = "device flag (step_signal)" if gb.signal is not None else "event"
         if backend == "peer_push":
             res["flags_in_uncached_memory"] = gb.push_flags_uncached
+            res["connection_selftest"] = gb.push_selftest  # a word + a flag stored through every mapping and checked on arrival
         res["communicator"] = dict(zip(("rank", "ranks"), gb.comm_info()))  # ncclCommUserRank / ncclCommCount, or the ranks whose buffers were mapped
         if res["communicator"]["ranks"] != max(world, 1):
             raise RuntimeError(f"the exchange communicator spans {res['communicator']['ranks']} ranks, the job has {world}")

@@ -642,6 +642,11 @@ int agx_exchange_push_peers(AgxExchange *x, void **recv_out, void **flags_out, v
 int agx_exchange_push_wait_seq(AgxExchange *x, uint32_t seq, void *stream);
 /* Has anything gone wrong so far (worker thread; a bounded device-side wait that gave up)?  Two host reads.            */
 int agx_exchange_check(AgxExchange *x);
+/* Connection self-test of the peer push; every rank calls it after agx_exchange_push_connect and before the first post (the
+ * callers put a barrier of their own behind it).  Each rank stores one word into every rank's receive buffer through the
+ * mapped addresses -- the way the observation kernels store rows --, raises a flag, waits at most timeout_ms for every rank's
+ * flag and compares what arrived.  *passed = 1: this rank received every rank's word.  The buffers are left as found. */
+int agx_exchange_push_selftest(AgxExchange *x, int timeout_ms, int *passed, void *stream);
 
 #ifdef __cplusplus
 }

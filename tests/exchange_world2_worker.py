@@ -38,6 +38,8 @@ ready = "event" if mode == "event" else "signal"
 BACKEND = os.environ.get("AGX_TEST_EXCHANGE_BACKEND", "rccl_thread")  # "peer_push": real hipIpcMemHandle mapping between the two processes
 sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready)
 assert sg.backend == BACKEND
+if BACKEND == "peer_push":  # both processes stored a word and a flag through the other's mapping and saw the other's arrive
+    assert sg.push_selftest == "passed", sg.push_selftest
 assert sg.comm_info() == (rank, world), sg.comm_info()  # what the communicator itself reports
 if ready == "signal":
     assert sg.signal is not None, "the device-flag hand-off was not available (probe failed)"

@@ -37,6 +37,8 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
     a = StepGather(n, d, dev, backend=library_backend)
     b = StepGather(n, d, dev, backend="process_group")
     assert a.backend == library_backend and b.backend == "process_group"
+    if library_backend == "peer_push":  # a word and a flag went through every mapping before the first post
+        assert a.push_selftest == "passed"
     assert StepGather(n, d, dev).backend == "peer_push"  # what "auto" picks on a HIP device (rccl_thread if it cannot be set up)
     g = torch.Generator(device=dev).manual_seed(3)
     # synchronous form: this step's rows
