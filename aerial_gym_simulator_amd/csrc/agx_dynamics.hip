@@ -671,18 +671,27 @@ AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p);
 struct QuadDerived {
   float euler, qveh, vveh, vbody, wbody;
 };
-AGX_DEV QuadDerived update_states_quad(float q, float v, float w) {
+// `extra` / `esn`, `ecs`: the half-yaw's sine and cosine are needed in lanes 2 and 3 only, so lanes 0 and 1 of the same
+// evaluation take another angle of the caller's (the position law's yaw set-point) and hand back its sine / cosine
+AGX_DEV QuadDerived update_states_quad(float q, float v, float w, float extra, float &esn, float &ecs) {
   const int l = q4::lane_in_quad();
   QuadDerived d;
   const float e = q4::euler_xyz_0_2pi(q);
   d.euler = ssa(e);
   float sy, cy;
-  sincos_bounded((q4::bc<2>(e) * 1.0f) * 0.5f, sy, cy);  // vehicle_frame_quat_from_quat: quat_from_yaw
+  const float half_yaw = (q4::bc<2>(e) * 1.0f) * 0.5f;  // vehicle_frame_quat_from_quat: quat_from_yaw
+  sincos_bounded(l < 2 ? extra : half_yaw, sy, cy);
+  esn = sy;
+  ecs = cy;
   d.qveh = l == 2 ? sy : (l == 3 ? cy : 0.0f);
   d.vveh = q4::quat_rotate_inverse(d.qveh, v);
   d.vbody = q4::quat_rotate_inverse(q, v);
   d.wbody = q4::quat_rotate_inverse(q, w);
   return d;
+}
+AGX_DEV QuadDerived update_states_quad(float q, float v, float w) {
+  float sn, cs;
+  return update_states_quad(q, v, w, 0.0f, sn, cs);
 }
 
 // Per-lane constants of the quad kernels: component l of a vector, row l of a matrix, motors l (and l + 4 of an 8-motor robot)
@@ -720,15 +729,19 @@ AGX_DEV float quad_thrust_along_body_z(float q, float f, int l) {
   return q4::dot3(f, l == 2 ? m22 : c2a);
 }
 // base_lee_controller.py:173-194 (desired_orientation_pos_vel)
-AGX_DEV float quad_desired_orientation_pos_vel(float f, float yaw, int l) {
+// (sy, cy: sine and cosine of the yaw set-point, each valid in the lane that uses it -- cy in lane 0, sy in lane 1)
+AGX_DEV float quad_desired_orientation_pos_vel_sc(float f, float sy, float cy, int l) {
   const float b3 = fdiv(f, q4::norm3(f));
-  float sy, cy;
-  sincos_bounded(yaw, sy, cy);
   const float tmp = l == 0 ? cy : (l == 1 ? sy : 0.0f);
   const float cb = q4::cross3(b3, tmp);
   const float b2 = fdiv(cb, q4::norm3(cb));
   const float b1 = q4::cross3(b2, b3);
   return q4::rotmat_cols_to_quat(b1, b2, b3);
+}
+AGX_DEV float quad_desired_orientation_pos_vel(float f, float yaw, int l) {
+  float sy, cy;
+  sincos_bounded(yaw, sy, cy);
+  return quad_desired_orientation_pos_vel_sc(f, sy, cy, l);
 }
 // base_lee_controller.py:136-154 (compute_body_torque); ZERO_RATE: the angular-velocity set-point is the constant 0
 template <bool ZERO_RATE, int M>
@@ -838,15 +851,16 @@ __global__ void __launch_bounds__(64, 1)
     const QuadConsts<4> C = load_quad_consts<4>(P, l, l3);
 
     // ---- update_states + controller (position_control.py:20-51)
-    const QuadDerived d = update_states_quad(q, v, w);
     const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions
+    float sy_sp, cy_sp;  // of the yaw set-point (lanes 0, 1), out of the evaluation that serves the vehicle-frame quaternion
+    const QuadDerived d = update_states_quad(q, v, w, q4::bc<3>(a), sy_sp, cy_sp);
     // compute_acceleration (velocity set-point 0): kp (sp - p) + kv (0 - v)
     const float pe = a - p;
     const float ve = 0.0f - v;
     const float acc = kp * pe + kv * ve;
     const float f = (acc - C.grav) * C.mass;
     const float fz = quad_thrust_along_body_z(q, f, l);
-    const float qd = quad_desired_orientation_pos_vel(f, q4::bc<3>(a), l);
+    const float qd = quad_desired_orientation_pos_vel_sc(f, sy_sp, cy_sp, l);
     const float torque = quad_body_torque<true>(C, q, qd, d.wbody, 0.0f, kr, kw, l);
 
     // ---- allocation + motor model + body wrench, rigid-body update

@@ -292,6 +292,11 @@ struct AgxExchange {
                              push_arrive, timed_out_dev, kSpinLimitTicks);
         e = hipGetLastError();
         if (e != hipSuccess) fail_worker("k_push_rows", hipGetErrorString(e));
+        // the consumer orders itself behind THIS rank's push with an event, never by spinning on this rank's own flag: its
+        // stream may share a hardware queue with the communication stream, and a spinning kernel in front of the kernel it
+        // waits for never ends (seen as a 10 s time-out, depending on how many streams the process had created before)
+        e = hipEventRecord(done[j.parity], comm_stream);
+        if (e != hipSuccess) fail_worker("hipEventRecord", hipGetErrorString(e));
       } else if (!failed.load(std::memory_order_relaxed)) {
         hipError_t e;
         if (j.signal) {  // producer = a simulator kernel: spin on its flag, no cross-queue event
@@ -623,9 +628,12 @@ extern "C" int agx_exchange_wait(AgxExchange *x, int parity, void *consumer_stre
   AGX_REQUIRE(x && (parity == 0 || parity == 1), "agx_exchange_wait: bad argument");
   if (x->last_job[parity] == 0) return AGX_OK;  // nothing was ever posted for this parity
   if (x->mode_push) {
-    // no hand-off with the worker and no cross-queue event: the arrival flags of that post's slot say when every rank's rows
-    // have landed (this rank's own included: after it the send rows may be overwritten)
+    // this rank's own push: an event behind its kernel (see the worker); the other ranks' rows: the arrival flags of that
+    // post's slot, raised by kernels of other processes (spinning on those is safe: different queues)
+    x->wait_issued(x->last_job[parity]);
     if (int e = check_failed(x)) return e;
+    hipError_t he = hipStreamWaitEvent((hipStream_t)consumer_stream, x->done[parity], 0);
+    if (he != hipSuccess) return agx::fail(AGX_E_LAUNCH, "hipStreamWaitEvent: %s", hipGetErrorString(he));
     const uint64_t seq = x->push_seq_of_parity[parity];
     const int slot = (int)((seq - 1) % kPushSlots);
     hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, (hipStream_t)consumer_stream, x->push_flags + (size_t)slot * x->world, x->world,

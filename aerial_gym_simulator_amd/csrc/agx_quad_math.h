@@ -101,13 +101,21 @@ AGX_DEV float euler_xyz_0_2pi(float q) {
   const float ww = bc<3>(sq), xx = bc<0>(sq), yy = bc<1>(sq), zz = bc<2>(sq);
   const float a1 = (l == 2 ? ww + xx : ww - xx) - yy;
   const float den = l == 2 ? a1 - zz : a1 + zz;  // cosr_cosp (lane 0), cosy_cosp (lane 2)
-  const float at = atan2_cw(num, den);
-  float pitch;
+  // roll and yaw are atan2(num, den), the pitch is asin(num) = the angle of the point (sqrt((1 - |num|)(1 + |num|)), |num|):
+  // ONE evaluation of atan2_pos for the three (lane 1 takes the asin's abscissa), then what atan2_cw / asin_cw do around it --
+  // the same double operations on the same operands as the two separate calls, hence the same bits
+  const double an = __builtin_fabs((double)num);
+  const double ax = l == 1 ? __builtin_sqrt((1.0 - an) * (1.0 + an)) : __builtin_fabs((double)den);
+  const double ang = atan2_pos(an, ax);  // (NaN where a special case below applies: discarded)
+  // atan2_cw
+  const double aq = den < 0.0f ? kPiD - ang : ang;
+  float at = (float)(num < 0.0f ? -aq : aq);
+  if (den == 0.0f) at = num == 0.0f ? 0.0f : (num > 0.0f ? (float)kPio2Hi : -(float)kPio2Hi);
+  // asin_cw, and the clamp of utils/math.py:136-140
+  float pitch = (float)(num < 0.0f ? -ang : ang);
   if (fabsf(num) >= 1.0f) {
     const float sg = (num > 0.0f) ? 1.0f : ((num < 0.0f) ? -1.0f : 0.0f);
     pitch = (kPi / 2.0f) * sg;
-  } else {
-    pitch = asin_cw(num);
   }
   return pymod(l == 1 ? pitch : at, kTwoPi);
 }

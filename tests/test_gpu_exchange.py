@@ -37,8 +37,8 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
     a = StepGather(n, d, dev, backend=library_backend)
     b = StepGather(n, d, dev, backend="process_group")
     assert a.backend == library_backend and b.backend == "process_group"
-    if library_backend == "peer_push":  # a word and a flag went through every mapping before the first post
-        assert a.push_selftest == "passed"
+    if library_backend == "peer_push" and os.environ.get("AGX_PUSH_SELFTEST", "1") != "0":
+        assert a.push_selftest == "passed"  # a word and a flag went through every mapping before the first post
     assert StepGather(n, d, dev).backend == "peer_push"  # what "auto" picks on a HIP device (rccl_thread if it cannot be set up)
     g = torch.Generator(device=dev).manual_seed(3)
     # synchronous form: this step's rows
@@ -75,6 +75,34 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
     assert torch.equal(last_a, sent[-1]) and torch.equal(b.gathered[1], sent[-1])
     a.close()
     a.close()  # idempotent
+
+
+def test_worker_thread_push_whatever_queue_its_stream_lands_on(world_of_one):
+    """HIP maps streams onto a few hardware queues in creation order.  The consumer of the worker-thread push must not spin
+    on this rank's own arrival flag: if its stream shares a queue with the communication stream the spinning kernel sits in
+    front of the push kernel it waits for (found as an order-dependent 10 s time-out).  Shift the assignment by creating
+    0 .. 7 streams first; every variant must exchange promptly."""
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    dev = torch.device("cuda:0")
+    n, d = 512, 13
+    keep = []
+    g = torch.Generator(device=dev).manual_seed(5)
+    for extra in range(8):
+        keep.append(torch.cuda.Stream(device=dev))
+        x = StepGather(n, d, dev, backend="peer_push")
+        for consumer in (torch.cuda.current_stream(dev), keep[-1]):
+            with torch.cuda.stream(consumer):
+                for step in range(4):
+                    rows = torch.rand(n, d + 3, device=dev, generator=g)
+                    consumer.wait_stream(torch.cuda.current_stream(dev))
+                    x.rows[step & 1].copy_(rows)
+                    t0 = time.time()
+                    got = x.exchange(step & 1, overlap=False).clone()
+                    torch.cuda.synchronize()
+                    assert time.time() - t0 < 2.0, (extra, step)
+                    assert torch.equal(got, rows), (extra, step)
+        x.close()
 
 
 @pytest.mark.parametrize("library_backend", ["rccl_thread", "peer_push"])
