@@ -1270,9 +1270,16 @@ AGX_DEV void write_obs_position(const AgxEnvBuffers &B, int n, int i, V3 tgt, fl
   for (int c = 0; c < 13; ++c) o[c] = v[c];
   if (float *rows = B.step_rows[B.flag_parity]) {
     float *r = rows + (size_t)i * 16;
+    if (B.push_world > 0) {  // the 64-byte row as four 16-byte stores per destination
+      row_store4_push(B, r, v[0], v[1], v[2], v[3]);
+      row_store4_push(B, r + 4, v[4], v[5], v[6], v[7]);
+      row_store4_push(B, r + 8, v[8], v[9], v[10], v[11]);
+      row_store4_push(B, r + 12, v[12], B.step_reward[i], B.crashes[i] ? 1.0f : 0.0f, B.truncations[i] ? 1.0f : 0.0f);
+    } else {
 #pragma unroll
-    for (int c = 0; c < 13; ++c) row_store(B, r + c, v[c]);
-    write_step_row_tail(B, i, r, 13);
+      for (int c = 0; c < 13; ++c) row_store(B, r + c, v[c]);
+      write_step_row_tail(B, i, r, 13);
+    }
   }
 }
 __global__ void __launch_bounds__(256) k_obs_position(AgxEnvBuffers B, int n, const float *__restrict__ target, float *__restrict__ obs) {
@@ -1690,9 +1697,28 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
     o[3 + l] = q;
     if (float *rows = B.step_rows[B.flag_parity]) {
       float *r = rows + (size_t)i * 16;
-      if (l < 3) { row_store(B, r + l, e); row_store(B, r + 7 + l, vbody); row_store(B, r + 10 + l, wbody); }
-      row_store(B, r + 3 + l, q);
-      if (l == 0) write_step_row_tail(B, i, r, 13);
+      if (B.push_world > 0) {
+        // peer push: lane l stores elements 4 l .. 4 l + 3 of the row (e0 e1 e2 q0 | q1 q2 q3 vb0 | vb1 vb2 wb0 wb1 | wb2 reward
+        // crashed truncated): the quad writes its env's 64-byte row as ONE line per destination, a wave 1 KB contiguous.
+        // (the permutes are evaluated on the whole quad before the per-lane pick)
+        const float e1 = q4::bc<1>(e), e2 = q4::bc<2>(e), q2 = q4::perm<0, 2, 2, 3>(q), q3 = q4::bc<3>(q);
+        const float vb0 = q4::bc<0>(vbody), vb1 = q4::bc<1>(vbody), wb0 = q4::bc<0>(wbody), wb1 = q4::bc<1>(wbody), wb2 = q4::bc<2>(wbody);
+        float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        if (l == 3) {
+          t1 = B.step_reward[i];
+          t2 = B.crashes[i] ? 1.0f : 0.0f;
+          t3 = B.truncations[i] ? 1.0f : 0.0f;
+        }
+        const float x0 = q4::by_lane(l, e, q, vb1, wb2);      // e0 (own) | q1 (own) | vb1 | wb2
+        const float x1 = q4::by_lane(l, e1, q2, vbody, t1);   // e1 | q2 | vb2 (own) | reward
+        const float x2 = q4::by_lane(l, e2, q3, wb0, t2);     // e2 | q3 | wb0 | crashed
+        const float x3 = q4::by_lane(l, q, vb0, wb1, t3);     // q0 (own) | vb0 | wb1 | truncated
+        row_store4_push(B, r + 4 * l, x0, x1, x2, x3);
+      } else {
+        if (l < 3) { row_store(B, r + l, e); row_store(B, r + 7 + l, vbody); row_store(B, r + 10 + l, wbody); }
+        row_store(B, r + 3 + l, q);
+        if (l == 0) write_step_row_tail(B, i, r, 13);
+      }
     }
   }
   step_rows_signal(B);

@@ -45,6 +45,18 @@ __device__ __forceinline__ void row_store(const AgxEnvBuffers &B, float *p, floa
   }
 }
 
+// Four consecutive elements of an exchange row (p 16-byte aligned) under PEER PUSH: one 16-byte store per destination instead
+// of four 4-byte ones.  What crosses xGMI is then 16-byte (one-lane kernels) or -- where four neighbouring lanes hold the four
+// quarters of a 64-byte row, the lane-quad observation kernel -- whole-line writes, and a rank with seven peers issues 8 store
+// instructions per row quarter instead of 32.  Callers check B.push_world > 0 (the other modes need the write-through stores).
+__device__ __forceinline__ void row_store4_push(const AgxEnvBuffers &B, float *p, float a, float b, float c, float d) {
+  const float4 v = make_float4(a, b, c, d);
+  *reinterpret_cast<float4 *>(p) = v;
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+    if (j < B.push_world - 1) *reinterpret_cast<float4 *>((char *)p + B.push_delta[j]) = v;
+}
+
 // peer push: the rows of the PREVIOUS step are complete at every destination (the kernel that stored them has ended); lanes
 // 0 .. world - 1 of the calling wave tell every rank so.  Called by one wave at the head of the first kernel of a step.
 __device__ __forceinline__ void push_publish_previous(const AgxEnvBuffers &B) {
