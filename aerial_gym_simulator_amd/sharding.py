@@ -68,13 +68,22 @@ class StepGather:
                      as the reference's Sample Factory recipe tolerate the one-step delay.
     """
 
-    def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None, backend="auto", ready="signal"):
+    KERNEL_PUSH_MAX_ROW = 16  # floats: rows up to this size are stored at every destination by the observation kernel itself
+
+    def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None, backend="auto", ready="signal",
+                 kernel_push=None):
         """backend: "process_group" (torch.distributed collective), "rccl_thread" (the library's worker
         thread on its own RCCL communicator; HIP devices only) or "auto" (rccl_thread when the group runs
         on RCCL and every rank could set it up, else process_group).
         ready (rccl_thread with `env` only): "signal" = the observation kernel publishes a flag in device
         memory that the communication stream spins on (no HIP call per step on this thread); "event" = an
-        event recorded after the step (what rows filled by `pack()` always use)."""
+        event recorded after the step (what rows filled by `pack()` always use).
+        kernel_push (peer_push with `env`): True = the observation kernels store the rows into every rank's receive buffer
+        themselves; False = they store them locally and the library's push kernel copies them (16-byte coalesced) behind the
+        step's flag; None = by row size: the 16-float row of the position task is written by its kernels as 16-byte quarters
+        (one 64-byte line per env and destination), and a microsecond-scale step cannot afford a second host thread
+        launching kernels; the wide rows of the sensor tasks (84 / 340 floats) are produced element by element -- 4-byte
+        stores across xGMI -- so they go through the copy kernel, whose launch is nothing next to a millisecond step."""
         self.group = group
         self.collective = dist.is_initialized()  # a world of one still goes through RCCL (bench debugging aid)
         self.world = dist.get_world_size(group) if self.collective else 1
@@ -106,7 +115,9 @@ class StepGather:
         self.backend = ("peer_push" if self._push else "rccl_thread") if self._native is not None else ("process_group" if self.collective else "none")
         self.lag = 1            # exchange(overlap=True) returns the rows of `lag` steps ago
         self._kernel_push = False
-        if env is not None and self._push and not getattr(env, "rows_written_twice_per_step", False):
+        if kernel_push is None:
+            kernel_push = obs_dim + 3 <= self.KERNEL_PUSH_MAX_ROW
+        if env is not None and self._push and kernel_push and not getattr(env, "rows_written_twice_per_step", False):
             # the observation kernels store their rows at every destination themselves: nothing per step on the host, no
             # launch, no worker thread; the buffer of TWO steps ago is complete by construction when a step's kernels ran
             recv, flags, tout = (C.c_void_p * self.world)(), (C.c_void_p * self.world)(), C.c_void_p()

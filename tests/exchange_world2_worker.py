@@ -36,7 +36,9 @@ task.reset()
 d = task.task_obs["observations"].shape[1]
 ready = "event" if mode == "event" else "signal"
 BACKEND = os.environ.get("AGX_TEST_EXCHANGE_BACKEND", "rccl_thread")  # "peer_push": real hipIpcMemHandle mapping between the two processes
-sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready)
+KERNEL_PUSH = {"0": False, "1": True}.get(os.environ.get("AGX_TEST_KERNEL_PUSH", ""), None)  # None: by row size (here: the kernels push)
+sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready, kernel_push=KERNEL_PUSH)
+assert BACKEND != "peer_push" or sg._kernel_push == (KERNEL_PUSH is not False)
 assert sg.backend == BACKEND
 if BACKEND == "peer_push":  # both processes stored a word and a flag through the other's mapping and saw the other's arrive
     assert sg.push_selftest == "passed", sg.push_selftest

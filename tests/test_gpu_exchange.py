@@ -150,10 +150,11 @@ def test_exchange_argument_errors(world_of_one):
     assert lib.agx_exchange_destroy(None) == 0
 
 
+@pytest.mark.parametrize("kernel_push", [None, True])
 @pytest.mark.parametrize("which", ["position", "navigation"])
 @pytest.mark.parametrize("ready", ["signal", "event"])
 @pytest.mark.parametrize("library_backend", ["rccl_thread", "peer_push"])
-def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library_backend):
+def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library_backend, kernel_push):
     """The rows the observation kernels write travel through the library-side exchange, ordered by the
     kernels' own step_signal flag (or by an event): every gathered buffer is exactly the step's
     obs | reward | terminated | truncated, in the synchronous and in the overlapped form, across resets."""
@@ -162,6 +163,8 @@ def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
     from aerial_gym_simulator_amd.sharding import StepGather
 
+    if kernel_push and not (library_backend == "peer_push" and which == "navigation"):
+        pytest.skip("kernel_push=True differs from the default only for the wide rows of the sensor tasks under peer push")
     dev = "cuda:0"
     cfg = position_setpoint_task_config if which == "position" else navigation_task_config
     old = (cfg.episode_len_steps, cfg.args, getattr(cfg, "controller_name", None))
@@ -173,7 +176,7 @@ def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library
         task = task_registry.make_task(which + ("_setpoint_task" if which == "position" else "_task"), seed=5, num_envs=n, headless=True)
         task.reset()
         d = task.task_obs["observations"].shape[1]
-        sg = StepGather(n, d, dev, env=task.sim_env, reward=task.rewards, backend=library_backend, ready=ready)
+        sg = StepGather(n, d, dev, env=task.sim_env, reward=task.rewards, backend=library_backend, ready=ready, kernel_push=kernel_push)
         assert ready == "signal" or sg.signal is None or sg._kernel_push  # "signal" may fall back to events (agx_exchange_probe)
         g = torch.Generator(device=dev).manual_seed(9)
         acts = [torch.rand(n, 4, device=dev, generator=g) * 2 - 1 for _ in range(4)]
@@ -221,7 +224,8 @@ def test_library_exchange_of_a_stepping_task(world_of_one, which, ready, library
         if sg.signal is not None and not sg._kernel_push:  # (rows pushed by the kernels: flags are raised by the next step's first kernel)
             assert int(sg.signal[2]) == 0  # the arrival counter is back at zero after every launch
             assert int(sg.signal[:2].max()) == task.sim_env.step_counter
-        assert sg._kernel_push == (library_backend == "peer_push")  # the observation kernels push the rows themselves
+        # the observation kernels push 16-float rows themselves; wide rows go through the library's copy kernel unless asked otherwise
+        assert sg._kernel_push == (library_backend == "peer_push" and (which == "position" or bool(kernel_push)))
         sg.close()
         assert task.sim_env._buffers.step_signal is None and task.sim_env._buffers.push_world == 0
         task.step(acts[0])  # stepping goes on without the exchange

@@ -83,12 +83,24 @@ def test_rccl_thread_exchange_world2(mode):
 def test_peer_push_exchange_world2(mode):
     """StepGather(backend="peer_push") at WORLD SIZE 2, two processes on the one GPU, NO test double: each rank's receive
     buffer and arrival flags are mapped into the other process through hipIpcMemHandle (the path the 8-GPU job takes, there
-    over xGMI), the rows are stored there by k_push_rows and the consumer's stream waits on its own flags -- no collective
-    kernel per step.  Same checks as the RCCL path: 2000 steps, overlapped and synchronous, flag and event hand-off for the
+    over xGMI), the rows are stored there by the observation kernel itself (16-byte quarters of the 64-byte row), the arrival flags are
+    raised by the next step's first kernel -- no collective and no extra kernel per step.  Same checks as the RCCL path: 2000 steps, overlapped and synchronous, flag and event hand-off for the
     producer side; every rank's own slice bit-identical to what it sent; per-step checksums of what rank r sent equal those
     of rank r's slice in what every rank received (ordering, the four receive slots, the double-buffered rows)."""
     steps = 2000 if mode in ("signal", "event") else 400
     codes, outs = _run_world2(mode, steps, extra_env={"AGX_TEST_EXCHANGE_BACKEND": "peer_push"})
+    assert codes == [0, 0], "\n".join(o[-1500:] for o in outs)
+    assert all("ok %d steps" % steps in o for o in outs)
+
+
+@pytest.mark.parametrize("mode", ["signal", "sync"])
+def test_peer_push_through_the_copy_kernel_world2(mode):
+    """The other producer of the peer push (what the wide rows of the sensor tasks take, `kernel_push=False`): the observation
+    kernel stores its rows locally and raises step_signal, the library's worker thread launches k_push_rows, which copies them
+    into both processes' receive buffers (16-byte coalesced) and raises the arrival flags; the consumer orders itself behind
+    the local copy with an event and behind the peer's with the flag.  Real IPC mappings, same checks."""
+    steps = 1000 if mode == "signal" else 400
+    codes, outs = _run_world2(mode, steps, extra_env={"AGX_TEST_EXCHANGE_BACKEND": "peer_push", "AGX_TEST_KERNEL_PUSH": "0"})
     assert codes == [0, 0], "\n".join(o[-1500:] for o in outs)
     assert all("ok %d steps" % steps in o for o in outs)
 
