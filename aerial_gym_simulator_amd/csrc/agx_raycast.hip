@@ -35,6 +35,9 @@ namespace agx {
 #ifndef AGX_RAY_THREADS
 #define AGX_RAY_THREADS 256
 #endif
+#ifndef AGX_RAY_WIDE
+#define AGX_RAY_WIDE 0  // experiment: 4-wide nodes (profiles/wide_probe.py)
+#endif
 #ifndef AGX_RAY_USE_LDS
 #define AGX_RAY_USE_LDS 0
 #endif
@@ -228,6 +231,122 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
 
 AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
 
+#if AGX_RAY_WIDE
+// EXPERIMENT (profiles/wide_probe.py; built only with -DAGX_RAY_WIDE=1): 4-wide nodes.  A record is 32 floats: box k = 0..3 at
+// [6 k .. 6 k + 5] (lo xyz, hi xyz), its reference at [24 + k] (>= 0: record index, < 0: leaf ~triangle, INT_MIN: no entry),
+// the second triangle of a two-triangle leaf at [28 + k].  Entries 0, 1 come from the binary node's left child, 2, 3 from its
+// right child (a leaf child occupies the first entry of its pair), so the visiting order can follow the binary tree's votes.
+constexpr int kNoEntry = (int)0x80000000;
+template <bool ANY = false>
+AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  int upid = -1;
+  {
+    const int pid = r.kz * 2 + (r.swap ? 1 : 0);
+    const unsigned long long act = vote(r.active);
+    if (act) {
+      const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
+      if (vote(r.active && pid != p0) == 0ull) upid = p0;
+    }
+  }
+  if (nt == 1) {
+    test_leaf<ANY>(r, tris, 0, r.active, upid);
+    return;
+  }
+  int sp = 0, node = 0, stack = 0;
+  const int lane = threadIdx.x & 63;
+  AGX_STAT(0, 1);
+  while (true) {
+    AGX_STAT(1, 1);
+    const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 32);
+    const float4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3], w4 = nd[4], w5 = nd[5], w6 = nd[6], w7 = nd[7];
+    const int r0 = __float_as_int(w6.x), r1 = __float_as_int(w6.y), r2 = __float_as_int(w6.z), r3 = __float_as_int(w6.w);
+    const int s0 = __float_as_int(w7.x), s1 = __float_as_int(w7.y), s2 = __float_as_int(w7.z), s3 = __float_as_int(w7.w);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    bool h0 = false, h1 = false, h2 = false, h3 = false;
+    if (r0 != kNoEntry) h0 = ray_box(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, t0);
+    if (r1 != kNoEntry) h1 = ray_box(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, t1);
+    if (r2 != kNoEntry) h2 = ray_box(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, t2);
+    if (r3 != kNoEntry) h3 = ray_box(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, t3);
+    unsigned long long m0 = vote(h0), m1 = vote(h1), m2 = vote(h2), m3 = vote(h3);
+    // leaves first, in entry order; whatever comes after a leaf test votes again with the shortened rays
+    bool shortened = false;
+#define AGX_WIDE_LEAF(R, S, H, T, M)                                   \
+  if (R < 0 && R != kNoEntry) {                                         \
+    if (shortened && M) {                                               \
+      H = H && (T <= r.best) && r.active;                               \
+      M = vote(H);                                                      \
+    }                                                                   \
+    if (M) {                                                            \
+      test_leaf<ANY>(r, tris, ~R, H, upid);                             \
+      if (S >= 0) test_leaf<ANY>(r, tris, S, H, upid);                  \
+      AGX_STAT(2, S >= 0 ? 2 : 1);                                      \
+      shortened = true;                                                 \
+    }                                                                   \
+    M = 0;                                                              \
+    H = false;                                                          \
+  }
+    AGX_WIDE_LEAF(r0, s0, h0, t0, m0)
+    AGX_WIDE_LEAF(r1, s1, h1, t1, m1)
+    AGX_WIDE_LEAF(r2, s2, h2, t2, m2)
+    AGX_WIDE_LEAF(r3, s3, h3, t3, m3)
+#undef AGX_WIDE_LEAF
+    if (shortened) {
+      if (m0) { h0 = h0 && (t0 <= r.best) && r.active; m0 = vote(h0); }
+      if (m1) { h1 = h1 && (t1 <= r.best) && r.active; m1 = vote(h1); }
+      if (m2) { h2 = h2 && (t2 <= r.best) && r.active; m2 = vote(h2); }
+      if (m3) { h3 = h3 && (t3 <= r.best) && r.active; m3 = vote(h3); }
+    }
+    // order: within each pair and between the pairs, the nearer first by majority among the lanes that hit both
+    bool a_swap = false, b_swap = false;  // entry 1 before entry 0 / entry 3 before entry 2
+    if (m0 && m1) {
+      const unsigned long long both = vote(h0 && h1), first = vote(h0 && h1 && t0 <= t1);
+      a_swap = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(m0) < __popcll(m1));
+    } else {
+      a_swap = m0 == 0ull;
+    }
+    if (m2 && m3) {
+      const unsigned long long both = vote(h2 && h3), first = vote(h2 && h3 && t2 <= t3);
+      b_swap = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(m2) < __popcll(m3));
+    } else {
+      b_swap = m2 == 0ull;
+    }
+    const unsigned long long ma = m0 | m1, mb = m2 | m3;
+    bool b_first = false;
+    if (ma && mb) {
+      const bool ha = h0 || h1, hb = h2 || h3;
+      const float ta = fminf(h0 ? t0 : 3.0e38f, h1 ? t1 : 3.0e38f), tb = fminf(h2 ? t2 : 3.0e38f, h3 ? t3 : 3.0e38f);
+      const unsigned long long both = vote(ha && hb), first = vote(ha && hb && ta <= tb);
+      b_first = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(ma) < __popcll(mb));
+    } else {
+      b_first = ma == 0ull;
+    }
+    // the four entries near -> far: (reference, hit by anybody)
+    const int a0r = a_swap ? r1 : r0, a1r = a_swap ? r0 : r1, b0r = b_swap ? r3 : r2, b1r = b_swap ? r2 : r3;
+    const bool a0h = (a_swap ? m1 : m0) != 0ull, a1h = (a_swap ? m0 : m1) != 0ull, b0h = (b_swap ? m3 : m2) != 0ull, b1h = (b_swap ? m2 : m3) != 0ull;
+    const int e0 = b_first ? b0r : a0r, e1 = b_first ? b1r : a1r, e2 = b_first ? a0r : b0r, e3 = b_first ? a1r : b1r;
+    const bool g0 = b_first ? b0h : a0h, g1 = b_first ? b1h : a1h, g2 = b_first ? a0h : b0h, g3 = b_first ? a1h : b1h;
+    int next = -1;
+    // push far -> near everything behind the first hit entry
+    const bool before3 = g0 || g1 || g2, before2 = g0 || g1, before1 = g0;
+    if (g3) {
+      if (before3) { stack = (lane == (sp & (kStackDepth - 1))) ? e3 : stack; ++sp; } else next = e3;
+    }
+    if (g2) {
+      if (before2) { stack = (lane == (sp & (kStackDepth - 1))) ? e2 : stack; ++sp; } else next = e2;
+    }
+    if (g1) {
+      if (before1) { stack = (lane == (sp & (kStackDepth - 1))) ? e1 : stack; ++sp; } else next = e1;
+    }
+    if (g0) next = e0;
+    if (next < 0) {
+      if (sp == 0) break;
+      --sp;
+      next = __builtin_amdgcn_readlane(stack, sp & (kStackDepth - 1));
+    }
+    node = __builtin_amdgcn_readfirstlane(next);
+  }
+}
+#else
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
 template <bool ANY = false>
@@ -305,6 +424,8 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
   }
 }
 
+#endif  // AGX_RAY_WIDE
+
 struct CamArgs {
   int n, ns, width, height;
   float k00, k02, k11, k12;
@@ -365,7 +486,7 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
   const int mode = LIDAR ? LA.mode : CA.mode;
   const float far_plane = LIDAR ? LA.far_plane : CA.far_plane;
   const int n_nodes = nt - 1;
-  const float *g_nodes = nodes_g + (size_t)env * n_nodes * 16;
+  const float *g_nodes = nodes_g + (size_t)env * n_nodes * (AGX_RAY_WIDE ? 32 : 16);
   const float *g_tris = tri_world + (size_t)env * nt * 9;
   const float *nodes = g_nodes, *tris = g_tris;
   if (USE_LDS) {
