@@ -35,6 +35,9 @@ namespace agx {
 #ifndef AGX_RAY_THREADS
 #define AGX_RAY_THREADS 256
 #endif
+#ifndef AGX_RAY_TRI_VARIANT
+#define AGX_RAY_TRI_VARIANT 1  // branch structure of the triangle test: 0 = an early return per condition (the reference's shape), 1 = one early-out (shipped: -3 %), 2 = none
+#endif
 #ifndef AGX_RAY_WIDE
 #define AGX_RAY_WIDE 0  // experiment: 4-wide nodes (profiles/wide_probe.py)
 #endif
@@ -167,6 +170,7 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
     double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
     W = (float)(BxAy - ByAx);
   }
+#if AGX_RAY_TRI_VARIANT == 0
   if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
   float det = U + V + W;
   if (det == 0.0f) return false;
@@ -177,6 +181,24 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   float rcp = 1.0f / det;
   t_out = T * rcp;
   return true;
+#else
+  // Fewer exec-mask branches around the same arithmetic (profiles/r03_raycast_variants.txt).  1: one early-out (edge signs +
+  // determinant), the rest unconditional; 2: no early-out at all.  A lane that is rejected computes values
+  // nobody reads (1 / 0 included); an accepted lane goes through exactly the operations of variant 0.
+  const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
+  const float det = U + V + W;
+  const bool ok = !mixed && det != 0.0f;
+#if AGX_RAY_TRI_VARIANT == 1
+  if (!ok) return false;
+#endif
+  const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+  const float T = U * Az + V * Bz + W * Cz;
+  const uint32_t ds = __float_as_uint(det) & 0x80000000u;
+  const bool front = !(__uint_as_float(__float_as_uint(T) ^ ds) < 0.0f);
+  const float rcp = 1.0f / det;
+  t_out = T * rcp;
+  return ok && front;
+#endif
 }
 
 // ANY: occlusion query -- the first accepted hit retires the lane (it stops voting in ray_box)
@@ -184,7 +206,7 @@ template <bool ANY>
 AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want, int upid) {
   if (!want) return;
   const float *t = tris + (size_t)f * 9;
-  float th;
+  float th = 0.0f;
   const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
   bool hit;
   switch (upid) {  // wave-uniform
