@@ -1,18 +1,19 @@
-# final GPU pass of round 3: the whole GPU test suite, then the default bench line, the same under rocprofv3, and the
-# bench with the sharded code path forced in a world of one
+# final GPU pass of round 3 (one gpurun call, ~15 min): the whole GPU test suite, every measurement bench.py's keys are read
+# from (profiles/measure_r03.sh), the sharded code path forced in a world of one, the reference's benchmark recipe
+#   gpurun --timeout 2400 -- 'bash profiles/measure_r03_final.sh'
 set -u
 O=gpurun_out/r03f
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
-echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
-cp profiles/r03_parity_report.json $O/parity_report_before.json 2>/dev/null
-python bench.py > $O/bench_default.json 2> $O/bench_default.err
-echo "bench rc=$?"
+echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
+cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
+bash profiles/measure_r03.sh > $O/measure_r03.log 2>&1
+echo "measure rc=$?"
 AGX_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline > $O/bench_forced_dist_world1.json 2> $O/bench_forced_dist.err
 echo "forced dist rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o p -- python bench.py --no-cpu-baseline > $O/bench_default_under_rocprofv3.json 2> $O/prof_default.err
-echo "prof rc=$?"
-find $O -name "*kernel_trace.csv" -size +20M -delete
-cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null
-ls $O $O/prof_default
+PYTHONPATH=. python examples/benchmark.py --steps 5000 > $O/reference_benchmark_recipe.txt 2>/dev/null
+PYTHONPATH=. python examples/benchmark.py --rendering --steps 2000 >> $O/reference_benchmark_recipe.txt 2>/dev/null
+PYTHONPATH=. python examples/benchmark.py --num-envs 8192 --steps 5000 >> $O/reference_benchmark_recipe.txt 2>/dev/null
+cat $O/reference_benchmark_recipe.txt
+ls $O gpurun_out/r03m | head -60
