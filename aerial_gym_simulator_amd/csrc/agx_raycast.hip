@@ -38,6 +38,12 @@ namespace agx {
 #ifndef AGX_RAY_TRI_VARIANT
 #define AGX_RAY_TRI_VARIANT 1  // branch structure of the triangle test: 0 = an early return per condition (the reference's shape), 1 = one early-out (shipped: -3 %), 2 = none
 #endif
+#ifndef AGX_RAY_HOIST_UPID
+#define AGX_RAY_HOIST_UPID 1  // one copy of the traversal loop per packet (axis, orientation) instead of a switch per triangle (-2 %)
+#endif
+#ifndef AGX_RAY_BOX_AXIS
+#define AGX_RAY_BOX_AXIS 1  // (needs AGX_RAY_HOIST_UPID) no min / max along the packet's dominant axis in the slab test (-2 %)
+#endif
 #ifndef AGX_RAY_WIDE
 #define AGX_RAY_WIDE 0  // experiment: 4-wide nodes (profiles/wide_probe.py)
 #endif
@@ -202,13 +208,18 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
 }
 
 // ANY: occlusion query -- the first accepted hit retires the lane (it stops voting in ray_box)
-template <bool ANY>
+// CUPID (AGX_RAY_HOIST_UPID builds): the packet's (axis, orientation) as a template parameter of the whole traversal instead of
+// a switch per triangle; -2 = decide here
+template <bool ANY, int CUPID = -2>
 AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want, int upid) {
   if (!want) return;
   const float *t = tris + (size_t)f * 9;
   float th = 0.0f;
   const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
   bool hit;
+  if (CUPID != -2) {
+    hit = ray_tri<CUPID>(r, a, b, c, th);
+  } else
   switch (upid) {  // wave-uniform
     case 0: hit = ray_tri<0>(r, a, b, c, th); break;
     case 1: hit = ray_tri<1>(r, a, b, c, th); break;
@@ -239,13 +250,19 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want,
 //     measured: occlusion rays with d_z == 0 lost their occluder, test_stereo_occlusion_ray_with_zero_direction_component):
 //     a hit at t <= max_t moves < 1e-26 along c, so the origin lies inside the un-grown slab up to that, i.e.
 //     >= 1e-3 inside the grown one; b * 1e30 - o * 1e30 then has the right sign and magnitude >= 1e27 > any max_t.
+// CUPID >= 0 (a packet whose rays share the dominant axis kz = CUPID >> 1 and its sign, CUPID & 1: d[kz] < 0): along THAT axis
+// the order of the two plane distances is known -- fma is monotone in its first argument, lo <= hi, and the sign of rcp is the
+// packet's -- so the min / max pair of that axis is dropped; the values that remain are the ones min / max would have picked.
+template <int CUPID = -1>
 AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tnear) {
+  constexpr int kzc = CUPID >= 0 ? (CUPID >> 1) : -1;
+  constexpr bool neg = CUPID >= 0 && (CUPID & 1);
   float t0 = fmaf(lx, r.rcp.x, -r.orcp.x), t1 = fmaf(hx, r.rcp.x, -r.orcp.x);
-  float tmin = fminf(t0, t1), tmax = fmaxf(t0, t1);
+  float tmin = kzc == 0 ? (neg ? t1 : t0) : fminf(t0, t1), tmax = kzc == 0 ? (neg ? t0 : t1) : fmaxf(t0, t1);
   t0 = fmaf(ly, r.rcp.y, -r.orcp.y); t1 = fmaf(hy, r.rcp.y, -r.orcp.y);
-  tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+  tmin = fmaxf(tmin, kzc == 1 ? (neg ? t1 : t0) : fminf(t0, t1)); tmax = fminf(tmax, kzc == 1 ? (neg ? t0 : t1) : fmaxf(t0, t1));
   t0 = fmaf(lz, r.rcp.z, -r.orcp.z); t1 = fmaf(hz, r.rcp.z, -r.orcp.z);
-  tmin = fmaxf(tmin, fminf(t0, t1)); tmax = fminf(tmax, fmaxf(t0, t1));
+  tmin = fmaxf(tmin, kzc == 2 ? (neg ? t1 : t0) : fminf(t0, t1)); tmax = fminf(tmax, kzc == 2 ? (neg ? t0 : t1) : fmaxf(t0, t1));
   tmax *= 1.0000004f;
   tnear = tmin;
   return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
@@ -371,20 +388,10 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
 #else
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
-template <bool ANY = false>
-AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
-  // do all active rays of the packet share the dominant axis and its orientation?
-  int upid = -1;  // 2 * kz + swap, or -1 (mixed)
-  {
-    const int pid = r.kz * 2 + (r.swap ? 1 : 0);
-    const unsigned long long act = vote(r.active);
-    if (act) {
-      const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
-      if (vote(r.active && pid != p0) == 0ull) upid = p0;
-    }
-  }
+template <bool ANY, int CUPID>
+AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt, int upid) {
   if (nt == 1) {
-    test_leaf<ANY>(r, tris, 0, r.active, upid);
+    test_leaf<ANY, CUPID>(r, tris, 0, r.active, upid);
     return;
   }
   int sp = 0;
@@ -399,13 +406,13 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
     const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
     float tl, tr;
-    bool hl = ray_box(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
-    bool hr = ray_box(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    bool hl = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
+    bool hr = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
     unsigned long long ml = vote(hl), mr = vote(hr);
     if (cl < 0) {
       if (ml) {
-        test_leaf<ANY>(r, tris, ~cl, hl, upid);
-        if (cl2 >= 0) test_leaf<ANY>(r, tris, cl2, hl, upid);
+        test_leaf<ANY, CUPID>(r, tris, ~cl, hl, upid);
+        if (cl2 >= 0) test_leaf<ANY, CUPID>(r, tris, cl2, hl, upid);
         AGX_STAT(2, cl2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(ml));
       }
       ml = 0;
@@ -416,8 +423,8 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
         mr = vote(hr);
       }
       if (mr) {
-        test_leaf<ANY>(r, tris, ~cr, hr, upid);
-        if (cr2 >= 0) test_leaf<ANY>(r, tris, cr2, hr, upid);
+        test_leaf<ANY, CUPID>(r, tris, ~cr, hr, upid);
+        if (cr2 >= 0) test_leaf<ANY, CUPID>(r, tris, cr2, hr, upid);
         AGX_STAT(2, cr2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(mr));
       }
       mr = 0;
@@ -446,6 +453,33 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
   }
 }
 
+
+template <bool ANY = false>
+AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  // do all active rays of the packet share the dominant axis and its orientation?
+  int upid = -1;  // 2 * kz + swap, or -1 (mixed)
+  {
+    const int pid = r.kz * 2 + (r.swap ? 1 : 0);
+    const unsigned long long act = vote(r.active);
+    if (act) {
+      const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
+      if (vote(r.active && pid != p0) == 0ull) upid = p0;
+    }
+  }
+#if AGX_RAY_HOIST_UPID
+  switch (upid) {  // wave-uniform, once per packet: seven copies of the loop
+    case 0: traverse_impl<ANY, 0>(r, nodes, tris, nt, upid); break;
+    case 1: traverse_impl<ANY, 1>(r, nodes, tris, nt, upid); break;
+    case 2: traverse_impl<ANY, 2>(r, nodes, tris, nt, upid); break;
+    case 3: traverse_impl<ANY, 3>(r, nodes, tris, nt, upid); break;
+    case 4: traverse_impl<ANY, 4>(r, nodes, tris, nt, upid); break;
+    case 5: traverse_impl<ANY, 5>(r, nodes, tris, nt, upid); break;
+    default: traverse_impl<ANY, -1>(r, nodes, tris, nt, upid); break;
+  }
+#else
+  traverse_impl<ANY, -2>(r, nodes, tris, nt, upid);
+#endif
+}
 #endif  // AGX_RAY_WIDE
 
 struct CamArgs {
