@@ -41,6 +41,9 @@ namespace agx {
 #ifndef AGX_RAY_HOIST_UPID
 #define AGX_RAY_HOIST_UPID 1  // one copy of the traversal loop per packet (axis, orientation) instead of a switch per triangle (-2 %)
 #endif
+#ifndef AGX_RAY_BOX_OCTANT
+#define AGX_RAY_BOX_OCTANT 0  // experiment (needs AGX_RAY_HOIST_UPID): octant-uniform packets pick near / far planes on the scalar unit
+#endif
 #ifndef AGX_RAY_BOX_AXIS
 #define AGX_RAY_BOX_AXIS 1  // (needs AGX_RAY_HOIST_UPID) no min / max along the packet's dominant axis in the slab test (-2 %)
 #endif
@@ -268,6 +271,20 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
 }
 
+// The same test for a packet whose rays all point into the same OCTANT (`oct`, wave-uniform: bit a set = every active ray has
+// 1 / d_a < 0): which plane of a slab is the near one is then the packet's choice, made on the scalar unit (the planes are
+// wave-uniform), and no min / max is left per lane.  Same plane distances, same comparisons as ray_box.
+AGX_DEV bool ray_box_oct(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, int oct, float &tnear) {
+  const bool nx = (oct & 1) != 0, ny = (oct & 2) != 0, nz = (oct & 4) != 0;
+  const float ax = nx ? hx : lx, bx = nx ? lx : hx, ay = ny ? hy : ly, by = ny ? ly : hy, az = nz ? hz : lz, bz = nz ? lz : hz;
+  float tmin = fmaf(ax, r.rcp.x, -r.orcp.x), tmax = fmaf(bx, r.rcp.x, -r.orcp.x);
+  tmin = fmaxf(tmin, fmaf(ay, r.rcp.y, -r.orcp.y)); tmax = fminf(tmax, fmaf(by, r.rcp.y, -r.orcp.y));
+  tmin = fmaxf(tmin, fmaf(az, r.rcp.z, -r.orcp.z)); tmax = fminf(tmax, fmaf(bz, r.rcp.z, -r.orcp.z));
+  tmax *= 1.0000004f;
+  tnear = tmin;
+  return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+}
+
 AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
 
 #if AGX_RAY_WIDE
@@ -388,8 +405,8 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
 #else
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
 // holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
-template <bool ANY, int CUPID>
-AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt, int upid) {
+template <bool ANY, int CUPID, bool OCT = false>
+AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt, int upid, int oct = 0) {
   if (nt == 1) {
     test_leaf<ANY, CUPID>(r, tris, 0, r.active, upid);
     return;
@@ -406,8 +423,14 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
     const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
     float tl, tr;
-    bool hl = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
-    bool hr = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    bool hl, hr;
+    if (OCT) {
+      hl = ray_box_oct(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, oct, tl);
+      hr = ray_box_oct(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, oct, tr);
+    } else {
+      hl = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
+      hr = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    }
     unsigned long long ml = vote(hl), mr = vote(hr);
     if (cl < 0) {
       if (ml) {
@@ -466,6 +489,26 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
       if (vote(r.active && pid != p0) == 0ull) upid = p0;
     }
   }
+#if AGX_RAY_HOIST_UPID && AGX_RAY_BOX_OCTANT
+  // ... and the same octant?  (sign bits of the clamped reciprocals: 1 / +0 counts as positive, 1 / -0 as negative, like ray_box)
+  int oct = -1;
+  if (upid >= 0) {
+    const int sb = (int)(__float_as_uint(r.rcp.x) >> 31) | ((int)(__float_as_uint(r.rcp.y) >> 31) << 1) | ((int)(__float_as_uint(r.rcp.z) >> 31) << 2);
+    const unsigned long long act = vote(r.active);
+    const int s0 = __builtin_amdgcn_readlane(sb, __ffsll((long long)act) - 1);
+    if (vote(r.active && sb != s0) == 0ull) oct = s0;
+  }
+  if (oct >= 0) {
+    switch (upid) {
+      case 0: traverse_impl<ANY, 0, true>(r, nodes, tris, nt, upid, oct); return;
+      case 1: traverse_impl<ANY, 1, true>(r, nodes, tris, nt, upid, oct); return;
+      case 2: traverse_impl<ANY, 2, true>(r, nodes, tris, nt, upid, oct); return;
+      case 3: traverse_impl<ANY, 3, true>(r, nodes, tris, nt, upid, oct); return;
+      case 4: traverse_impl<ANY, 4, true>(r, nodes, tris, nt, upid, oct); return;
+      default: traverse_impl<ANY, 5, true>(r, nodes, tris, nt, upid, oct); return;
+    }
+  }
+#endif
 #if AGX_RAY_HOIST_UPID
   switch (upid) {  // wave-uniform, once per packet: seven copies of the loop
     case 0: traverse_impl<ANY, 0>(r, nodes, tris, nt, upid); break;
