@@ -41,6 +41,18 @@ namespace agx {
 #ifndef AGX_RAY_HOIST_UPID
 #define AGX_RAY_HOIST_UPID 1  // one copy of the traversal loop per packet (axis, orientation) instead of a switch per triangle (-2 %)
 #endif
+#ifndef AGX_RAY_ADDR32
+#define AGX_RAY_ADDR32 1  // 32-bit offsets for node / triangle fetches: scalar loads with a register offset (-2.5 %)
+#endif
+#ifndef AGX_RAY_NOWANT
+#define AGX_RAY_NOWANT 1  // lanes that missed the leaf's box run the triangle test too (no exec branch around it); only the update is masked (-2 %)
+#endif
+#ifndef AGX_RAY_PAIRLOAD
+#define AGX_RAY_PAIRLOAD 1  // both triangles of a two-triangle leaf fetched before the first test (-1 %)
+#endif
+#ifndef AGX_RAY_PREFETCH_LEAF
+#define AGX_RAY_PREFETCH_LEAF 0  // experiment: the triangles of a left leaf child requested before the node's box tests
+#endif
 #ifndef AGX_RAY_BOX_OCTANT
 #define AGX_RAY_BOX_OCTANT 0  // experiment (needs AGX_RAY_HOIST_UPID): octant-uniform packets pick near / far planes on the scalar unit
 #endif
@@ -215,8 +227,14 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
 // a switch per triangle; -2 = decide here
 template <bool ANY, int CUPID = -2>
 AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want, int upid) {
+#if !AGX_RAY_NOWANT
   if (!want) return;
+#endif
+#if AGX_RAY_ADDR32
+  const float *t = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)f * 36u);
+#else
   const float *t = tris + (size_t)f * 9;
+#endif
   float th = 0.0f;
   const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
   bool hit;
@@ -232,7 +250,7 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want,
     case 5: hit = ray_tri<5>(r, a, b, c, th); break;
     default: hit = ray_tri<-1>(r, a, b, c, th); break;
   }
-  if (hit) {
+  if (AGX_RAY_NOWANT ? (hit && want) : hit) {
     if (ANY) {
       if (th >= 0.0f && th < r.best) {
         r.face = f;
@@ -243,6 +261,51 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want,
       r.face = f;
     }
   }
+}
+
+struct TriPair {
+  V3 a1, b1, c1, a2, b2, c2;
+};
+AGX_DEV TriPair load_tri_pair(const float *__restrict__ tris, int f1, int f2) {
+  const float *t1 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)f1 * 36u);
+  const float *t2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)(f2 >= 0 ? f2 : f1) * 36u);
+  return TriPair{V3{t1[0], t1[1], t1[2]}, V3{t1[3], t1[4], t1[5]}, V3{t1[6], t1[7], t1[8]},
+                 V3{t2[0], t2[1], t2[2]}, V3{t2[3], t2[4], t2[5]}, V3{t2[6], t2[7], t2[8]}};
+}
+template <bool ANY, int CUPID>
+AGX_DEV void test_tri_pair(Ray &r, const TriPair &P, int f1, int f2, bool want) {
+  float th = 0.0f;
+  bool hit = ray_tri<CUPID>(r, P.a1, P.b1, P.c1, th) && want;
+  if (ANY) {
+    if (hit && th >= 0.0f && th < r.best) { r.face = f1; r.active = false; }
+  } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f1 < r.face))) {
+    r.best = th;
+    r.face = f1;
+  }
+  if (f2 >= 0) {
+    th = 0.0f;
+    hit = ray_tri<CUPID>(r, P.a2, P.b2, P.c2, th) && want;
+    if (ANY) {
+      if (hit && th >= 0.0f && th < r.best) { r.face = f2; r.active = false; }
+    } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f2 < r.face))) {
+      r.best = th;
+      r.face = f2;
+    }
+  }
+}
+// A leaf and the second triangle of a two-triangle leaf (f2 < 0: none).  AGX_RAY_PAIRLOAD: both triangles are fetched before the
+// first is tested (one exposed scalar-load latency per leaf instead of two); the tests and updates stay in order.
+template <bool ANY, int CUPID>
+AGX_DEV void test_leaf_pair(Ray &r, const float *__restrict__ tris, int f1, int f2, bool want, int upid) {
+#if AGX_RAY_PAIRLOAD
+  if (CUPID != -2) {
+    const TriPair P = load_tri_pair(tris, f1, f2);
+    test_tri_pair<ANY, CUPID>(r, P, f1, f2, want);
+    return;
+  }
+#endif
+  test_leaf<ANY, CUPID>(r, tris, f1, want, upid);
+  if (f2 >= 0) test_leaf<ANY, CUPID>(r, tris, f2, want, upid);
 }
 
 // Conservative slab test, one fma per plane: t = b * rcp - o * rcp, with rcp CLAMPED to +-1e30 in ray_setup.
@@ -418,10 +481,20 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
   AGX_STAT(0, 1);  // packets
   while (true) {
     AGX_STAT(1, 1);  // node visits
+#if AGX_RAY_ADDR32
+    // 32-bit byte offsets from the env's node block (< 2^31 bytes): a scalar load with a register offset, no 64-bit address arithmetic
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)node << 6));
+#else
     const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 16);
+#endif
     float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
     const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
+#if AGX_RAY_PREFETCH_LEAF
+    TriPair PL;  // a leaf on the left: its triangles are requested before the box tests run
+    constexpr bool kPrefetch = CUPID != -2;
+    if (kPrefetch && cl < 0) PL = load_tri_pair(tris, ~cl, cl2);
+#endif
     float tl, tr;
     bool hl, hr;
     if (OCT) {
@@ -434,8 +507,11 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
     unsigned long long ml = vote(hl), mr = vote(hr);
     if (cl < 0) {
       if (ml) {
-        test_leaf<ANY, CUPID>(r, tris, ~cl, hl, upid);
-        if (cl2 >= 0) test_leaf<ANY, CUPID>(r, tris, cl2, hl, upid);
+#if AGX_RAY_PREFETCH_LEAF
+        if (kPrefetch) test_tri_pair<ANY, CUPID>(r, PL, ~cl, cl2, hl);
+        else
+#endif
+        test_leaf_pair<ANY, CUPID>(r, tris, ~cl, cl2, hl, upid);
         AGX_STAT(2, cl2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(ml));
       }
       ml = 0;
@@ -446,8 +522,7 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
         mr = vote(hr);
       }
       if (mr) {
-        test_leaf<ANY, CUPID>(r, tris, ~cr, hr, upid);
-        if (cr2 >= 0) test_leaf<ANY, CUPID>(r, tris, cr2, hr, upid);
+        test_leaf_pair<ANY, CUPID>(r, tris, ~cr, cr2, hr, upid);
         AGX_STAT(2, cr2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(mr));
       }
       mr = 0;
