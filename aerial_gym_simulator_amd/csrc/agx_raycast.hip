@@ -53,6 +53,9 @@ namespace agx {
 #ifndef AGX_RAY_PREFETCH_LEAF
 #define AGX_RAY_PREFETCH_LEAF 0  // experiment: the triangles of a left leaf child requested before the node's box tests
 #endif
+#ifndef AGX_RAY_NOACTIVE
+#define AGX_RAY_NOACTIVE 1  // retired lanes carry best = -inf instead of being masked in every slab test (-1 % camera)
+#endif
 #ifndef AGX_RAY_BOX_OCTANT
 #define AGX_RAY_BOX_OCTANT 0  // experiment (needs AGX_RAY_HOIST_UPID): octant-uniform packets pick near / far planes on the scalar unit
 #endif
@@ -255,6 +258,7 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want,
       if (th >= 0.0f && th < r.best) {
         r.face = f;
         r.active = false;
+        if (AGX_RAY_NOACTIVE) r.best = -INFINITY;
       }
     } else if (th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
       r.best = th;
@@ -277,7 +281,7 @@ AGX_DEV void test_tri_pair(Ray &r, const TriPair &P, int f1, int f2, bool want) 
   float th = 0.0f;
   bool hit = ray_tri<CUPID>(r, P.a1, P.b1, P.c1, th) && want;
   if (ANY) {
-    if (hit && th >= 0.0f && th < r.best) { r.face = f1; r.active = false; }
+    if (hit && th >= 0.0f && th < r.best) { r.face = f1; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
   } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f1 < r.face))) {
     r.best = th;
     r.face = f1;
@@ -286,7 +290,7 @@ AGX_DEV void test_tri_pair(Ray &r, const TriPair &P, int f1, int f2, bool want) 
     th = 0.0f;
     hit = ray_tri<CUPID>(r, P.a2, P.b2, P.c2, th) && want;
     if (ANY) {
-      if (hit && th >= 0.0f && th < r.best) { r.face = f2; r.active = false; }
+      if (hit && th >= 0.0f && th < r.best) { r.face = f2; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
     } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f2 < r.face))) {
       r.best = th;
       r.face = f2;
@@ -331,7 +335,11 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   tmin = fmaxf(tmin, kzc == 2 ? (neg ? t1 : t0) : fminf(t0, t1)); tmax = fminf(tmax, kzc == 2 ? (neg ? t0 : t1) : fmaxf(t0, t1));
   tmax *= 1.0000004f;
   tnear = tmin;
+#if AGX_RAY_NOACTIVE  // a retired lane carries best = -inf (traverse): the last comparison fails for it
+  return (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+#else
   return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+#endif
 }
 
 // The same test for a packet whose rays all point into the same OCTANT (`oct`, wave-uniform: bit a set = every active ray has
@@ -518,7 +526,7 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
     }
     if (cr < 0) {
       if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
-        hr = hr && (tr <= r.best) && r.active;
+        hr = hr && (tr <= r.best) && (AGX_RAY_NOACTIVE || r.active);
         mr = vote(hr);
       }
       if (mr) {
@@ -564,6 +572,9 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
       if (vote(r.active && pid != p0) == 0ull) upid = p0;
     }
   }
+#if AGX_RAY_NOACTIVE
+  if (!r.active) r.best = -INFINITY;  // (a lane outside the image: nobody reads its `best`)
+#endif
 #if AGX_RAY_HOIST_UPID && AGX_RAY_BOX_OCTANT
   // ... and the same octant?  (sign bits of the clamped reciprocals: 1 / +0 counts as positive, 1 / -0 as negative, like ray_box)
   int oct = -1;
