@@ -56,6 +56,12 @@ namespace agx {
 #ifndef AGX_RAY_NOACTIVE
 #define AGX_RAY_NOACTIVE 1  // retired lanes carry best = -inf instead of being masked in every slab test (-1 % camera)
 #endif
+#ifndef AGX_RAY_FLAT
+#define AGX_RAY_FLAT 1  // one comparison per slab test, |.|-min3 for the zero-edge test, hit update as selects: no exec regions (-7 %)
+#endif
+#ifndef AGX_RAY_VOTEMASK
+#define AGX_RAY_VOTEMASK 1  // votes of conjunctions as mask arithmetic on the votes of their terms (-2 %)
+#endif
 #ifndef AGX_RAY_BOX_OCTANT
 #define AGX_RAY_BOX_OCTANT 0  // experiment (needs AGX_RAY_HOIST_UPID): octant-uniform packets pick near / far planes on the scalar unit
 #endif
@@ -186,7 +192,11 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   float U = diff_product(Cx, By, Cy, Bx);
   float V = diff_product(Ax, Cy, Ay, Cx);
   float W = diff_product(Bx, Ay, By, Ax);
+#if AGX_RAY_FLAT
+  if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.0f) {  // any of the three exactly 0 (one v_min3 with |.| modifiers, one compare)
+#else
   if (U == 0.0f || V == 0.0f || W == 0.0f) {
+#endif
     double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
     U = (float)(CxBy - CyBx);
     double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
@@ -267,6 +277,31 @@ AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want,
   }
 }
 
+// closest hit: smaller t wins, on an exact tie the smaller face index (DESIGN.md "closest-hit semantics"); any-hit: the first
+// accepted hit retires the lane.  AGX_RAY_FLAT: the condition as mask arithmetic and the update as selects -- no exec regions.
+template <bool ANY>
+AGX_DEV void accept_hit(Ray &r, bool hit, float th, int f) {
+#if AGX_RAY_FLAT
+  if (ANY) {
+    const bool acc = hit & (th >= 0.0f) & (th < r.best);
+    r.face = acc ? f : r.face;
+    r.active = acc ? false : r.active;
+    if (AGX_RAY_NOACTIVE) r.best = acc ? -INFINITY : r.best;
+  } else {
+    const bool acc = hit & (th >= 0.0f) & ((th < r.best) | ((th == r.best) & (r.face >= 0) & (f < r.face)));
+    r.best = acc ? th : r.best;
+    r.face = acc ? f : r.face;
+  }
+#else
+  if (ANY) {
+    if (hit && th >= 0.0f && th < r.best) { r.face = f; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
+  } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
+    r.best = th;
+    r.face = f;
+  }
+#endif
+}
+
 struct TriPair {
   V3 a1, b1, c1, a2, b2, c2;
 };
@@ -280,21 +315,11 @@ template <bool ANY, int CUPID>
 AGX_DEV void test_tri_pair(Ray &r, const TriPair &P, int f1, int f2, bool want) {
   float th = 0.0f;
   bool hit = ray_tri<CUPID>(r, P.a1, P.b1, P.c1, th) && want;
-  if (ANY) {
-    if (hit && th >= 0.0f && th < r.best) { r.face = f1; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
-  } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f1 < r.face))) {
-    r.best = th;
-    r.face = f1;
-  }
+  accept_hit<ANY>(r, hit, th, f1);
   if (f2 >= 0) {
     th = 0.0f;
     hit = ray_tri<CUPID>(r, P.a2, P.b2, P.c2, th) && want;
-    if (ANY) {
-      if (hit && th >= 0.0f && th < r.best) { r.face = f2; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
-    } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f2 < r.face))) {
-      r.best = th;
-      r.face = f2;
-    }
+    accept_hit<ANY>(r, hit, th, f2);
   }
 }
 // A leaf and the second triangle of a two-triangle leaf (f2 < 0: none).  AGX_RAY_PAIRLOAD: both triangles are fetched before the
@@ -335,7 +360,12 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   tmin = fmaxf(tmin, kzc == 2 ? (neg ? t1 : t0) : fminf(t0, t1)); tmax = fminf(tmax, kzc == 2 ? (neg ? t0 : t1) : fmaxf(t0, t1));
   tmax *= 1.0000004f;
   tnear = tmin;
-#if AGX_RAY_NOACTIVE  // a retired lane carries best = -inf (traverse): the last comparison fails for it
+#if AGX_RAY_NOACTIVE && AGX_RAY_FLAT
+  // tmax >= 0 and tmax >= tmin and tmin <= best, with best >= 0 for a live lane and -inf for a retired one (traverse), is the
+  // ONE comparison max(tmin, 0) <= min(tmax, best): a v_cmp that writes the packet's mask directly (the ballot of a conjunction
+  // goes through a VGPR)
+  return fmaxf(tmin, 0.0f) <= fminf(tmax, r.best);
+#elif AGX_RAY_NOACTIVE  // a retired lane carries best = -inf (traverse): the last comparison fails for it
   return (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
 #else
   return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
@@ -526,8 +556,13 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
     }
     if (cr < 0) {
       if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
+#if AGX_RAY_VOTEMASK && AGX_RAY_NOACTIVE
+        mr &= vote(tr <= r.best);  // (the ballot of ONE comparison is the comparison's own mask; a conjunction goes through a VGPR)
+        hr = hr && (tr <= r.best);
+#else
         hr = hr && (tr <= r.best) && (AGX_RAY_NOACTIVE || r.active);
         mr = vote(hr);
+#endif
       }
       if (mr) {
         test_leaf_pair<ANY, CUPID>(r, tris, ~cr, cr2, hr, upid);
@@ -538,9 +573,15 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
     int next = -1;
     if (ml && mr) {
       // majority vote on which child is nearer among lanes that hit both
+#if AGX_RAY_VOTEMASK
+      const unsigned long long both = ml & mr;
+      const unsigned long long lfirst = both & vote(tl <= tr);
+      const bool left_first = both ? (2 * (int)__popcll(lfirst) >= (int)__popcll(both)) : ((int)__popcll(ml) >= (int)__popcll(mr));
+#else
       unsigned long long both = vote(hl && hr);
       unsigned long long lfirst = vote(hl && hr && tl <= tr);
       bool left_first = both ? (2 * __popcll(lfirst) >= __popcll(both)) : (__popcll(ml) >= __popcll(mr));
+#endif
       next = left_first ? cl : cr;
       int far = left_first ? cr : cl;
       stack = (lane == (sp & (kStackDepth - 1))) ? far : stack;  // push: entry sp lives in lane sp
