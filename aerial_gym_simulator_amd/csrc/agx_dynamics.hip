@@ -97,6 +97,15 @@ AGX_DEV T &soa_at(T *base, int c, int n, int i) {
                                 (size_t)((unsigned)i * (unsigned)sizeof(T)));
 }
 #define AGX_AT(p, c) agx::soa_at((p), (c), n, i)
+// The lane-quad kernels index a column by the lane's component (c0 + l): the per-lane part of the address, (l n + i) sizeof(T),
+// is computed ONCE as a 32-bit byte offset (n <= 65536 there) and every access is scalar column base + that offset -- instead of
+// a 64-bit multiply-add and two 64-bit adds on the vector unit per access, in front of the kernel's first load.
+template <class T>
+AGX_DEV T &soa_at_off(T *base, int c, int n, unsigned off_bytes) {
+  T *col = base + (ptrdiff_t)c * (ptrdiff_t)n;
+  return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(col)) + (size_t)off_bytes);
+}
+#define AGX_QAT(p, c, off) agx::soa_at_off((p), (c), n, (off))
 
 AGX_DEV EnvState load_state(const float *__restrict__ s, int n, int i) {
   EnvState e;
@@ -832,22 +841,23 @@ __global__ void __launch_bounds__(64, 1)
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2;  // component of a 4-vector / of a 3-vector (lane 3 repeats z: don't care)
   const int i = blockIdx.x * 16 + (tid >> 2);  // env
+  const unsigned ol = ((unsigned)l * (unsigned)n + (unsigned)i) * 4u, ol3 = ((unsigned)l3 * (unsigned)n + (unsigned)i) * 4u;  // AGX_QAT
   bool reset = false;
   if (blockIdx.x == 0) push_publish_previous(B);  // peer push: the previous step's rows have landed everywhere
   const uint32_t push_peek = blockIdx.x == 0 ? push_wait_peek(B) : 0u;  // ... and this step's slot: looked at when the kernel is done
   if (i < n) {
     // ---- loads: one instruction per vector
-    float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
-    float u[1] = {AGX_AT(B.motor_thrust, l)};  // motor l
-    const float kT[1] = {P.use_rps ? AGX_AT(B.motor_kT, l) : 1.0f};
-    const float tinc[1] = {B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l) : P.tau_inc_uniform};
-    const float tdec[1] = {B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l) : P.tau_dec_uniform};
+    float p = AGX_QAT(B.state, 0, ol3), q = AGX_QAT(B.state, 3, ol), v = AGX_QAT(B.state, 7, ol3), w = AGX_QAT(B.state, 10, ol3);
+    float u[1] = {AGX_QAT(B.motor_thrust, 0, ol)};  // motor l
+    const float kT[1] = {P.use_rps ? AGX_QAT(B.motor_kT, 0, ol) : 1.0f};
+    const float tinc[1] = {B.motor_tau_inc ? AGX_QAT(B.motor_tau_inc, 0, ol) : P.tau_inc_uniform};
+    const float tdec[1] = {B.motor_tau_dec ? AGX_QAT(B.motor_tau_dec, 0, ol) : P.tau_dec_uniform};
     const float a_in = actions_in[(size_t)i * 4 + l];
-    const float a_old = AGX_AT(B.actions, l);
-    const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
-    const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
-    const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
-    const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
+    const float a_old = AGX_QAT(B.actions, 0, ol);
+    const float kp = B.gains ? AGX_QAT(B.gains, 0, ol3) : P.gains_uniform[0 + l3];
+    const float kv = B.gains ? AGX_QAT(B.gains, 3, ol3) : P.gains_uniform[3 + l3];
+    const float kr = B.gains ? AGX_QAT(B.gains, 6, ol3) : P.gains_uniform[6 + l3];
+    const float kw = B.gains ? AGX_QAT(B.gains, 9, ol3) : P.gains_uniform[9 + l3];
     const QuadConsts<4> C = load_quad_consts<4>(P, l, l3);
 
     // ---- update_states + controller (position_control.py:20-51)
@@ -866,37 +876,37 @@ __global__ void __launch_bounds__(64, 1)
     // ---- allocation + motor model + body wrench, rigid-body update
     float fb, tb;
     quad_allocate<4>(P, C, l == 2 ? fz : 0.0f, torque, u, kT, tinc, tdec, fb, tb);
-    if (B.body_force && l < 3) AGX_AT(B.body_force, l) = fb;
+    if (B.body_force && l < 3) AGX_QAT(B.body_force, 0, ol) = fb;
     quad_integrate(P, C, p, q, v, w, fb, tb, l);
 
     // ---- stores: state, derived, motors, controller output, actions
-    if (l < 3) AGX_AT(B.state, 0 + l) = p;
-    AGX_AT(B.state, 3 + l) = q;
+    if (l < 3) AGX_QAT(B.state, 0, ol) = p;
+    AGX_QAT(B.state, 3, ol) = q;
     if (l < 3) {
-      AGX_AT(B.state, 7 + l) = v;
-      AGX_AT(B.state, 10 + l) = w;
-      AGX_AT(B.derived, 0 + l) = d.euler;
-      AGX_AT(B.derived, 7 + l) = d.vveh;
-      AGX_AT(B.derived, 10 + l) = d.vbody;
-      AGX_AT(B.derived, 13 + l) = d.wbody;
+      AGX_QAT(B.state, 7, ol) = v;
+      AGX_QAT(B.state, 10, ol) = w;
+      AGX_QAT(B.derived, 0, ol) = d.euler;
+      AGX_QAT(B.derived, 7, ol) = d.vveh;
+      AGX_QAT(B.derived, 10, ol) = d.vbody;
+      AGX_QAT(B.derived, 13, ol) = d.wbody;
     }
-    AGX_AT(B.derived, 3 + l) = d.qveh;
-    AGX_AT(B.motor_thrust, l) = u[0];
+    AGX_QAT(B.derived, 3, ol) = d.qveh;
+    AGX_QAT(B.motor_thrust, 0, ol) = u[0];
     if (B.wrench_cmd) {
       if (l < 3) {
-        AGX_AT(B.wrench_cmd, l) = l == 2 ? fz : 0.0f;
-        AGX_AT(B.wrench_cmd, 3 + l) = torque;
+        AGX_QAT(B.wrench_cmd, 0, ol) = l == 2 ? fz : 0.0f;
+        AGX_QAT(B.wrench_cmd, 3, ol) = torque;
       }
     }
-    AGX_AT(B.prev_actions, l) = a_old;  // RobotManagerIGE.pre_physics_step: prev <- cur, cur <- action
-    AGX_AT(B.actions, l) = a_in;
+    AGX_QAT(B.prev_actions, 0, ol) = a_old;  // RobotManagerIGE.pre_physics_step: prev <- cur, cur <- action
+    AGX_QAT(B.actions, 0, ol) = a_in;
 
     // ---- EnvManager bookkeeping + the position task's reward / truncation / reset set (position_setpoint_task.py:245-282)
     const int steps = B.sim_steps[i] + 1;
     bool crashed = false, trunc = false;
     float rew = 0.0f;
     if (T.kind == AGX_TASK_POSITION) {
-      const float tgt = AGX_AT(T.target, l3);
+      const float tgt = AGX_QAT(T.target, 0, ol3);
       const float pe_t = q4::quat_apply(q4::conj(d.qveh), tgt - p);  // quat_apply_inverse
       const float dist = q4::norm3(pe_t);
       // 3 exp(-8 d^2) + 2 exp(-4 d^2): both exponentials in one evaluation (lanes 0 / 1)
@@ -1042,27 +1052,28 @@ __global__ void __launch_bounds__(64, 1)
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2, slot = tid >> 2;
   const int i = blockIdx.x * 16 + slot;
+  const unsigned ol = ((unsigned)l * (unsigned)n + (unsigned)i) * 4u, ol3 = ((unsigned)l3 * (unsigned)n + (unsigned)i) * 4u;  // AGX_QAT
   bool reset = false;
   if (blockIdx.x == 0) push_publish_previous(B);  // peer push: the previous step's rows have landed everywhere
   const uint32_t push_peek = blockIdx.x == 0 ? push_wait_peek(B) : 0u;  // ... and this step's slot: looked at when the kernel is done
   if (i < n) {
-    float p = AGX_AT(B.state, 0 + l3), q = AGX_AT(B.state, 3 + l), v = AGX_AT(B.state, 7 + l3), w = AGX_AT(B.state, 10 + l3);
+    float p = AGX_QAT(B.state, 0, ol3), q = AGX_QAT(B.state, 3, ol), v = AGX_QAT(B.state, 7, ol3), w = AGX_QAT(B.state, 10, ol3);
     float u[MH], kT[MH], tinc[MH], tdec[MH];
 #pragma unroll
     for (int h = 0; h < MH; ++h) {  // motors l and l + 4
-      u[h] = AGX_AT(B.motor_thrust, l + 4 * h);
-      kT[h] = P.use_rps ? AGX_AT(B.motor_kT, l + 4 * h) : 1.0f;
-      tinc[h] = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, l + 4 * h) : P.tau_inc_uniform;
-      tdec[h] = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, l + 4 * h) : P.tau_dec_uniform;
+      u[h] = AGX_QAT(B.motor_thrust, 4 * h, ol);
+      kT[h] = P.use_rps ? AGX_QAT(B.motor_kT, 4 * h, ol) : 1.0f;
+      tinc[h] = B.motor_tau_inc ? AGX_QAT(B.motor_tau_inc, 4 * h, ol) : P.tau_inc_uniform;
+      tdec[h] = B.motor_tau_dec ? AGX_QAT(B.motor_tau_dec, 4 * h, ol) : P.tau_dec_uniform;
     }
     const float a_in = actions_in[(size_t)i * A + l];  // (a0 .. a3); fully actuated: position set-point in lanes 0..2
-    const float a_old = AGX_AT(B.actions, l);
+    const float a_old = AGX_QAT(B.actions, 0, ol);
     const float a_in2 = FA ? actions_in[(size_t)i * A + 3 + l] : 0.0f;  // fully actuated: orientation set-point xyzw
-    const float a_old2 = FA ? AGX_AT(B.actions, 3 + l) : 0.0f;
-    const float kp = B.gains ? AGX_AT(B.gains, 0 + l3) : P.gains_uniform[0 + l3];
-    const float kv = B.gains ? AGX_AT(B.gains, 3 + l3) : P.gains_uniform[3 + l3];
-    const float kr = B.gains ? AGX_AT(B.gains, 6 + l3) : P.gains_uniform[6 + l3];
-    const float kw = B.gains ? AGX_AT(B.gains, 9 + l3) : P.gains_uniform[9 + l3];
+    const float a_old2 = FA ? AGX_QAT(B.actions, 3, ol) : 0.0f;
+    const float kp = B.gains ? AGX_QAT(B.gains, 0, ol3) : P.gains_uniform[0 + l3];
+    const float kv = B.gains ? AGX_QAT(B.gains, 3, ol3) : P.gains_uniform[3 + l3];
+    const float kr = B.gains ? AGX_QAT(B.gains, 6, ol3) : P.gains_uniform[6 + l3];
+    const float kw = B.gains ? AGX_QAT(B.gains, 9, ol3) : P.gains_uniform[9 + l3];
     const QuadConsts<M> C = load_quad_consts<M>(P, l, l3);
     const float dmax = B.disturb_max[l3], dmax_t = B.disturb_max[3 + l3];
     const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions (the same every sub-step)
@@ -1096,7 +1107,7 @@ __global__ void __launch_bounds__(64, 1)
         thi = fmaxf(thi, p);
       }
     }
-    if (B.body_force && l < 3 && k > 0) AGX_AT(B.body_force, l) = fb;
+    if (B.body_force && l < 3 && k > 0) AGX_QAT(B.body_force, 0, ol) = fb;
     // ---- obstacles: the env's boxes over the four lanes
     bool crashed = false;
     if (B.boxes && k > 0) {
@@ -1121,47 +1132,47 @@ __global__ void __launch_bounds__(64, 1)
       crashed = ((vote(hit) >> (tid & 60)) & 0xFull) != 0ull;
     }
     // ---- stores
-    if (l < 3) AGX_AT(B.state, 0 + l) = p;
-    AGX_AT(B.state, 3 + l) = q;
+    if (l < 3) AGX_QAT(B.state, 0, ol) = p;
+    AGX_QAT(B.state, 3, ol) = q;
     if (l < 3) {
-      AGX_AT(B.state, 7 + l) = v;
-      AGX_AT(B.state, 10 + l) = w;
+      AGX_QAT(B.state, 7, ol) = v;
+      AGX_QAT(B.state, 10, ol) = w;
     }
     if (k > 0) {
       if (l < 3) {
-        AGX_AT(B.derived, 0 + l) = d.euler;
-        AGX_AT(B.derived, 7 + l) = d.vveh;
-        AGX_AT(B.derived, 10 + l) = d.vbody;
-        AGX_AT(B.derived, 13 + l) = d.wbody;
+        AGX_QAT(B.derived, 0, ol) = d.euler;
+        AGX_QAT(B.derived, 7, ol) = d.vveh;
+        AGX_QAT(B.derived, 10, ol) = d.vbody;
+        AGX_QAT(B.derived, 13, ol) = d.wbody;
       }
-      AGX_AT(B.derived, 3 + l) = d.qveh;
+      AGX_QAT(B.derived, 3, ol) = d.qveh;
 #pragma unroll
-      for (int h = 0; h < MH; ++h) AGX_AT(B.motor_thrust, l + 4 * h) = u[h];
+      for (int h = 0; h < MH; ++h) AGX_QAT(B.motor_thrust, 4 * h, ol) = u[h];
       if (B.wrench_cmd && l < 3) {
-        AGX_AT(B.wrench_cmd, l) = force;
-        AGX_AT(B.wrench_cmd, 3 + l) = torque;
+        AGX_QAT(B.wrench_cmd, 0, ol) = force;
+        AGX_QAT(B.wrench_cmd, 3, ol) = torque;
       }
       // RobotManagerIGE.pre_physics_step runs every sub-step: prev <- cur, cur <- action
       if (!FA || l < 3) {
-        AGX_AT(B.prev_actions, l) = k >= 2 ? a_in : a_old;
-        AGX_AT(B.actions, l) = a_in;
+        AGX_QAT(B.prev_actions, 0, ol) = k >= 2 ? a_in : a_old;
+        AGX_QAT(B.actions, 0, ol) = a_in;
       }
       if (FA) {
-        AGX_AT(B.prev_actions, 3 + l) = k >= 2 ? a_in2 : a_old2;
-        AGX_AT(B.actions, 3 + l) = a_in2;
+        AGX_QAT(B.prev_actions, 3, ol) = k >= 2 ? a_in2 : a_old2;
+        AGX_QAT(B.actions, 3, ol) = a_in2;
       }
     }
     // ---- EnvManager bookkeeping + task epilogue (scalar code, the same in the four lanes; lane 0 stores)
     const float acur = k > 0 ? a_in : a_old;
-    const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : AGX_AT(B.prev_actions, l));
+    const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : AGX_QAT(B.prev_actions, 0, ol));
     // action component 3 as the navigation reward reads it: a3, or the first orientation component of the 7-D command
     const float acur3 = FA ? q4::bc<0>(k > 0 ? a_in2 : a_old2) : q4::bc<3>(acur);
-    const float aprev3 = FA ? q4::bc<0>(k >= 2 ? a_in2 : (k == 1 ? a_old2 : AGX_AT(B.prev_actions, 3 + l))) : q4::bc<3>(aprev);
+    const float aprev3 = FA ? q4::bc<0>(k >= 2 ? a_in2 : (k == 1 ? a_old2 : AGX_QAT(B.prev_actions, 3, ol))) : q4::bc<3>(aprev);
     const int steps = B.sim_steps[i] + 1;
     bool trunc = false;
     float rew = 0.0f;
     if (T.kind != AGX_TASK_NONE) {
-      const float tgt = AGX_AT(T.target, l3);
+      const float tgt = AGX_QAT(T.target, 0, ol3);
       if (T.kind == AGX_TASK_POSITION) {
         EnvState s;
         s.p = V3{q4::bc<0>(p), q4::bc<1>(p), q4::bc<2>(p)};
@@ -1172,11 +1183,11 @@ __global__ void __launch_bounds__(64, 1)
                               V3{q4::bc<0>(d.wbody), q4::bc<1>(d.wbody), q4::bc<2>(d.wbody)},
                               V3{q4::bc<0>(tgt), q4::bc<1>(tgt), q4::bc<2>(tgt)}, crashed);
       } else {
-        const float ppe = AGX_AT(T.pos_err, l3);
+        const float ppe = AGX_QAT(T.pos_err, 0, ol3);
         const float pe = q4::quat_rotate_inverse(d.qveh, tgt - p);
         if (l < 3) {
-          AGX_AT(T.prev_pos_err, l) = ppe;
-          AGX_AT(T.pos_err, l) = pe;
+          AGX_QAT(T.prev_pos_err, 0, ol) = ppe;
+          AGX_QAT(T.pos_err, 0, ol) = pe;
         }
         rew = reward_navigation(T.rp, T.curriculum_progress, V3{q4::bc<0>(pe), q4::bc<1>(pe), q4::bc<2>(pe)},
                                 V3{q4::bc<0>(ppe), q4::bc<1>(ppe), q4::bc<2>(ppe)}, q4::bc<0>(acur), q4::bc<2>(acur), acur3,
@@ -1644,6 +1655,7 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2;
   const int i = blockIdx.x * 16 + (tid >> 2);
+  const unsigned ol = ((unsigned)l * (unsigned)n + (unsigned)i) * 4u, ol3 = ((unsigned)l3 * (unsigned)n + (unsigned)i) * 4u;  // AGX_QAT
   if (blockIdx.x == 0 && tid == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
   push_wait_for_slot(B);
   const bool valid = i < n;
@@ -1651,9 +1663,9 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
   bool mine = false;
   int ep = 0;
   if (valid) {  // every load before the flag is looked at
-    p = AGX_AT(B.state, 0 + l3); q = AGX_AT(B.state, 3 + l); v = AGX_AT(B.state, 7 + l3); w = AGX_AT(B.state, 10 + l3);
-    vbody = AGX_AT(B.derived, 10 + l3); wbody = AGX_AT(B.derived, 13 + l3);
-    tgt = AGX_AT(target, l3);
+    p = AGX_QAT(B.state, 0, ol3); q = AGX_QAT(B.state, 3, ol); v = AGX_QAT(B.state, 7, ol3); w = AGX_QAT(B.state, 10, ol3);
+    vbody = AGX_QAT(B.derived, 10, ol3); wbody = AGX_QAT(B.derived, 13, ol3);
+    tgt = AGX_QAT(target, 0, ol3);
     mine = B.reset_mask[i] != 0;
     if (B.episode_count) ep = B.episode_count[i];
   }
@@ -1680,12 +1692,12 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
     const QuadDerived d = update_states_quad(q, v, w);
     if (valid) {
       if (l < 3) {
-        AGX_AT(B.derived, 0 + l) = d.euler;
-        AGX_AT(B.derived, 7 + l) = d.vveh;
-        AGX_AT(B.derived, 10 + l) = d.vbody;
-        AGX_AT(B.derived, 13 + l) = d.wbody;
+        AGX_QAT(B.derived, 0, ol) = d.euler;
+        AGX_QAT(B.derived, 7, ol) = d.vveh;
+        AGX_QAT(B.derived, 10, ol) = d.vbody;
+        AGX_QAT(B.derived, 13, ol) = d.wbody;
       }
-      AGX_AT(B.derived, 3 + l) = d.qveh;
+      AGX_QAT(B.derived, 3, ol) = d.qveh;
     }
     vbody = d.vbody;
     wbody = d.wbody;
