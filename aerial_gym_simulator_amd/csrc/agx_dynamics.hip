@@ -1388,23 +1388,38 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
         const int x = x0 + lane;
         float m = INFINITY;
         if (x < Wv) {
-          for (int y = y0; y < y1; ++y) {
+          // one wave per env: the rows of a cell are requested TOGETHER (batches of 8 loads in flight) -- issued one by one, the
+          // 48 row loads of a 64 x 48 frame were 48 memory latencies in sequence and the whole kernel (min is exact: any order)
+          for (int yb = y0; yb < y1; yb += 8) {
             if (vec4) {
-              const float4 v4 = *reinterpret_cast<const float4 *>(img + (size_t)y * W + 4 * x);
-              const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+              float4 v4[8];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                m = fminf(m, vv[k]);
-                float v10 = 10.0f * vv[k];
+              for (int r = 0; r < 8; ++r) {
+                const int y = min(yb + r, y1 - 1);  // (a row read twice changes no minimum)
+                v4[r] = *reinterpret_cast<const float4 *>(img + (size_t)y * W + 4 * x);
+              }
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const float vv[4] = {v4[r].x, v4[r].y, v4[r].z, v4[r].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  m = fminf(m, vv[k]);
+                  float v10 = 10.0f * vv[k];
+                  if (v10 < 0.0f) v10 = 10.0f;
+                  imin = fminf(imin, v10);
+                }
+              }
+            } else {
+              float vr[8];
+#pragma unroll
+              for (int r = 0; r < 8; ++r) vr[r] = img[(size_t)min(yb + r, y1 - 1) * W + x];
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                m = fminf(m, vr[r]);
+                float v10 = 10.0f * vr[r];
                 if (v10 < 0.0f) v10 = 10.0f;
                 imin = fminf(imin, v10);
               }
-            } else {
-              const float v = img[(size_t)y * W + x];
-              m = fminf(m, v);
-              float v10 = 10.0f * v;
-              if (v10 < 0.0f) v10 = 10.0f;
-              imin = fminf(imin, v10);
             }
           }
         }

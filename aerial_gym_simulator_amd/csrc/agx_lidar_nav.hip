@@ -40,8 +40,18 @@ __global__ void __launch_bounds__(256) k_lidar_image_obs(AgxEnvBuffers B, int n,
   const V3 lv = V3{B.state[7 * n + i], B.state[8 * n + i], B.state[9 * n + i]};
   const float *pc = pointcloud + (size_t)i * npts * 3;
   float tmin = INFINITY;
-  for (int j = tid; j < npts; j += blockDim.x) {
-    V3 d = V3{pc[3 * j] - p.x, pc[3 * j + 1] - p.y, pc[3 * j + 2] - p.z};
+  // four points per trip, their twelve loads requested before the first is used (the loop was one memory latency per point)
+  for (int j0 = tid; j0 < npts; j0 += 4 * blockDim.x) {
+    float raw[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = min(j0 + q * (int)blockDim.x, npts - 1);  // (a point read twice changes neither its range nor the minimum)
+      raw[q][0] = pc[3 * j]; raw[q][1] = pc[3 * j + 1]; raw[q][2] = pc[3 * j + 2];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+    const int j = min(j0 + q * (int)blockDim.x, npts - 1);
+    V3 d = V3{raw[q][0] - p.x, raw[q][1] - p.y, raw[q][2] - p.z};
     float r = norm(d);  // torch.norm(world_dir_vectors, dim=-1)
     float den = r + 1e-6f;
     V3 u = V3{d.x / den, d.y / den, d.z / den};
@@ -52,6 +62,7 @@ __global__ void __launch_bounds__(256) k_lidar_image_obs(AgxEnvBuffers B, int n,
     float vc = lv.x * u.x + lv.y * u.y + lv.z * u.z;
     float t = (vc > 0.0f) ? rc / (vc + 1e-6f) : 10.0f;
     tmin = fminf(tmin, t);
+    }
   }
   for (int off = 32; off > 0; off >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, off));
   if ((tid & 63) == 0) wmin[tid >> 6] = tmin;
