@@ -159,6 +159,32 @@ AGX_DEV void node_box(const float *box, const unsigned long long *keys, const fl
   }
 }
 
+// Bitonic sort of m (a power of two) 64-bit keys in LDS by the whole workgroup.
+// A thread owns elements tid + q * kBvhThreads, so a WAVE owns whole 64-element blocks: the stages with j < 64 exchange
+// inside a block, i.e. inside the wave (LDS operations of a wave execute in order), and need no workgroup barrier.
+// Barriers remain where the next stage reads what other waves wrote: 21 of the 66 stages for 2048 keys.
+AGX_DEV void bitonic_sort_lds(unsigned long long *keys, int m, int tid) {
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < m; i += kBvhThreads) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long a = keys[i], b = keys[ixj];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      const int next_j = j > 1 ? (j >> 1) : k;  // (the stage after j == 1 is (2k, k))
+      if (j >= 64 || next_j >= 64) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // compiler: keep the stages' LDS accesses in order
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
 // Node record written to HBM (16 floats):
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
@@ -187,14 +213,32 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   float *ocen = reinterpret_cast<float *>(counter);  // [K][8] centre, largest extent (< 0: parked), AABB lo, -; counter is not live yet
   const int K = ppo > 0 ? nt / ppo : 0;
+  // (every thread takes triangles -- nine independent loads each -- and leaves their bounds in LDS; the object's thread then
+  //  reduces ppo LDS entries.  One thread per object walking its 3 ppo vertices was 36 memory latencies in sequence: the longest
+  //  phase of the build.  The scratch is the box region, one entry longer than it: it runs into `parent`, not live yet.)
+  float *tb = box;  // [nt][6]
+  if (ppo > 0) {
+    for (int f = tid; f < nt; f += kBvhThreads) {
+      const float *t = tris + (size_t)f * 9;
+      float v[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = t[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        tb[6 * f + c] = fminf(fminf(v[c], v[3 + c]), v[6 + c]);
+        tb[6 * f + 3 + c] = fmaxf(fmaxf(v[c], v[3 + c]), v[6 + c]);
+      }
+    }
+    __syncthreads();
+  }
   for (int o = tid; o < K; o += kBvhThreads) {
     const float *t = tris + (size_t)o * ppo * 9;
     float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int v = 0; v < 3 * ppo; ++v)
+    for (int j = 0; j < ppo; ++j)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        alo[c] = fminf(alo[c], t[3 * v + c]);
-        ahi[c] = fmaxf(ahi[c], t[3 * v + c]);
+        alo[c] = fminf(alo[c], tb[6 * (o * ppo + j) + c]);
+        ahi[c] = fmaxf(ahi[c], tb[6 * (o * ppo + j) + 3 + c]);
       }
     const bool parked = tri_parked(t);
     float big = 0.0f;
@@ -218,6 +262,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       hi[c] = fmaxf(hi[c], cen);
     }
   }
+  if (ppo > 0) __syncthreads();  // the reduction scratch below shares the region the triangle bounds were read from
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     red[c * kBvhThreads + tid] = lo[c];
@@ -243,7 +288,91 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   }
   // --- keys: [large flag | 30-bit Morton code of the sort centre] . [triangle index]
   float max_ext = fmaxf(fmaxf(red[3 * kBvhThreads] - blo[0], red[4 * kBvhThreads] - blo[1]), red[5 * kBvhThreads] - blo[2]);
-  for (int f = tid; f < npad; f += kBvhThreads) {
+  // --- objects of ppo triangles each (boxes: 12): the order of the keys is the order of the OBJECTS' codes, and inside an
+  // object (face class, index).  So sort the K object keys (128 instead of 2048: the full sort was 35 of the build's 67 us) and
+  // RANK every triangle inside its object against the ppo - 1 others.  This is the full sort's order exactly unless two
+  // objects that are in the env share all 27 upper Morton bits -- their triangles would interleave by face class --, which is
+  // looked for, and then the full sort runs.  (Parked objects all carry the code 0xFFFFFFFE: index order, which the object
+  // keys' low word gives.)
+  bool presorted = false;
+#ifndef AGX_BVH_EXPERIMENT
+  if (ppo >= 2 && K >= 2 && K * ppo == nt) {
+    __syncthreads();  // (the reduction's result is in registers everywhere: its scratch is reused)
+    int Kpad = 1;
+    while (Kpad < K) Kpad <<= 1;
+    unsigned long long *okey = reinterpret_cast<unsigned long long *>(box);  // [Kpad] code . object
+    uint32_t *ocode = reinterpret_cast<uint32_t *>(okey + Kpad);             // [K]    the object's code (Morton | large flag, or parked)
+    int *orank = reinterpret_cast<int *>(ocode + K);                         // [K]    position of the object in the order
+    int *tie = orank + K;                                                     // [1]
+    uint8_t *cls = reinterpret_cast<uint8_t *>(tie + 1);                      // [nt]   face class of the triangle (0 when parked)
+    if (tid == 0) *tie = 0;
+    for (int o = tid; o < Kpad; o += kBvhThreads) {
+      unsigned long long k64 = ~0ull;
+      if (o < K) {
+        const float *oc = ocen + 8 * o;
+        uint32_t code = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float qv = fminf(fmaxf((oc[c] - blo[c]) * inv[c], 0.0f), 1023.0f);
+          code |= expand_bits10((uint32_t)qv) << (2 - c);
+        }
+        const float big = oc[3];
+        const bool parked = big < 0.0f;
+        if (big > kBvhLargeFraction * max_ext) code |= 1u << 30;
+        if (parked) code = 0xFFFFFFFEu;
+        ocode[o] = code;
+        k64 = ((unsigned long long)(parked ? code : (code & ~7u)) << 32) | (unsigned long long)(uint32_t)o;
+      }
+      okey[o] = k64;
+    }
+    for (int f = tid; f < nt; f += kBvhThreads) {
+      const float *t = tris + (size_t)f * 9;
+      uint32_t fc = 0;
+      if (!(ocen[8 * (f / ppo) + 3] < 0.0f)) {
+        V3 e1 = V3{t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2 = V3{t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+        V3 nrm = cross_plain(e1, e2);
+        float ax = fabsf(nrm.x), ay = fabsf(nrm.y), az = fabsf(nrm.z);
+        int d = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+        float comp = d == 0 ? nrm.x : (d == 1 ? nrm.y : nrm.z);
+        fc = (uint32_t)(2 * d + (comp < 0.0f ? 1 : 0));
+      }
+      cls[f] = (uint8_t)fc;
+    }
+    __syncthreads();
+    bitonic_sort_lds(okey, Kpad, tid);
+    __syncthreads();
+    for (int p = tid; p < K; p += kBvhThreads) {
+      const unsigned long long a = okey[p];
+      orank[(int)(uint32_t)(a & 0xFFFFFFFFull)] = p;
+      if (p + 1 < K) {
+        const uint32_t c0 = (uint32_t)(a >> 32), c1 = (uint32_t)(okey[p + 1] >> 32);
+        if (c0 == c1 && c0 != 0xFFFFFFFEu) *tie = 1;  // (every writer stores the same value)
+      }
+    }
+    __syncthreads();
+    presorted = *tie == 0;  // the same for the whole workgroup
+    if (presorted) {
+      for (int f = tid; f < npad; f += kBvhThreads) {
+        if (f < nt) {
+          const int o = f / ppo, g0 = o * ppo;
+          const uint32_t oc = ocode[o];
+          const uint32_t cf = cls[f];
+          const uint32_t code = oc == 0xFFFFFFFEu ? oc : ((oc & ~7u) | cf);
+          int r = 0;
+          for (int g = g0; g < g0 + ppo; ++g) {
+            const uint32_t cg = cls[g];
+            r += (cg < cf || (cg == cf && g < f)) ? 1 : 0;
+          }
+          keys[orank[o] * ppo + r] = ((unsigned long long)code << 32) | (unsigned long long)(uint32_t)f;
+        } else {
+          keys[f] = ~0ull;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#endif
+  for (int f = tid; f < npad && !presorted; f += kBvhThreads) {
     unsigned long long key = ~0ull;
     if (f < nt) {
       const float *t = tris + (size_t)f * 9;
@@ -294,29 +423,8 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     keys[f] = key;
   }
   __syncthreads();
-  // --- bitonic sort in LDS
-  // A thread owns elements tid + m * kBvhThreads, so a WAVE owns whole 64-element blocks: the stages with j < 64 exchange
-  // inside a block, i.e. inside the wave (LDS operations of a wave execute in order), and need no workgroup barrier.
-  // Barriers remain where the next stage reads what other waves wrote: 21 of the 66 stages for 2048 keys.
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npad; i += kBvhThreads) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          unsigned long long a = keys[i], b = keys[ixj];
-          bool up = (i & k) == 0;
-          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-        }
-      }
-      const int next_j = j > 1 ? (j >> 1) : k;  // (the stage after j == 1 is (2k, k))
-      if (j >= 64 || next_j >= 64) {
-        __syncthreads();
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // compiler: keep the stages' LDS accesses in order
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
+  // --- sort
+  if (!presorted) bitonic_sort_lds(keys, npad, tid);
   __syncthreads();
   // --- Karras 2012 radix tree: internal nodes 0..nt-2, leaves nt-1+i (i = sorted position)
   const int n_int = nt - 1;

@@ -81,12 +81,15 @@ def main():
     px = sensor.pixels.cpu().numpy()
     seg = sensor.segmentation_pixels.cpu().numpy() if getattr(sensor, "segmentation_pixels", None) is not None else np.zeros(1, np.int32)
     out["raycast_us"] = t * 1e6
+    nodes = sc.bvh_nodes.cpu().numpy() if which != "wide" else np.zeros(1, np.float32)
     if which == "base":
-        np.savez(path, px=px, seg=seg)
+        np.savez(path, px=px, seg=seg, nodes=nodes)
     else:
         ref = np.load(path)
         out["frame_bit_identical"] = bool(np.array_equal(ref["px"].view(np.int32), px.view(np.int32)) and np.array_equal(ref["seg"], seg))
         out["pixels_differing"] = int((ref["px"].view(np.int32) != px.view(np.int32)).sum())
+        if which == "variant" and "nodes" in ref.files:  # same builder input -> are the TREES the same?
+            out["bvh_nodes_bit_identical"] = bool(np.array_equal(ref["nodes"].view(np.int32), nodes.view(np.int32)))
     print(json.dumps(out))
 
 
