@@ -199,6 +199,8 @@ class StepGather:
         handle = C.c_void_p()
         rc = lib.agx_exchange_create_push(dist.get_rank(self.group), self.world, index, self._count, C.byref(handle))
         err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
+        if os.environ.get("AGX_TEST_PUSH_SETUP_FAIL") == "1" and rc == 0:  # test hook: a platform that refuses the peer mappings
+            rc, err = 1, "injected set-up failure (AGX_TEST_PUSH_SETUP_FAIL)"
         mine = (C.c_char * 128)()
         if rc == 0:
             rc = lib.agx_exchange_push_export(handle, mine, 128)

@@ -513,6 +513,7 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
     dog = threading.Timer(limit_s, give_up)
     dog.daemon = True
     dog.start()
+    stage = "build"
     try:
         torch.cuda.empty_cache()
         task = make_task("dynamics", args.num_envs, device, args.strict_rng, rank)
@@ -520,7 +521,9 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
         N, A = task.num_envs, task.task_config.action_space_dim
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
+        stage = "setup"  # a backend that cannot be SET UP fails on every rank together (StepGather._agree) and leaves nothing behind
         gb = StepGather(N, task.task_obs["observations"].shape[1], device, env=task.sim_env, reward=task.rewards, backend=backend)
+        stage = "run"
         res["backend"] = gb.backend
         res["producer_hand_off"] = "device flag (step_signal)" if gb.signal is not None else "event"
         if backend == "peer_push":
@@ -547,15 +550,20 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
             gb2.close()
     except Exception as e:  # noqa: BLE001  (reported, the process-group numbers stand)
         res["error"] = f"{type(e).__name__}: {e}"
+        res["failed_in"] = stage
     # a rank that failed alone leaves the others inside a collective: the watchdog stays armed until every rank
     # has reached this barrier, and all ranks agree on whether the numbers of this leg count
-    ok = torch.tensor([0 if "error" in res else 1], device=device, dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    all_ok = int(ok.item()) == 1
+    # 0 = fine, 1 = the exchange could not be set up (every rank, together, nothing left behind), 2 = anything else
+    code = torch.tensor([0 if "error" not in res else (1 if stage == "setup" else 2)], device=device, dtype=torch.int32)
+    dist.all_reduce(code, op=dist.ReduceOp.MAX)
+    worst = int(code.item())
+    all_ok = worst == 0
     dog.cancel()
     if not all_ok and "error" not in res:
         res["error"] = "another rank failed"
     report[backend] = res
+    if worst == 1:  # e.g. peer mappings refused on this platform: the next backend can still be measured
+        return "setup_failed"
     if not all_ok:
         # whatever is left of this leg (a communicator some rank never joined, a device-side wait nobody will
         # release) must not get a chance to block a destructor before rank 0 has printed: keep it alive and let
@@ -838,7 +846,7 @@ def main():
             del t2, gb2
         except NameError:
             pass
-        if library_exchange_leg(args, world, rank, device, out, "peer_push"):
+        if library_exchange_leg(args, world, rank, device, out, "peer_push"):  # (True, or "setup_failed": nothing half-built)
             library_exchange_leg(args, world, rank, device, out, "rccl_thread")
     if rank == 0:
         emit_line(out, json_fd)

@@ -77,6 +77,25 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
     a.close()  # idempotent
 
 
+def test_auto_falls_back_to_the_rccl_thread_when_peer_push_cannot_be_set_up(world_of_one, monkeypatch):
+    """A platform that refuses the peer mappings (injected: AGX_TEST_PUSH_SETUP_FAIL): every rank learns it before anything is
+    built (StepGather._agree), "auto" takes the RCCL worker thread instead, an explicit backend="peer_push" raises."""
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("AGX_TEST_PUSH_SETUP_FAIL", "1")
+    sg = StepGather(256, 13, dev)
+    assert sg.backend == "rccl_thread"
+    rows = torch.rand(256, 16, device=dev)
+    sg.rows[0].copy_(rows)
+    got = sg.exchange(0, overlap=False).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, rows)
+    sg.close()
+    with pytest.raises(RuntimeError, match="peer_push exchange unavailable"):
+        StepGather(256, 13, dev, backend="peer_push")
+
+
 def test_worker_thread_push_whatever_queue_its_stream_lands_on(world_of_one):
     """HIP maps streams onto a few hardware queues in creation order.  The consumer of the worker-thread push must not spin
     on this rank's own arrival flag: if its stream shares a queue with the communication stream the spinning kernel sits in
