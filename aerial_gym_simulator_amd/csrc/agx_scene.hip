@@ -190,6 +190,8 @@ AGX_DEV void bitonic_sort_lds(unsigned long long *keys, int m, int tid) {
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
 // child >= 0: internal node index, child < 0: leaf holding triangle ~child and, if second >= 0, that triangle too.
 AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
+  const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
+  ppo &= ~AGX_BVH_FULL_SORT;
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
@@ -296,7 +298,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   // keys' low word gives.)
   bool presorted = false;
 #ifndef AGX_BVH_EXPERIMENT
-  if (ppo >= 2 && K >= 2 && K * ppo == nt) {
+  if (ppo >= 2 && K >= 2 && K * ppo == nt && !force_full_sort) {
     __syncthreads();  // (the reduction's result is in registers everywhere: its scratch is reused)
     int Kpad = 1;
     while (Kpad < K) Kpad <<= 1;
@@ -604,6 +606,8 @@ extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *t
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
   AGX_REQUIRE(tri_world && nodes, "null buffer");
   AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
+  const int force_full_sort = prims_per_object & AGX_BVH_FULL_SORT;  // test hook (include/aerial_gym_hip.h)
+  prims_per_object &= ~AGX_BVH_FULL_SORT;
   AGX_REQUIRE(prims_per_object == 0 || (prims_per_object >= 9 && nt % prims_per_object == 0),
               "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;
@@ -620,7 +624,7 @@ extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *t
   AGX_REQUIRE(lds <= 160 * 1024 - 256, "LBVH build needs %zu bytes of LDS (> 160 KiB)", lds);
   if (mask) hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
   const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
-  hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object,
-                     tri_world, mask ? work : nullptr, nodes);
+  hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad,
+                     prims_per_object | force_full_sort, tri_world, mask ? work : nullptr, nodes);
   return check_launch("agx_bvh_build");
 }

@@ -489,7 +489,11 @@ int agx_assets_integrate(int num_envs, int num_assets, float *asset_state, const
  * 12); the Morton order is then taken over object centres, which keeps an object's triangles
  * together (two-level hierarchy).  0 = order by triangle centroid.
  * mask != NULL rebuilds only the flagged envs and needs `work` (int32[num_envs + 2], scratch):
- * the dirty env ids are compacted into it and a CU-sized persistent grid pulls from the list.   */
+ * the dirty env ids are compacted into it and a CU-sized persistent grid pulls from the list.
+ * With objects, the order of the keys is obtained from a sort of the OBJECTS' codes plus every triangle's rank inside its
+ * object (the full key sort runs only when two objects that are in the env share a code); AGX_BVH_FULL_SORT ORed into
+ * prims_per_object forces the full sort -- a test hook: both must give the same tree.   */
+#define AGX_BVH_FULL_SORT 0x40000000
 size_t agx_bvh_nodes_bytes(int num_envs, int num_tris);
 int agx_bvh_build(int num_envs, int num_tris, int prims_per_object, const float *tri_world,
                   const uint8_t *mask, float *nodes, int32_t *work, void *stream);

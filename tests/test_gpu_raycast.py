@@ -569,6 +569,26 @@ def test_full_size_frame_properties(orc):
     assert (seg >= 0).mean() > 0.9
 
 
+def test_bvh_object_level_order_equals_the_full_key_sort(orc):
+    """The builder orders the keys by sorting the OBJECTS and ranking each triangle inside its object; AGX_BVH_FULL_SORT takes
+    the 2048-key sort instead.  Same keys, same order, same tree -- bit for bit -- on box scenes with and without walls; and
+    with two objects at the SAME place (equal Morton codes: their triangles interleave by face class) the builder notices
+    and falls back, again the same tree."""
+    FULL = 0x40000000
+    for n, k, walls, twin in ((2, 7, False, False), (3, 100, True, False), (2, 7, False, True), (2, 40, True, True)):
+        sc = random_box_scene(n, k, seed=11, walls=walls)
+        if twin:
+            sc["asset_state"][:, 1, 0:7] = sc["asset_state"][:, 0, 0:7]  # the second box sits on the first
+        S = Scene(sc)
+        assert S.ppo == 12
+        S.build()
+        a = S.nodes.clone()
+        S.nodes.zero_()
+        S.ppo = 12 | FULL
+        S.build()
+        assert torch.equal(a.view(torch.int32), S.nodes.view(torch.int32)), (n, k, walls, twin)
+
+
 def test_bvh_structure_covers_every_triangle_once(orc):
     """Independent of any ray: the device-built tree reaches every triangle exactly once (one- and two-triangle
     leaves), every child box contains its triangles, and folded nodes are unreachable."""
