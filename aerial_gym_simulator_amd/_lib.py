@@ -152,6 +152,30 @@ class AgxTaskArgs(C.Structure):
 TASK_NONE, TASK_POSITION, TASK_NAVIGATION = 0, 1, 2
 
 
+class AgxNavRobotSideArgs(C.Structure):
+    _fields_ = [
+        ("num_sensors", C.c_int32),
+        ("randomize_mount", C.c_int32),
+        ("mount_t_min", C.c_float * 3),
+        ("mount_t_max", C.c_float * 3),
+        ("mount_r_min", C.c_float * 3),
+        ("mount_r_max", C.c_float * 3),
+        ("local_pos", C.c_void_p),
+        ("local_quat", C.c_void_p),
+        ("frame_quat", C.c_float * 4),
+        ("sensor_pos", C.c_void_p),
+        ("sensor_quat", C.c_void_p),
+        ("reset_target", C.c_int32),
+        ("num_actions", C.c_int32),
+        ("zero_prev_actions", C.c_int32),
+        ("pad_", C.c_int32),
+        ("target_ratio_min", C.c_float * 3),
+        ("target_ratio_max", C.c_float * 3),
+        ("target", C.c_void_p),
+        ("target_yaw", C.c_void_p),
+    ]
+
+
 class AgxResetArgs(C.Structure):
     _fields_ = [
         ("u_bounds_lo", C.c_void_p),
@@ -222,6 +246,8 @@ _SIGNATURES = {
     "agx_env_step_kernel": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxTaskArgs),
                                       C.c_char_p, C.c_int]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
+    "agx_nav_robot_side": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs),
+                                     C.POINTER(AgxNavRobotSideArgs), _P]),
     "agx_post_step_position": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P]),
     "agx_position_task_step": (C.c_int, [C.POINTER(AgxPositionStepPlan), _P, _P]),
     "agx_reset_assets": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P, _P, _P, C.c_int,

@@ -38,6 +38,7 @@
 #pragma clang fp contract(off)
 #endif
 #include "agx_device_math.h"
+#include "agx_nav_parts.h"
 #include "agx_quad_math.h"
 #include "agx_rng.h"
 #include "agx_step_signal.h"
@@ -1662,6 +1663,45 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
   if (WITH_OBS) step_rows_signal(B);
 }
 
+// The robot side of a navigation step in one launch (agx_nav_robot_side): the masked robot reset, the sensor mounts and the
+// target of the envs that reset, the world pose of every sensor -- four dependent launches of ~5 us each at RL batch sizes.
+// Same device functions as the stand-alone kernels, same order; what the later parts read (episode count, bounds, state) was
+// written by the SAME thread, so program order is all the ordering it takes.
+template <int M>
+__global__ void __launch_bounds__(256) k_nav_robot_side(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R, AgxNavRobotSideArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
+  const bool valid = i < n;
+  EnvState s{};
+  bool mine = false;
+  int ep = 0;
+  if (valid) {
+    s = load_state(B.state, n, i);
+    mine = B.reset_mask[i] != 0;
+    if (B.episode_count) ep = B.episode_count[i];
+  }
+  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  reset_and_observe<M, false>(P, B, n, R, i, valid, any, mine && any, ep, V3{}, nullptr, s, Derived{});
+  if (!valid) return;
+  const int ns = A.num_sensors;
+  if (any && mine) {
+    if (A.randomize_mount) {
+      Ratio3 Tr, Ro;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Tr.lo[c] = A.mount_t_min[c]; Tr.hi[c] = A.mount_t_max[c]; Ro.lo[c] = A.mount_r_min[c]; Ro.hi[c] = A.mount_r_max[c]; }
+      for (int q = 0; q < ns; ++q) sensor_mount_reset_env(B, i, q, i * ns + q, Tr, Ro, nullptr, nullptr, A.local_pos, A.local_quat);
+    }
+    if (A.reset_target) {
+      Ratio3 Rt;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { Rt.lo[c] = A.target_ratio_min[c]; Rt.hi[c] = A.target_ratio_max[c]; }
+      nav_target_reset_env(B, n, i, A.num_actions, Rt, nullptr, A.target, A.target_yaw, A.zero_prev_actions);
+    }
+  }
+  const Q4 fq = Q4{A.frame_quat[0], A.frame_quat[1], A.frame_quat[2], A.frame_quat[3]};
+  for (int q = 0; q < ns; ++q) sensor_pose_env(B, n, i, i * ns + q, A.local_pos, A.local_quat, fq, A.sensor_pos, A.sensor_quat);
+}
+
 // k_reset_masked<4, WITH_OBS> with four lanes per env (see k_env_step_quad_position): the refresh of every env's derived
 // tensors and the observation are vector work; the reset of an env itself (rare: a few of 8192 per step) stays the scalar
 // code, run by the first lane of the env's quad, which then hands the new state to the other three.
@@ -2060,6 +2100,21 @@ extern "C" int agx_reset_masked(const AgxRobotParams *P, const AgxEnvBuffers *B,
   AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, false>), dim3(blocks_for(n, block)), dim3(block), 0,
                                                    (hipStream_t)stream, *P, *B, n, *R, nullptr, nullptr));
   return check_launch("agx_reset_masked");
+}
+
+extern "C" int agx_nav_robot_side(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R,
+                                  const AgxNavRobotSideArgs *A, void *stream) {
+  if (int e = check_reset(P, B, n, R)) return e;
+  AGX_REQUIRE(A, "null AgxNavRobotSideArgs");
+  AGX_REQUIRE(R->u_state == nullptr, "agx_nav_robot_side draws with the device generator only (sync-free mode)");
+  AGX_REQUIRE(A->num_sensors >= 0 && (A->num_sensors == 0 || (A->local_pos && A->local_quat && A->sensor_pos && A->sensor_quat)),
+              "sensor buffers missing");
+  AGX_REQUIRE(!A->reset_target || (A->target && B->bounds_min && B->bounds_max), "target part needs target and the env bounds");
+  AGX_REQUIRE((!A->reset_target && !(A->num_sensors && A->randomize_mount)) || B->episode_count, "device RNG needs buf->episode_count");
+  AGX_REQUIRE(!A->zero_prev_actions || B->prev_actions, "zero_prev_actions needs buf->prev_actions");
+  AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_nav_robot_side<kM>), dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                                                   *P, *B, n, *R, *A));
+  return check_launch("agx_nav_robot_side");
 }
 
 extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const AgxResetArgs *R,

@@ -25,6 +25,7 @@
 // profiles/r01_sq_counters_navigation.json), with HBM traffic ~ scene + image bytes.
 #include "agx_common.h"
 #include "agx_device_math.h"
+#include "agx_nav_parts.h"
 
 namespace agx {
 
@@ -830,14 +831,7 @@ __global__ void __launch_bounds__(256) k_sensor_pose(AgxEnvBuffers B, int n, int
                                                       float *__restrict__ pos, float *__restrict__ quat) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * ns) return;
-  const int i = idx / ns;
-  const V3 p = V3{B.state[0 * n + i], B.state[1 * n + i], B.state[2 * n + i]};
-  const Q4 q = Q4{B.state[3 * n + i], B.state[4 * n + i], B.state[5 * n + i], B.state[6 * n + i]};
-  const float *lp = local_pos + (size_t)idx * 3, *lq = local_quat + (size_t)idx * 4;
-  V3 sp = tf_apply(q, p, V3{lp[0], lp[1], lp[2]});
-  Q4 sq = quat_mul(q, quat_mul(Q4{lq[0], lq[1], lq[2], lq[3]}, frame_quat));
-  pos[(size_t)idx * 3] = sp.x; pos[(size_t)idx * 3 + 1] = sp.y; pos[(size_t)idx * 3 + 2] = sp.z;
-  quat[(size_t)idx * 4] = sq.x; quat[(size_t)idx * 4 + 1] = sq.y; quat[(size_t)idx * 4 + 2] = sq.z; quat[(size_t)idx * 4 + 3] = sq.w;
+  sensor_pose_env(B, n, idx / ns, idx, local_pos, local_quat, frame_quat, pos, quat);
 }
 
 // WarpSensor.apply_noise / apply_range_limits / normalize_observation (warp_sensor.py:202-247)

@@ -4,13 +4,10 @@
 // at the 512-2048 envs an RL run typically uses, those launches -- not the simulation -- bound the step time.
 #include "agx_common.h"
 #include "agx_device_math.h"
+#include "agx_nav_parts.h"
 #include "agx_rng.h"
 
 namespace agx {
-
-struct Ratio3 {
-  float lo[3], hi[3];
-};
 
 // navigation_task.py:311-326 / lidar_navigation_task.py:405-418: successes = truncated & within `radius` of the
 // target & not crashed; timeouts = truncated & not success & not crashed.  counters += (successes, crashes, timeouts).
@@ -63,22 +60,7 @@ __global__ void __launch_bounds__(256) k_nav_target_reset(AgxEnvBuffers B, int n
                                                            int zero_prev_actions) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || B.reset_flag[B.flag_parity] == 0 || B.reset_mask[i] == 0) return;
-  float uu[4];
-  if (u) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) uu[c] = u[(size_t)i * 4 + c];
-  } else {
-    rng_fill<4>(B.rng_seed, B.env_index_base + i, B.episode_count ? B.episode_count[i] : 0, RNG_TARGET, uu);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float ratio = (R.hi[c] - R.lo[c]) * uu[c] + R.lo[c];
-    float lo = B.bounds_min[c * n + i], hi = B.bounds_max[c * n + i];
-    target[c * n + i] = lo + (hi - lo) * ratio;
-  }
-  if (target_yaw) target_yaw[i] = (kPi - (-kPi)) * uu[3] + (-kPi);
-  if (zero_prev_actions)
-    for (int c = 0; c < num_actions; ++c) B.prev_actions[c * n + i] = 0.0f;
+  nav_target_reset_env(B, n, i, num_actions, R, u, target, target_yaw, zero_prev_actions);
 }
 
 // WarpSensor.reset_idx (warp_sensor.py:153-172) for the envs of reset_mask
@@ -89,22 +71,7 @@ __global__ void __launch_bounds__(256) k_sensor_mount_reset(AgxEnvBuffers B, int
   if (idx >= n * ns) return;
   const int i = idx / ns, s = idx % ns;
   if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[i] == 0) return;
-  float uu[6];
-  if (u_pos) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { uu[c] = u_pos[(size_t)idx * 3 + c]; uu[3 + c] = u_rot[(size_t)idx * 3 + c]; }
-  } else {
-    rng_fill<6>(B.rng_seed, B.env_index_base + i, B.episode_count ? B.episode_count[i] : 0, RNG_SENSOR_MOUNT + s, uu);
-  }
-  float e[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    local_pos[(size_t)idx * 3 + c] = (Tr.hi[c] - Tr.lo[c]) * uu[c] + Tr.lo[c];
-    e[c] = (Ro.hi[c] - Ro.lo[c]) * uu[3 + c] + Ro.lo[c];
-  }
-  Q4 q = quat_from_euler(e[0], e[1], e[2]);
-  float *o = local_quat + (size_t)idx * 4;
-  o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+  sensor_mount_reset_env(B, i, s, idx, Tr, Ro, u_pos, u_rot, local_pos, local_quat);
 }
 
 }  // namespace agx

@@ -399,10 +399,26 @@ class EnvManager(BaseManager):
             rs.rand_into(u["kT"], tag="kT")
         self.robot_manager.draw_sensor_reset_randoms(env_ids)
 
-    def _launch_reset(self, with_obs=False):
+    # A navigation task may hand over what follows the robot reset on the robot side of its step -- sensor mounts and target of
+    # the envs that reset, the world pose of every sensor -- to run in the SAME launch (agx_nav_robot_side: one launch instead
+    # of four dependent ones).  Only the per-step reset of task.step() takes it; an explicit reset_idx() stays as it was.
+    _nav_side = None
+    _sensor_pose_fresh = False    # the fused launch computed this step's sensor poses: HipSensor.compose_pose skips once
+    _targets_reset_fused = False  # ... and resampled the targets of the reset envs: the task's _reset_targets skips once
+
+    def enable_fused_robot_side(self, nav_args):
+        self._nav_side = nav_args
+
+    def _launch_reset(self, with_obs=False, per_step=False):
         """Device side of EnvManager.reset_idx for the envs flagged in reset_mask (all kernels
         return immediately when reset_flag[parity] is 0)."""
         self.asset_manager.reset_masked(self)  # obstacle poses, scene triangles, BVH, boxes
+        if per_step and self._nav_side is not None and self.post_obs is None and not self.strict_rng:
+            _lib.check(self._lib.agx_nav_robot_side(self._params, self._buffers, self.num_envs, self._reset_args,
+                                                    _lib.C.byref(self._nav_side), self._stream()), "agx_nav_robot_side")
+            self._sensor_pose_fresh = self._nav_side.num_sensors > 0
+            self._targets_reset_fused = bool(self._nav_side.reset_target)
+            return
         if with_obs and self.post_obs is not None:
             _lib.check(self._lib.agx_post_step_position(self._params, self._buffers, self.num_envs, self._reset_args,
                                                         self.post_obs[0], self.post_obs[1], self._stream()),
@@ -450,7 +466,7 @@ class EnvManager(BaseManager):
         if self.strict_rng and int(g["reset_flag"][self._parity].item()) != 0:  # host sync, like the reference's nonzero()/len()
             env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1)
             self._draw_reset_randoms(env_ids)
-        self._launch_reset(with_obs=True)
+        self._launch_reset(with_obs=True, per_step=True)
         return ResetSet(g["reset_mask"])
 
     # ------------------------------------------------------------------ stepping

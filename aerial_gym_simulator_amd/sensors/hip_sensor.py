@@ -145,6 +145,9 @@ class HipSensor:
 
     def compose_pose(self):
         env = self.g["env_manager"]
+        if env._sensor_pose_fresh:  # this step's poses were written by the fused robot-side launch (agx_nav_robot_side)
+            env._sensor_pose_fresh = False
+            return
         p = _lib.dptr
         _lib.check(
             env._lib.agx_sensor_pose(env._buffers, self.num_envs, self.num_sensors, p(self.sensor_local_position),

@@ -7,6 +7,7 @@ The reference encodes the depth image with a pre-trained VAE (dense conv net, ou
 simulation hot path); with `vae_config.use_vae = False` (default here) the 64
 latent slots carry an 8 x 8 min-pooled depth grid instead."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -210,12 +211,49 @@ class NavigationTask(BaseTask):
             if len(reset_envs) > 0:
                 self.reset_idx(reset_envs.indices)
             return
+        if env._targets_reset_fused:  # done by the launch that reset the robots (agx_nav_robot_side)
+            env._targets_reset_fused = False
+            self.infos = {}
+            return
         _lib.check(env._lib.agx_nav_target_reset(env._buffers, env.num_envs, env.num_robot_actions, self._min_ratio, self._max_ratio, None,
                                                  _lib.dptr(self.target_soa), self._target_yaw_ptr(), int(self._zero_prev_actions_on_reset),
                                                  env._stream()), "agx_nav_target_reset")
         self.infos = {}
 
     _zero_prev_actions_on_reset = False
+    _fused_side = None  # False: not applicable; else the AgxNavRobotSideArgs handed to the EnvManager
+
+    def _setup_fused_robot_side(self):
+        """Sync-free mode: the robot reset, the sensor mounts and the target of the envs that reset and the pose of every sensor
+        as ONE launch per step (agx_nav_robot_side) instead of four.  The stand-alone entry points stay
+        what explicit reset_idx() / render() calls use; both run the same device functions."""
+        env = self.sim_env
+        rm = env.robot_manager
+        wanted = os.environ.get("AGX_FUSED_ROBOT_SIDE", "1") != "0"
+        if not wanted or env.strict_rng or env._buffers is None or rm.imu_sensor is not None or env.post_obs is not None:
+            self._fused_side = False
+            return
+        A = _lib.AgxNavRobotSideArgs()
+        sensor = rm.warp_sensor
+        if sensor is not None:
+            A.num_sensors = int(sensor.num_sensors)
+            A.randomize_mount = int(bool(sensor.cfg.randomize_placement))
+            for c in range(3):
+                A.mount_t_min[c], A.mount_t_max[c] = sensor._min_t[c], sensor._max_t[c]
+                A.mount_r_min[c], A.mount_r_max[c] = sensor._min_r[c], sensor._max_r[c]
+            for c in range(4):
+                A.frame_quat[c] = sensor.frame_quat[c]
+            A.local_pos, A.local_quat = _lib.dptr(sensor.sensor_local_position), _lib.dptr(sensor.sensor_local_orientation)
+            A.sensor_pos, A.sensor_quat = _lib.dptr(sensor.sensor_position), _lib.dptr(sensor.sensor_orientation)
+        A.reset_target = 1
+        A.num_actions = int(env.num_robot_actions)
+        A.zero_prev_actions = int(self._zero_prev_actions_on_reset)
+        for c in range(3):
+            A.target_ratio_min[c], A.target_ratio_max[c] = self._min_ratio[c], self._max_ratio[c]
+        A.target = _lib.dptr(self.target_soa)
+        A.target_yaw = self._target_yaw_ptr()
+        self._fused_side = A
+        env.enable_fused_robot_side(A)
 
     def _target_yaw_ptr(self):
         return None
@@ -261,6 +299,8 @@ class NavigationTask(BaseTask):
             return_tuple = self.get_return_tuple()
         self._bookkeeping_device()
         self._bookkeeping_host(in_step=True)
+        if self._fused_side is None:
+            self._setup_fused_robot_side()
         reset_envs = env.post_reward_calculation_step()
         self._reset_targets(reset_envs)
         self.process_image_observation()

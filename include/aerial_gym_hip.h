@@ -422,6 +422,25 @@ typedef struct AgxResetArgs {
 int agx_reset_masked(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                      const AgxResetArgs *args, void *stream);
 
+/* The robot side of a navigation task's step as ONE launch (sync-free mode: device generator only): agx_reset_masked, then for
+ * the envs that reset agx_sensor_mount_reset and agx_nav_target_reset, then agx_sensor_pose for every env -- the same device
+ * functions as those four entry points, in that order (the mount and the target draws are keyed by the episode count the robot
+ * reset has just advanced).  Replaces four dependent 5-us launches at the 256 .. 1024 envs an RL run uses.
+ * num_sensors = 0: no sensor part; randomize_mount = 0: the mount is left alone; reset_target = 0: no target part.   */
+typedef struct AgxNavRobotSideArgs {
+  int32_t num_sensors, randomize_mount;
+  float mount_t_min[3], mount_t_max[3], mount_r_min[3], mount_r_max[3];
+  float *local_pos, *local_quat;   /* [N][S][3], [N][S][4]: the mount in the robot frame */
+  float frame_quat[4];
+  float *sensor_pos, *sensor_quat; /* out [N][S][3], [N][S][4]: world pose of every sensor */
+  int32_t reset_target, num_actions, zero_prev_actions, pad_;
+  float target_ratio_min[3], target_ratio_max[3];
+  float *target;      /* [3][N] */
+  float *target_yaw;  /* [N] or NULL */
+} AgxNavRobotSideArgs;
+int agx_nav_robot_side(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, const AgxResetArgs *args,
+                       const AgxNavRobotSideArgs *nav, void *stream);
+
 /* agx_reset_masked + agx_obs_position in one launch (the position task has no sensor to
  * render between reset and observation).                                                  */
 int agx_post_step_position(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,

@@ -366,6 +366,53 @@ def test_replayed_step_graph_equals_eager_stepping(task_name, cfg_name):
         cfg.episode_len_steps, cfg.args, cfg.device = old
 
 
+@pytest.mark.parametrize("task_name,cfg_name", [("navigation_task", "navigation_task_config"),
+                                                ("lidar_navigation_task", "lidar_navigation_task_config")])
+def test_fused_robot_side_launch_equals_the_four_separate_launches(task_name, cfg_name, monkeypatch):
+    """agx_nav_robot_side (robot reset + sensor mounts + target of the envs that reset + every sensor's pose, one launch) against
+    agx_reset_masked / agx_sensor_mount_reset / agx_nav_target_reset / agx_sensor_pose (AGX_FUSED_ROBOT_SIDE=0): same seed, same
+    actions -> bit-identical observations, rewards, flags, states, targets, mounts, sensor poses and images over 60 steps with
+    episodes of 7 steps (resets on most steps)."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import task_config as tc
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg = getattr(tc, cfg_name)
+    old = (cfg.episode_len_steps, cfg.args, cfg.device)
+    n = 40
+    tasks = []
+    try:
+        for fused in ("0", "1"):
+            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", fused)
+            cfg.device, cfg.episode_len_steps = DEV, 7
+            cfg.args = {"rng_seed": 99}
+            t = task_registry.make_task(task_name, seed=3, num_envs=n, headless=True)
+            t.reset()
+            tasks.append(t)
+        separate, fused = tasks
+        g = torch.Generator(device=DEV).manual_seed(2)
+        for step in range(60):
+            a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
+            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", "0")
+            out0 = separate.step(a)
+            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", "1")
+            out1 = fused.step(a)
+            torch.cuda.synchronize()
+            (o0, r0, te0, tr0, _), (o1, r1, te1, tr1, _) = out0, out1
+            assert torch.equal(o0["observations"], o1["observations"]), step
+            assert torch.equal(r0, r1) and torch.equal(te0, te1) and torch.equal(tr0, tr1), step
+            for key in ("robot_state_tensor", "depth_range_pixels"):
+                assert torch.equal(separate.obs_dict[key], fused.obs_dict[key]), (step, key)
+            assert torch.equal(separate.target_soa, fused.target_soa), step
+            s0, s1 = separate.sim_env.robot_manager.warp_sensor, fused.sim_env.robot_manager.warp_sensor
+            for name in ("sensor_local_position", "sensor_local_orientation", "sensor_position", "sensor_orientation"):
+                assert torch.equal(getattr(s0, name), getattr(s1, name)), (step, name)
+        assert separate._fused_side is False and fused._fused_side not in (None, False)
+        assert int(fused.sim_env.global_tensor_dict["episode_count"].sum()) >= 6 * n
+    finally:
+        cfg.episode_len_steps, cfg.args, cfg.device = old
+
+
 def test_builtin_action_transformations_as_one_launch():
     """agx_action_transform (what the tasks use when the config carries the built-in function) against the torch functions of
     config/task_config.py evaluated in float64-backed numpy: the linear columns bit for bit, sine / cosine correctly rounded
