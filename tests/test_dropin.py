@@ -391,3 +391,21 @@ def test_user_registered_torch_controller_runs_and_matches_the_builtin_law(env_n
         assert torch.equal(envs[0].sim_steps, envs[1].sim_steps)
     assert worst < (5e-2 if substeps > 1 else 4e-4), worst  # 12 free-running env steps under white-noise set-points
     assert int(envs[1].sim_steps[0]) == 12
+
+
+def test_reference_benchmark_script_api_surface():
+    """aerial_gym/examples/benchmark.py:30-100 (the reference's only benchmark recipe) touches, besides build_env / reset / step:
+    env_manager.num_envs, env_manager.sim_config.sim.dt (real-time factor), robot.cfg.sensor_config.enable_camera (its sanity
+    check of the two modes) and render(render_components="sensor").  All present on envs built through the alias package with the
+    recipe's own arguments (CPU construction: stepping needs the GPU; examples/benchmark.py is the runnable counterpart)."""
+    from aerial_gym.sim.sim_builder import SimBuilder
+
+    physics = SimBuilder().build_env(sim_name="base_sim", env_name="empty_env", robot_name="base_quadrotor", controller_name="no_control",
+                                     args=None, device="cpu", num_envs=4, headless=True, use_warp=True)
+    assert physics.num_envs == 4 and float(physics.sim_config.sim.dt) == 0.01
+    assert physics.robot_manager.robot.cfg.sensor_config.enable_camera is False
+    physics.render(render_components="sensor")  # (the reference's spelling: not "sensors", so nothing is rendered there either)
+    rendering = SimBuilder().build_env(sim_name="base_sim", env_name="env_with_obstacles", robot_name="base_quadrotor_with_camera",
+                                       controller_name="lee_velocity_control", args=None, device="cpu", num_envs=2, headless=True,
+                                       use_warp=True)
+    assert rendering.robot_manager.robot.cfg.sensor_config.enable_camera is True
