@@ -498,7 +498,7 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
 
     n_gpus = max(world, 1)
     report = out.setdefault("exchange", {})
-    report.setdefault("process_group", {"value": out["value"], "ms_per_step": out["ms_per_step"],
+    report.setdefault("process_group", {"value": out["value"], "ms_per_step": out["ms_per_step"], "ranks_seen": report.get("ranks_seen"),
                                         "plus_depth_value": out.get("plus_depth", {}).get("value"),
                                         "plus_depth_ms_per_step": out.get("plus_depth", {}).get("ms_per_step")})
 
@@ -530,6 +530,11 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
             res["flags_in_uncached_memory"] = gb.push_flags_uncached
             res["connection_selftest"] = gb.push_selftest  # a word + a flag stored through every mapping and checked on arrival
         res["communicator"] = dict(zip(("rank", "ranks"), gb.comm_info()))  # ncclCommUserRank / ncclCommCount, or the ranks whose buffers were mapped
+        res["ranks_seen"] = res["communicator"]["ranks"]
+        print(f"[bench rank {rank}/{world}] exchange leg {backend}: set up as {gb.backend}, communicator reports rank "
+              f"{res['communicator']['rank']} of {res['ranks_seen']}"
+              + (f", peer-mapping self-test {gb.push_selftest}, kernel push {gb._kernel_push}" if backend == "peer_push" else ""),
+              file=sys.stderr, flush=True)
         if res["communicator"]["ranks"] != max(world, 1):
             raise RuntimeError(f"the exchange communicator spans {res['communicator']['ranks']} ranks, the job has {world}")
         if os.environ.get("AGX_BENCH_INJECT_EXCHANGE_FAILURE") == str(rank):  # exercises the abandon path below
@@ -668,14 +673,73 @@ def cpu_baseline_raycast(task, budget_s=8.0, sample_envs=512):
                                       "included in every frame (OpenMP over envs), scenes and poses of the GPU run"}
 
 
+def ensure_ranks(args):
+    """`--gpus N` is a request for N ranks, one per GPU, and it is honoured or refused -- never silently reduced:
+
+    * WORLD_SIZE set (the process was started by torch.distributed.run / torchrun): it must equal N;
+    * WORLD_SIZE unset and N > 1: this process becomes the launcher -- it re-runs itself under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`
+      with the same arguments and returns the children's exit code (rank 0 prints the ONE JSON line on the inherited stdout);
+    * fewer than N HIP devices visible: exit non-zero naming both numbers, before anything is launched.
+    AGX_BENCH_SPAWN=1 sends N = 1 through the same launcher (tests)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}: start {args.gpus} ranks "
+                             f"(--nproc-per-node {args.gpus}) or pass --gpus {env_world}")
+    if visible < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} requested but {visible} HIP device(s) visible "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}, "
+                         f"ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES', '<unset>')}); there is no CPU fallback and no "
+                         "smaller job is run in its place")
+    if env_world is not None:
+        return
+    if args.gpus == 1 and os.environ.get("AGX_BENCH_SPAWN") != "1":
+        return
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} rank(s): {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL and the peer-push mappings need it on this driver)
+    env.pop("AGX_BENCH_SPAWN", None)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def rank_diagnostics(rank, world, local_rank):
+    """What this rank sees before anything is timed, on stderr: the first contact with an N-GPU node explains itself."""
+    n = torch.cuda.device_count()
+    row = []
+    for j in range(n):
+        try:
+            row.append(1 if j == local_rank else int(torch.cuda.can_device_access_peer(local_rank, j)))  # hipDeviceCanAccessPeer
+        except Exception:  # noqa: BLE001
+            row.append(-1)
+    info = {"rank": rank, "world": world, "local_rank": local_rank, "devices_visible": n, "device": torch.cuda.get_device_name(local_rank),
+            "can_access_peer": row, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES")}
+    print("[bench rank %d/%d] %s" % (rank, world, json.dumps(info)), file=sys.stderr, flush=True)
+    return info
+
+
 def main():
     args = parse()
+    ensure_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP GPU (no CPU fallback); use gpurun")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible")
     torch.cuda.set_device(local_rank)
+    diag = rank_diagnostics(rank, world, local_rank)
     device = f"cuda:{local_rank}"
     use_dist = world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1"
     json_fd = None
@@ -708,6 +772,8 @@ def main():
                                 backend=primary_backend)
     if gather_buf is not None:
         comm_rank, comm_ranks = gather_buf.comm_info()
+        print(f"[bench rank {rank}/{world}] first leg: exchange backend {gather_buf.backend}, communicator reports rank {comm_rank} of {comm_ranks}",
+              file=sys.stderr, flush=True)
         if comm_ranks != max(world, 1) or comm_rank != rank:
             raise SystemExit(f"the step exchange's communicator reports rank {comm_rank} of {comm_ranks}; the job is rank {rank} of {world}")
     dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf, overlap=not args.sync_gather)
@@ -750,7 +816,9 @@ def main():
                  "launch is latency bound (one wave's instruction stream + two memory round trips); roofline_at_scale prices the "
                  "one-lane-per-env kernel at 2^21 envs")
     if exchange is not None:
-        exchange["communicator_ranks"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
+        exchange["communicator_ranks"] = exchange["ranks_seen"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
+        exchange["backend_of_first_leg"] = gather_buf.backend
+        exchange["rank0_devices"] = diag
         out["exchange"] = exchange
     if rank == 0 and args.workload != "dynamics":
         kt = kernel_time_raycast(task)

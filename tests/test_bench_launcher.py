@@ -1,0 +1,71 @@
+"""bench.py --gpus N is honoured or refused, never silently reduced (BASELINE configs[4]).
+
+The reference has replicas only (rl_training/rl_games/runner.py:260-265): the sharded job is this build's own entry point,
+so its launcher is tested here -- the refusals on CPU, the self-spawn path on a GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(argv, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def json_lines(stdout):
+    out = []
+    for line in stdout.splitlines():
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
+
+
+def test_more_gpus_than_devices_is_refused_loudly():
+    """no device (this container) or one device (the GPU box): --gpus 2 exits non-zero naming both numbers, no JSON line"""
+    import torch
+
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    want = visible + 1 if visible else 2
+    r = run_bench(["--gpus", str(want), "--steps", "5", "--warmup", "1"], timeout=300)
+    assert r.returncode != 0
+    assert f"--gpus {want}" in r.stderr and f"{visible} HIP device(s) visible" in r.stderr, r.stderr[-2000:]
+    assert json_lines(r.stdout) == []
+
+
+def test_world_size_mismatch_is_refused_loudly():
+    r = run_bench(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "WORLD_SIZE=4" in r.stderr
+    assert json_lines(r.stdout) == []
+    r = run_bench(["--gpus", "8"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and json_lines(r.stdout) == []
+
+
+@pytest.mark.gpu
+def test_self_spawn_path_prints_the_same_line():
+    """AGX_BENCH_SPAWN=1 sends --gpus 1 through the launcher (torch.distributed.run, one rank): ONE JSON line on stdout with the
+    keys of the direct run, n_gpus 1, and the rank's device diagnostics on stderr"""
+    argv = ["--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-depth"]
+    direct = run_bench(argv)
+    assert direct.returncode == 0, direct.stderr[-3000:]
+    spawned = run_bench(argv, {"AGX_BENCH_SPAWN": "1"})
+    assert spawned.returncode == 0, spawned.stderr[-3000:]
+    a, b = json_lines(direct.stdout), json_lines(spawned.stdout)
+    assert len(a) == 1 and len(b) == 1
+    a, b = a[0], b[0]
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"] and a["config"] == b["config"]
+    assert set(a) == set(b)
+    assert "torch.distributed.run" in spawned.stderr and "[bench rank 0/1]" in spawned.stderr and '"can_access_peer"' in spawned.stderr
+    assert 0.2 < b["value"] / a["value"] < 5.0
