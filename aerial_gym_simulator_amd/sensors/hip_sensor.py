@@ -14,6 +14,30 @@ RAY_MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "nor
 SENSOR_TYPES = ("camera", "stereo_camera", "lidar", "normal_faceID_camera", "normal_faceID_lidar")  # warp_sensor.py:36-81
 
 
+def pinhole_kinv(width, height, horizontal_fov_deg):
+    """((K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]), c_x, c_y) of warp_cam.py:31-64 -- the four entries of K_inv that
+    wp.transform_vector(K_inv, (x, y, 1)) touches, with the arithmetic the reference gets them by: `wp.mat44(...)` rounds
+    alpha_u, alpha_v, u_0, v_0 to float32, and `wp.inverse` (warp/native/mat.h, adapted from USD's GfMatrix4f::Inverse) inverts
+    THAT matrix by cofactors: for K = [[a, 0, u, 0], [0, b, v, 0], [0, 0, 1, 0], [0, 0, 0, 1]] the determinant is the float32
+    product a b, its reciprocal is taken in double, and the cofactors b, -b u, a, -a v (float32 roundings of double products)
+    are multiplied by it in double and rounded once.  1 / alpha_u evaluated in double from the unrounded alpha_u (rounds 1-2)
+    differs from this in the last bit for most resolutions (tests/golden/warp_kernels_camera.npz holds the reference's values)."""
+    import numpy as np
+
+    W, H = width, height
+    u0, v0 = W / 2, H / 2
+    hfov = math.radians(horizontal_fov_deg)
+    f = W / 2 * 1 / math.tan(hfov / 2)
+    vfov = 2 * math.atan(H / (2 * f))
+    alpha_u, alpha_v = u0 / math.tan(hfov / 2), v0 / math.tan(vfov / 2)
+    f32, f64 = np.float32, np.float64
+    a, b, u, v = f32(alpha_u), f32(alpha_v), f32(u0), f32(v0)
+    rcp = f64(1.0) / f64(a * b)  # a * b: one float32 product
+    entry = lambda cof: float(f32(f64(f32(cof)) * rcp))  # noqa: E731
+    k = (entry(f64(b)), entry(-(f64(b) * f64(u))), entry(f64(a)), entry(-(f64(a) * f64(v))))
+    return k, int(u0), int(v0)
+
+
 class HipSensor:
     def __init__(self, sensor_config, num_envs, scene, device):
         self.cfg, self.num_envs, self.scene, self.device = sensor_config, num_envs, scene, device
@@ -42,15 +66,8 @@ class HipSensor:
 
     # warp_cam.py:31-64
     def _init_intrinsics(self):
-        W, H = self.cfg.width, self.cfg.height
-        u0, v0 = W / 2, H / 2
-        hfov = math.radians(self.cfg.horizontal_fov_deg)
-        f = W / 2 * 1 / math.tan(hfov / 2)
-        vfov = 2 * math.atan(H / (2 * f))
-        alpha_u, alpha_v = u0 / math.tan(hfov / 2), v0 / math.tan(vfov / 2)
-        # the four entries of K_inv that wp.transform_vector(K_inv, (x, y, 1)) touches
-        self.kinv = (C.c_float * 4)(1.0 / alpha_u, -u0 / alpha_u, 1.0 / alpha_v, -v0 / alpha_v)
-        self.c_x, self.c_y = int(u0), int(v0)
+        k, self.c_x, self.c_y = pinhole_kinv(self.cfg.width, self.cfg.height, self.cfg.horizontal_fov_deg)
+        self.kinv = (C.c_float * 4)(*k)
 
     # warp_lidar.py:40-64
     def _init_ray_table(self):

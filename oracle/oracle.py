@@ -286,8 +286,20 @@ def sensor_pose(state, local_pos, local_quat, frame_quat):
     return pos, quat
 
 
+def mesh_query_ray(o, d, max_t, tris):
+    """(hit, t, face) of ONE ray against [T, 9] float32 triangles: brute-force closest hit (oracle_raycast.c closest_hit)"""
+    t, f = C.c_float(0.0), C.c_int(-1)
+    o3, d3 = (C.c_float * 3)(*[float(x) for x in o]), (C.c_float * 3)(*[float(x) for x in d])
+    fn = lib().orc_mesh_query_ray
+    fn.restype = C.c_int
+    hit = fn(o3, d3, C.c_float(float(max_t)), _p(tris), int(tris.shape[0]), C.byref(t), C.byref(f))
+    return bool(hit), np.float32(t.value), int(f.value)
+
+
 def camera_kinv(width, height, hfov_deg):
-    """{K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]} of warp_cam.py:31-64 (float32)."""
+    """{K_inv[0][0], K_inv[0][2], K_inv[1][1], K_inv[1][2]} of warp_cam.py:31-64: K is a float32 matrix (wp.mat44) and
+    wp.inverse inverts it by cofactors with the determinant's reciprocal in double (warp mat.h / USD GfMatrix4f::Inverse);
+    pinned by tests/golden/warp_kernels_camera.npz (the reference's WarpCam under oracle/wp_emul.py)."""
     import math
 
     W, H = width, height
@@ -295,9 +307,12 @@ def camera_kinv(width, height, hfov_deg):
     hfov = math.radians(hfov_deg)
     f = W / 2 * 1 / math.tan(hfov / 2)
     vfov = 2 * math.atan(H / (2 * f))
-    au = u0 / math.tan(hfov / 2)
-    av = v0 / math.tan(vfov / 2)
-    return np.array([1.0 / au, -u0 / au, 1.0 / av, -v0 / av], dtype=np.float32), int(u0), int(v0)
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[0, 2], K[1, 1], K[1, 2] = u0 / math.tan(hfov / 2), u0, v0 / math.tan(vfov / 2), v0
+    det = np.float64(K[0, 0] * K[1, 1])  # float32 product: the only non-zero term of the cofactor expansion
+    adj = np.array([np.float32(np.float64(K[1, 1])), np.float32(-(np.float64(K[1, 1]) * np.float64(K[0, 2]))),
+                    np.float32(np.float64(K[0, 0])), np.float32(-(np.float64(K[0, 0]) * np.float64(K[1, 2])))], np.float64)
+    return (adj * (np.float64(1.0) / det)).astype(np.float32), int(u0), int(v0)
 
 
 MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "normal": 4, "normal_world": 5}

@@ -261,6 +261,13 @@ static int closest_hit(v3 o, v3 d, float max_t, const float *tris, int nt, const
   return 1;
 }
 
+/* wp.mesh_query_ray as one call (the closest-hit rule of the header comment, brute force over the nt triangles):
+ * used by oracle/wp_emul.py to answer the query inside the reference's OWN kernel bodies. */
+int orc_mesh_query_ray(const float *o, const float *d, float max_t, const float *tris, int nt, float *t_hit, int *f_hit) {
+  v3 ro = {o[0], o[1], o[2]}, rd = {d[0], d[1], d[2]};
+  return closest_hit(ro, rd, max_t, tris, nt, NULL, t_hit, f_hit);
+}
+
 /* ------------------------------------------------------------------ */
 /* a21: WarpEnv.reset_idx vertex transform, warp_env_manager.py:40-54  */
 /*  v_world = tf_apply(q_asset, p_asset, v_local) for the triangle soup */

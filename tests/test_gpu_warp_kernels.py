@@ -1,0 +1,108 @@
+"""The HIP ray-cast kernels through the C ABI vs frames produced by EXECUTING the reference's own kernel source and sensor
+classes under oracle/wp_emul.py (tests/golden/warp_kernels_*.npz; generator oracle/gen_golden_warp_kernels.py; what is
+emulated: that module's header).  No CPU oracle is involved here: GPU output vs the reference's recorded output, bit for bit
+-- raw distances / point clouds / normals, segmentation and face ids, and the frame after WarpSensor's range limits and
+normalisation (both as the separate post-processing launch and fused into the ray-cast's store epilogue).
+Rows a23, a24, a25, f1 of SURVEY section 8."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+from warp_golden_util import bits, cases, cfg_of, limits_of, load, mode_of, seg_mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "normal": 4, "normal_world": 5}
+
+
+def _scene(g):
+    """the fixture's world-frame triangles as the scene (identity asset pose), BVH built by the library"""
+    from test_gpu_raycast import Scene
+
+    tw = g["tri_world"]
+    n, nt = tw.shape[0], tw.shape[1]
+    ident = np.zeros((n, 1, 13), np.float32)
+    ident[:, :, 6] = 1.0
+    sc = dict(tri_local=tw, tri_asset=np.zeros(nt, np.int32), asset_state=ident, tri_seg=g["tri_seg"], half=np.ones((n, 1, 3), np.float32))
+    S = Scene(sc)
+    S.build()
+    S.tri_world.copy_(torch.from_numpy(tw).to(DEV))  # exactly the fixture's bits (the identity transform may flip a -0)
+    S.L.check(S.lib.agx_bvh_build(S.n, S.nt, S.ppo, S.L.dptr(S.tri_world), None, S.L.dptr(S.nodes), S.L.dptr(S.work), S.stream))
+    torch.cuda.synchronize()
+    return S
+
+
+def _post(S, g, tag, raw):
+    lim = limits_of(g, tag)
+    if lim is None:
+        return raw
+    c = cfg_of(g, tag)
+    px = torch.from_numpy(raw.copy()).to(DEV)
+    p = S.L.dptr
+    if c["return_pointcloud"]:
+        S.L.check(S.lib.agx_sensor_postprocess_points(px.numel() // 3, p(px), None, None, 0.0, 0.0, 0.0, 0.0, 0.0, lim[0], lim[1], lim[2], lim[3],
+                                                      int(not c["world_frame"]), int(lim[4]), S.stream))
+    else:
+        S.L.check(S.lib.agx_sensor_postprocess(px.numel(), p(px), None, None, 0.0, 0.0, 0.0, 0.0, 0.0, lim[0], lim[1], lim[2], lim[3], int(lim[4]), S.stream))
+    torch.cuda.synchronize()
+    return px.cpu().numpy()
+
+
+def _check(S, g, tag, px, seg, fused=None):
+    raw = g[tag + "_raw"]
+    assert px.shape == raw.shape
+    assert np.array_equal(bits(px), bits(raw)), (tag, int((bits(px) != bits(raw)).sum()), float(np.abs(px - raw).max()))
+    if tag + "_seg" in g.files:
+        m, ref = seg_mask(g, tag), g[tag + "_seg"]
+        assert np.array_equal(seg[m], ref[m]) if m is not None else np.array_equal(seg, ref), tag
+    assert np.array_equal(bits(_post(S, g, tag, px)), bits(g[tag + "_final"])), tag
+    if fused is not None:  # limits + normalisation in the ray-cast's own epilogue (scalar images)
+        assert np.array_equal(bits(fused), bits(g[tag + "_final"])), tag
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    return {}
+
+
+def _get(scenes, kind):
+    if kind not in scenes:
+        g = load(kind)
+        scenes[kind] = (g, _scene(g))
+    return scenes[kind]
+
+
+@pytest.mark.parametrize("tag", cases("camera"))
+def test_camera_kernels_vs_reference_source(scenes, tag):
+    g, S = _get(scenes, "camera")
+    c = cfg_of(g, tag)
+    mode = MODE[mode_of(g, tag, "camera")]
+    args = (int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], int(g[tag + "_cxy"][0]), int(g[tag + "_cxy"][1]), mode,
+            g[tag + "_sensor_position"], g[tag + "_sensor_orientation"])
+    px, seg = S.camera(*args)
+    fused = S.camera(*args, limits=limits_of(g, tag))[0] if mode <= 1 else None
+    _check(S, g, tag, px, seg, fused)
+
+
+@pytest.mark.parametrize("tag", cases("lidar"))
+def test_lidar_kernels_vs_reference_source(scenes, tag):
+    g, S = _get(scenes, "lidar")
+    c = cfg_of(g, tag)
+    mode = MODE[mode_of(g, tag, "lidar")]
+    args = (g[tag + "_ray_vectors"], c["max_range"], mode, g[tag + "_sensor_position"], g[tag + "_sensor_orientation"])
+    px, seg = S.lidar(*args)
+    fused = S.lidar(*args, limits=limits_of(g, tag))[0] if mode == 0 else None
+    _check(S, g, tag, px, seg, fused)
+
+
+@pytest.mark.parametrize("tag", cases("stereo"))
+def test_stereo_kernels_vs_reference_source(scenes, tag):
+    g, S = _get(scenes, "stereo")
+    c = cfg_of(g, tag)
+    mode = MODE[mode_of(g, tag, "stereo")]
+    args = (int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], c["baseline"], int(g[tag + "_cxy"][0]), int(g[tag + "_cxy"][1]), mode,
+            g[tag + "_sensor_position"], g[tag + "_sensor_orientation"])
+    px, seg = S.stereo(*args)
+    fused = S.stereo(*args, limits=limits_of(g, tag))[0] if mode <= 1 else None
+    _check(S, g, tag, px, seg, fused)
