@@ -61,17 +61,28 @@ NAV_CASES = {
 
 @pytest.mark.parametrize("case", list(NAV_CASES))
 def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
+    task_name, cfg_name, n, T = NAV_CASES[case]
+    run_nav_case(orc, parity, case, task_name, cfg_name, n, T)
+
+
+def run_nav_case(orc, parity, case, task_name, cfg_name, n, T, episode_len=12, all_obstacles=False, use_bvh=False, min_resets=None):
+    """`use_bvh`: the oracle's ray-cast goes through its own median-split BVH (bit-identical to its brute force,
+    tests/test_oracle_raycast.py) -- what makes the full-size cases of tests/test_gpu_full_size_parity.py affordable.
+    `all_obstacles`: every obstacle of the scene is in the env (BASELINE configs 2/3: 100 boxes + 6 walls; bench.py's setting)
+    instead of the task's curriculum start."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config import task_config as tc
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
 
-    task_name, cfg_name, n, T = NAV_CASES[case]
     cfg = getattr(tc, cfg_name)
     seed = 0xC0FFEE1234
     rs = RecordingSource(DEV, 77)
     old_cfg = (cfg.episode_len_steps, cfg.args, cfg.device)
-    cfg.device, cfg.episode_len_steps = DEV, 12
-    if case == "config3_camera":
+    old_cur = (cfg.curriculum.min_level, cfg.curriculum.max_level)
+    if all_obstacles:
+        cfg.curriculum.min_level, cfg.curriculum.max_level = 106, 107
+    cfg.device, cfg.episode_len_steps = DEV, episode_len
+    if case.startswith("config3_camera"):
         cfg.robot_name, cfg.controller_name = "base_quadrotor_with_camera_64x48", "lee_velocity_control"
     cfg.args = {"strict_rng": False, "random_source": rs, "rng_seed": seed}
     try:
@@ -207,10 +218,10 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             spos, squat = orc.sensor_pose(post["state"], lpos, lquat, frame)
             assert np.array_equal(npy(sensor.sensor_position), spos) and np.array_equal(npy(sensor.sensor_orientation), squat), t
             if sensor.is_lidar:
-                px_ref, seg_ref = orc.raycast_lidar(rays, float(scfg.max_range), "range", spos, squat, tris_ref, tri_seg)
+                px_ref, seg_ref = orc.raycast_lidar(rays, float(scfg.max_range), "range", spos, squat, tris_ref, tri_seg, use_bvh=use_bvh)
             else:
                 px_ref, seg_ref = orc.raycast_camera(scfg.width, scfg.height, kinv, float(scfg.max_range), cx, cy, "depth", spos, squat,
-                                                     tris_ref, tri_seg)
+                                                     tris_ref, tri_seg, use_bvh=use_bvh)
             px_ref = orc.sensor_postprocess(px_ref, float(scfg.min_range), float(scfg.max_range), float(scfg.far_out_of_range_value),
                                             float(scfg.near_out_of_range_value), bool(scfg.normalize_range))
             assert np.array_equal(npy(g["segmentation_pixels"]), seg_ref), t                # segmentation ids: bit-exact
@@ -227,9 +238,12 @@ def test_navigation_task_step_by_step_vs_oracle(orc, parity, case):
             if reset_ref.any():  # the reference refreshes EVERY env's derived tensors when any env resets
                 eu, qv, vv, vb, wb = orc.update_states(post["state"])
                 assert max_abs(post["vbody"], vb) < 1e-5 and max_abs(post["qveh"], qv) < 1e-5, t
-        assert n_resets >= 2 * n and (n_crashes >= 1 or "lidar" in case), (n_resets, n_crashes)  # truncations and collisions seen
+        need = 2 * n if min_resets is None else min_resets
+        assert n_resets >= need and (n_crashes >= 1 or "lidar" in case), (n_resets, n_crashes)  # truncations and collisions seen
+        return dict(resets=n_resets, crashes=n_crashes)
     finally:
         cfg.episode_len_steps, cfg.args, cfg.device = old_cfg
+        cfg.curriculum.min_level, cfg.curriculum.max_level = old_cur
 
 
 @pytest.mark.parametrize("shape", [(48, 64), (32, 512), (30, 50), (270, 480), (5, 7), (64, 1024), (17, 200)])
