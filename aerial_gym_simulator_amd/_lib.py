@@ -223,7 +223,7 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 8  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 9  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -245,6 +245,7 @@ _SIGNATURES = {
                                      C.c_int, C.c_int, _P, _P, _P]),
     "agx_env_step_kernel": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxTaskArgs),
                                       C.c_char_p, C.c_int]),
+    "agx_raycast_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "agx_reset_masked": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P]),
     "agx_nav_robot_side": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs),
                                      C.POINTER(AgxNavRobotSideArgs), _P]),

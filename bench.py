@@ -259,21 +259,19 @@ def env_step_key(task, k):
     return buf.value.decode()
 
 
-def raycast_grid_threads(task):
-    """grid size (threads) of the frame's k_raycast launch: the key of its counters in the PMC file"""
-    cfg = task.sim_env.robot_manager.warp_sensor.cfg
-    n, ns = task.num_envs, cfg.num_sensors
-    tw = 16 if task.sim_env.robot_manager.warp_sensor.is_lidar else 8  # csrc/agx_raycast.hip: Tile<LIDAR>
-    tiles = ((cfg.width + tw - 1) // tw) * ((cfg.height + 64 // tw - 1) // (64 // tw))
-    split = max(1, min((16384 + n * ns * 4 - 1) // (n * ns * 4), (tiles + 3) // 4))
-    return n * ns * split * 256
-
-
 def raycast_key(task):
-    """key of the frame's ray-cast kernel instance in the PMC file (template arguments <lidar, lds, variant> + grid)"""
+    """key of the frame's ray-cast kernel instance in the PMC file (template arguments <lidar, variant> + grid size in threads),
+    as the library names the instance it launches for these sizes"""
+    import ctypes as C
+
+    from aerial_gym_simulator_amd import _lib
+
     sen = task.sim_env.robot_manager.warp_sensor
+    cfg = sen.cfg
     variant = 2 if sen.is_stereo else (1 if sen.is_normal else 0)
-    return "k_raycast<%s,false,%d>_%d" % ("true" if sen.is_lidar else "false", variant, raycast_grid_threads(task))
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().agx_raycast_kernel(task.num_envs, cfg.num_sensors, cfg.width, cfg.height, int(sen.is_lidar), variant, buf, 128), "agx_raycast_kernel")
+    return buf.value.decode()
 
 
 def cpu_baseline_reference():

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 8
+#define AGX_ABI_VERSION 9
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -577,6 +577,11 @@ int agx_raycast_lidar(int num_envs, int num_sensors, int width, int height,
                       const float *quat, const float *tri_world, const int32_t *tri_seg,
                       const float *nodes, int num_tris, float *pixels, int32_t *seg,
                       const AgxRangeLimits *limits, void *stream);
+
+/* Which kernel instance the three entry points above launch for these sizes, as "<kernel name incl. template arguments>_<grid
+ * size in threads>" (e.g. "k_raycast<false,0>_6291456"): the key under which profilers list it (like agx_env_step_kernel).
+ * variant: 0 depth / range / point cloud, 1 normal + face id, 2 stereo.                                                  */
+int agx_raycast_kernel(int num_envs, int num_sensors, int width, int height, int lidar, int variant, char *out, int out_len);
 
 /* WarpSensor.apply_noise / apply_range_limits / normalize_observation
  * (warp_sensor.py:202-247), scalar images, in place.  z_normal/u_dropout optional.     */

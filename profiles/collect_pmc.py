@@ -28,7 +28,7 @@ def load(path, counter):
         elif "k_raycast" in name:
             import re
 
-            m = re.search(r"k_raycast<([^>]*)>", name)  # <lidar, lds, variant>
+            m = re.search(r"k_raycast<([^>]*)>", name)  # <lidar, variant>
             key = ("k_raycast<%s>" % m.group(1).replace(" ", "") if m else "k_raycast", int(r["Grid_Size"]))
         elif "k_reset_masked" in name:
             key = ("k_reset_masked", int(r["Grid_Size"]))

@@ -6,9 +6,8 @@
 //   * one workgroup per (env, sensor); the env's BVH nodes (64 B each, both child boxes inline)
 //     and triangles (36 B each) are read through wave-uniform addresses, i.e. one L2 request
 //     (scalar load) per visited node for the whole packet; the env's tree (127 KB) stays in the
-//     XCD's L2 for the frame, so HBM sees each scene once per frame.  (Staging the whole tree in LDS caps a CU at one
-//     workgroup and measured slower: profiles/r01_raycast_variants.txt; that variant and every other rejected one live in
-//     profiles/src/raycast_variants/, not here.)
+//     XCD's L2 for the frame, so HBM sees each scene once per frame.  (An LDS-staged variant of
+//     the same traversal is kept behind AGX_RAY_USE_LDS; it is slower here, see below.)
 //   * a wavefront (64 lanes) owns an 8x8 pixel tile and walks the tree as ONE packet:
 //     every node fetch is a wave-uniform (scalar) load, lanes vote with __ballot on which
 //     children to visit and in which order (majority near-first), and the packet's
@@ -30,12 +29,51 @@
 
 namespace agx {
 
-// Build-time shape parameters (measured: profiles/r01..r03_raycast_variants.txt).  The algorithmic variants that were tried and
-// rejected -- LDS-staged trees, 4-wide nodes, octant-uniform slab tests, leaf prefetch, per-condition early returns, the
-// unspecialised traversal loop -- are archived with their switches in profiles/src/raycast_variants/agx_raycast_r03_with_switches.hip;
-// this file holds the shipped path only.
+// Measured on MI355X (profiles/r01_raycast_variants.txt, config 3, 8192 envs): traversing straight from
+// L2 with wave-uniform (scalar) node loads at full occupancy beats staging the tree in LDS, because
+// the 127 KB LDS footprint caps a CU at one workgroup:   LDS/512 thr 4.74 ms, LDS/1024 thr 3.39 ms,
+// L2/512 thr 2.62 ms, L2/256 thr 2.54 ms per env step.  The LDS path is kept for A/B runs.
 #ifndef AGX_RAY_THREADS
 #define AGX_RAY_THREADS 256
+#endif
+#ifndef AGX_RAY_TRI_VARIANT
+#define AGX_RAY_TRI_VARIANT 1  // branch structure of the triangle test: 0 = an early return per condition (the reference's shape), 1 = one early-out (shipped: -3 %), 2 = none
+#endif
+#ifndef AGX_RAY_HOIST_UPID
+#define AGX_RAY_HOIST_UPID 1  // one copy of the traversal loop per packet (axis, orientation) instead of a switch per triangle (-2 %)
+#endif
+#ifndef AGX_RAY_ADDR32
+#define AGX_RAY_ADDR32 1  // 32-bit offsets for node / triangle fetches: scalar loads with a register offset (-2.5 %)
+#endif
+#ifndef AGX_RAY_NOWANT
+#define AGX_RAY_NOWANT 1  // lanes that missed the leaf's box run the triangle test too (no exec branch around it); only the update is masked (-2 %)
+#endif
+#ifndef AGX_RAY_PAIRLOAD
+#define AGX_RAY_PAIRLOAD 1  // both triangles of a two-triangle leaf fetched before the first test (-1 %)
+#endif
+#ifndef AGX_RAY_PREFETCH_LEAF
+#define AGX_RAY_PREFETCH_LEAF 0  // experiment: the triangles of a left leaf child requested before the node's box tests
+#endif
+#ifndef AGX_RAY_NOACTIVE
+#define AGX_RAY_NOACTIVE 1  // retired lanes carry best = -inf instead of being masked in every slab test (-1 % camera)
+#endif
+#ifndef AGX_RAY_FLAT
+#define AGX_RAY_FLAT 1  // one comparison per slab test, |.|-min3 for the zero-edge test, hit update as selects: no exec regions (-7 %)
+#endif
+#ifndef AGX_RAY_VOTEMASK
+#define AGX_RAY_VOTEMASK 1  // votes of conjunctions as mask arithmetic on the votes of their terms (-2 %)
+#endif
+#ifndef AGX_RAY_BOX_OCTANT
+#define AGX_RAY_BOX_OCTANT 0  // experiment (needs AGX_RAY_HOIST_UPID): octant-uniform packets pick near / far planes on the scalar unit
+#endif
+#ifndef AGX_RAY_BOX_AXIS
+#define AGX_RAY_BOX_AXIS 1  // (needs AGX_RAY_HOIST_UPID) no min / max along the packet's dominant axis in the slab test (-2 %)
+#endif
+#ifndef AGX_RAY_WIDE
+#define AGX_RAY_WIDE 0  // experiment: 4-wide nodes (profiles/wide_probe.py)
+#endif
+#ifndef AGX_RAY_USE_LDS
+#define AGX_RAY_USE_LDS 0
 #endif
 constexpr int kRayThreads = AGX_RAY_THREADS;  // waves per workgroup = kRayThreads / 64
 // pixel tile of a 64-ray packet.  Measured (profiles/r02_raycast_variants.txt, bit-exact either way): the pinhole camera
@@ -78,6 +116,13 @@ AGX_DEV float diff_product(float a, float b, float c, float d) {
   return diff + error;
 }
 
+#ifdef AGX_RAY_STATS  // experimental builds only (profiles/raystats.py): traversal counters
+__device__ unsigned long long g_ray_stats[8];
+#define AGX_STAT(i, v) if ((threadIdx.x & 63) == 0) atomicAdd(&g_ray_stats[i], (unsigned long long)(v))
+#else
+#define AGX_STAT(i, v)
+#endif
+
 struct Ray {
   V3 op, d;   // op: the origin's components in the order (kx, ky, kz) the triangle test uses them
   V3 rcp, orcp;  // 1 / d clamped to +-1e30, and o * rcp (slab test only; the triangle test uses d)
@@ -116,13 +161,12 @@ AGX_DEV void ray_setup(Ray &r, V3 o, V3 d, float max_t, bool active) {
 
 // warp intersect.h intersect_ray_tri_woop (t only).
 // The vertices are wave-uniform (scalar loads); which of their components plays x / y / z depends on the ray's dominant
-// axis.  UPID >= 0: every active ray of the packet has the same dominant axis and orientation (2 * kz + swap: the usual case
-// for an 8 x 8 pixel tile or a 16 x 4 LiDAR bundle) -- the component choice is then made at COMPILE time (the whole traversal
-// loop is instantiated per UPID, `traverse`) instead of with two v_cndmask per component and lane (18 of the ~95 vector
-// instructions of a triangle test).  UPID = -1: mixed packet, per-lane choice.  Same operands, same operations either way.
-// Branch structure: ONE early-out (mixed edge signs | zero determinant); T, the sign test and 1 / det are unconditional -- a lane
-// that is rejected computes values nobody reads (1 / 0 included), an accepted lane goes through exactly the operations of the
-// reference's test (which returns early per condition: three nested exec regions more per triangle, +3 %).
+// axis.  `ukz` >= 0: every active ray of the packet has the same dominant axis and orientation (`ukz`, `uswap`: the usual
+// case for an 8 x 8 pixel tile or a 16 x 4 LiDAR bundle) -- the component choice is then made ONCE on the scalar unit
+// instead of with two v_cndmask per component and lane (18 of the ~95 vector instructions of a triangle test): the leaf
+// test switches on the packet's (axis, orientation) into one of six instances with the components fixed at compile time.
+// Mixed packet: per-lane choice.  Same operands, same operations either way.
+// UPID: 2 * kz + swap when known at compile time (the caller switches on the packet's wave-uniform value), -1 = per lane
 template <int UPID>
 AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   float Akx, Aky, Akz, Bkx, Bky, Bkz, Ckx, Cky, Ckz;
@@ -149,7 +193,11 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   float U = diff_product(Cx, By, Cy, Bx);
   float V = diff_product(Ax, Cy, Ay, Cx);
   float W = diff_product(Bx, Ay, By, Ax);
+#if AGX_RAY_FLAT
   if (fminf(fminf(fabsf(U), fabsf(V)), fabsf(W)) == 0.0f) {  // any of the three exactly 0 (one v_min3 with |.| modifiers, one compare)
+#else
+  if (U == 0.0f || V == 0.0f || W == 0.0f) {
+#endif
     double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
     U = (float)(CxBy - CyBx);
     double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
@@ -157,10 +205,27 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
     double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
     W = (float)(BxAy - ByAx);
   }
+#if AGX_RAY_TRI_VARIANT == 0
+  if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+  float det = U + V + W;
+  if (det == 0.0f) return false;
+  float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
+  float T = U * Az + V * Bz + W * Cz;
+  uint32_t ds = __float_as_uint(det) & 0x80000000u;
+  if (__uint_as_float(__float_as_uint(T) ^ ds) < 0.0f) return false;
+  float rcp = 1.0f / det;
+  t_out = T * rcp;
+  return true;
+#else
+  // Fewer exec-mask branches around the same arithmetic (profiles/r03_raycast_variants.txt).  1: one early-out (edge signs +
+  // determinant), the rest unconditional; 2: no early-out at all.  A lane that is rejected computes values
+  // nobody reads (1 / 0 included); an accepted lane goes through exactly the operations of variant 0.
   const bool mixed = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
   const float det = U + V + W;
   const bool ok = !mixed && det != 0.0f;
+#if AGX_RAY_TRI_VARIANT == 1
   if (!ok) return false;
+#endif
   const float Az = r.Sz * Akz, Bz = r.Sz * Bkz, Cz = r.Sz * Ckz;
   const float T = U * Az + V * Bz + W * Cz;
   const uint32_t ds = __float_as_uint(det) & 0x80000000u;
@@ -168,43 +233,109 @@ AGX_DEV bool ray_tri(const Ray &r, V3 a, V3 b, V3 c, float &t_out) {
   const float rcp = 1.0f / det;
   t_out = T * rcp;
   return ok && front;
+#endif
 }
 
-// closest hit: smaller t wins, on an exact tie the smaller face index (DESIGN.md "closest-hit semantics"); ANY (occlusion query):
-// the first accepted hit retires the lane -- it carries best = -inf from then on, so every later slab test fails for it.
-// The condition is mask arithmetic and the update two selects: no exec regions.
+// ANY: occlusion query -- the first accepted hit retires the lane (it stops voting in ray_box)
+// CUPID (AGX_RAY_HOIST_UPID builds): the packet's (axis, orientation) as a template parameter of the whole traversal instead of
+// a switch per triangle; -2 = decide here
+template <bool ANY, int CUPID = -2>
+AGX_DEV void test_leaf(Ray &r, const float *__restrict__ tris, int f, bool want, int upid) {
+#if !AGX_RAY_NOWANT
+  if (!want) return;
+#endif
+#if AGX_RAY_ADDR32
+  const float *t = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)f * 36u);
+#else
+  const float *t = tris + (size_t)f * 9;
+#endif
+  float th = 0.0f;
+  const V3 a = V3{t[0], t[1], t[2]}, b = V3{t[3], t[4], t[5]}, c = V3{t[6], t[7], t[8]};
+  bool hit;
+  if (CUPID != -2) {
+    hit = ray_tri<CUPID>(r, a, b, c, th);
+  } else
+  switch (upid) {  // wave-uniform
+    case 0: hit = ray_tri<0>(r, a, b, c, th); break;
+    case 1: hit = ray_tri<1>(r, a, b, c, th); break;
+    case 2: hit = ray_tri<2>(r, a, b, c, th); break;
+    case 3: hit = ray_tri<3>(r, a, b, c, th); break;
+    case 4: hit = ray_tri<4>(r, a, b, c, th); break;
+    case 5: hit = ray_tri<5>(r, a, b, c, th); break;
+    default: hit = ray_tri<-1>(r, a, b, c, th); break;
+  }
+  if (AGX_RAY_NOWANT ? (hit && want) : hit) {
+    if (ANY) {
+      if (th >= 0.0f && th < r.best) {
+        r.face = f;
+        r.active = false;
+        if (AGX_RAY_NOACTIVE) r.best = -INFINITY;
+      }
+    } else if (th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
+      r.best = th;
+      r.face = f;
+    }
+  }
+}
+
+// closest hit: smaller t wins, on an exact tie the smaller face index (DESIGN.md "closest-hit semantics"); any-hit: the first
+// accepted hit retires the lane.  AGX_RAY_FLAT: the condition as mask arithmetic and the update as selects -- no exec regions.
 template <bool ANY>
 AGX_DEV void accept_hit(Ray &r, bool hit, float th, int f) {
+#if AGX_RAY_FLAT
   if (ANY) {
     const bool acc = hit & (th >= 0.0f) & (th < r.best);
     r.face = acc ? f : r.face;
     r.active = acc ? false : r.active;
-    r.best = acc ? -INFINITY : r.best;
+    if (AGX_RAY_NOACTIVE) r.best = acc ? -INFINITY : r.best;
   } else {
     const bool acc = hit & (th >= 0.0f) & ((th < r.best) | ((th == r.best) & (r.face >= 0) & (f < r.face)));
     r.best = acc ? th : r.best;
     r.face = acc ? f : r.face;
   }
+#else
+  if (ANY) {
+    if (hit && th >= 0.0f && th < r.best) { r.face = f; r.active = false; if (AGX_RAY_NOACTIVE) r.best = -INFINITY; }
+  } else if (hit && th >= 0.0f && (th < r.best || (th == r.best && r.face >= 0 && f < r.face))) {
+    r.best = th;
+    r.face = f;
+  }
+#endif
 }
 
-// A leaf: triangle f1 and, in a two-triangle leaf, f2 (< 0: none).  Both triangles are fetched (32-bit byte offsets from the
-// env's block: scalar loads with a register offset) before the first is tested -- one exposed scalar-load latency per leaf
-// instead of two; the tests and updates stay in order.  Lanes that missed the leaf's box (`want` false) run the tests too, only
-// the update is masked: no exec branch around a triangle test.
-template <bool ANY, int UPID>
-AGX_DEV void test_leaf_pair(Ray &r, const float *__restrict__ tris, int f1, int f2, bool want) {
+struct TriPair {
+  V3 a1, b1, c1, a2, b2, c2;
+};
+AGX_DEV TriPair load_tri_pair(const float *__restrict__ tris, int f1, int f2) {
   const float *t1 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)f1 * 36u);
   const float *t2 = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tris) + (uint32_t)(f2 >= 0 ? f2 : f1) * 36u);
-  const V3 a1 = V3{t1[0], t1[1], t1[2]}, b1 = V3{t1[3], t1[4], t1[5]}, c1 = V3{t1[6], t1[7], t1[8]};
-  const V3 a2 = V3{t2[0], t2[1], t2[2]}, b2 = V3{t2[3], t2[4], t2[5]}, c2 = V3{t2[6], t2[7], t2[8]};
+  return TriPair{V3{t1[0], t1[1], t1[2]}, V3{t1[3], t1[4], t1[5]}, V3{t1[6], t1[7], t1[8]},
+                 V3{t2[0], t2[1], t2[2]}, V3{t2[3], t2[4], t2[5]}, V3{t2[6], t2[7], t2[8]}};
+}
+template <bool ANY, int CUPID>
+AGX_DEV void test_tri_pair(Ray &r, const TriPair &P, int f1, int f2, bool want) {
   float th = 0.0f;
-  bool hit = ray_tri<UPID>(r, a1, b1, c1, th) && want;
+  bool hit = ray_tri<CUPID>(r, P.a1, P.b1, P.c1, th) && want;
   accept_hit<ANY>(r, hit, th, f1);
   if (f2 >= 0) {
     th = 0.0f;
-    hit = ray_tri<UPID>(r, a2, b2, c2, th) && want;
+    hit = ray_tri<CUPID>(r, P.a2, P.b2, P.c2, th) && want;
     accept_hit<ANY>(r, hit, th, f2);
   }
+}
+// A leaf and the second triangle of a two-triangle leaf (f2 < 0: none).  AGX_RAY_PAIRLOAD: both triangles are fetched before the
+// first is tested (one exposed scalar-load latency per leaf instead of two); the tests and updates stay in order.
+template <bool ANY, int CUPID>
+AGX_DEV void test_leaf_pair(Ray &r, const float *__restrict__ tris, int f1, int f2, bool want, int upid) {
+#if AGX_RAY_PAIRLOAD
+  if (CUPID != -2) {
+    const TriPair P = load_tri_pair(tris, f1, f2);
+    test_tri_pair<ANY, CUPID>(r, P, f1, f2, want);
+    return;
+  }
+#endif
+  test_leaf<ANY, CUPID>(r, tris, f1, want, upid);
+  if (f2 >= 0) test_leaf<ANY, CUPID>(r, tris, f2, want, upid);
 }
 
 // Conservative slab test, one fma per plane: t = b * rcp - o * rcp, with rcp CLAMPED to +-1e30 in ray_setup.
@@ -215,16 +346,13 @@ AGX_DEV void test_leaf_pair(Ray &r, const float *__restrict__ tris, int f1, int 
 //     measured: occlusion rays with d_z == 0 lost their occluder, test_stereo_occlusion_ray_with_zero_direction_component):
 //     a hit at t <= max_t moves < 1e-26 along c, so the origin lies inside the un-grown slab up to that, i.e.
 //     >= 1e-3 inside the grown one; b * 1e30 - o * 1e30 then has the right sign and magnitude >= 1e27 > any max_t.
-// UPID >= 0 (a packet whose rays share the dominant axis kz = UPID >> 1 and its sign, UPID & 1: d[kz] < 0): along THAT axis the
-// order of the two plane distances is known -- fma is monotone in its first argument, lo <= hi, and the sign of rcp is the
+// CUPID >= 0 (a packet whose rays share the dominant axis kz = CUPID >> 1 and its sign, CUPID & 1: d[kz] < 0): along THAT axis
+// the order of the two plane distances is known -- fma is monotone in its first argument, lo <= hi, and the sign of rcp is the
 // packet's -- so the min / max pair of that axis is dropped; the values that remain are the ones min / max would have picked.
-// The verdict tmax >= 0 and tmax >= tmin and tmin <= best -- with best >= 0 for a live lane and -inf for a retired one or a lane
-// outside the image -- is the ONE comparison max(tmin, 0) <= min(tmax, best): a v_cmp that writes the packet's mask directly (the
-// ballot of a conjunction goes through a VGPR).
-template <int UPID>
+template <int CUPID = -1>
 AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, float &tnear) {
-  constexpr int kzc = UPID >= 0 ? (UPID >> 1) : -1;
-  constexpr bool neg = UPID >= 0 && (UPID & 1);
+  constexpr int kzc = CUPID >= 0 ? (CUPID >> 1) : -1;
+  constexpr bool neg = CUPID >= 0 && (CUPID & 1);
   float t0 = fmaf(lx, r.rcp.x, -r.orcp.x), t1 = fmaf(hx, r.rcp.x, -r.orcp.x);
   float tmin = kzc == 0 ? (neg ? t1 : t0) : fminf(t0, t1), tmax = kzc == 0 ? (neg ? t0 : t1) : fmaxf(t0, t1);
   t0 = fmaf(ly, r.rcp.y, -r.orcp.y); t1 = fmaf(hy, r.rcp.y, -r.orcp.y);
@@ -233,52 +361,228 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   tmin = fmaxf(tmin, kzc == 2 ? (neg ? t1 : t0) : fminf(t0, t1)); tmax = fminf(tmax, kzc == 2 ? (neg ? t0 : t1) : fmaxf(t0, t1));
   tmax *= 1.0000004f;
   tnear = tmin;
+#if AGX_RAY_NOACTIVE && AGX_RAY_FLAT
+  // tmax >= 0 and tmax >= tmin and tmin <= best, with best >= 0 for a live lane and -inf for a retired one (traverse), is the
+  // ONE comparison max(tmin, 0) <= min(tmax, best): a v_cmp that writes the packet's mask directly (the ballot of a conjunction
+  // goes through a VGPR)
   return fmaxf(tmin, 0.0f) <= fminf(tmax, r.best);
+#elif AGX_RAY_NOACTIVE  // a retired lane carries best = -inf (traverse): the last comparison fails for it
+  return (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+#else
+  return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
+#endif
+}
+
+// The same test for a packet whose rays all point into the same OCTANT (`oct`, wave-uniform: bit a set = every active ray has
+// 1 / d_a < 0): which plane of a slab is the near one is then the packet's choice, made on the scalar unit (the planes are
+// wave-uniform), and no min / max is left per lane.  Same plane distances, same comparisons as ray_box.
+AGX_DEV bool ray_box_oct(const Ray &r, float lx, float ly, float lz, float hx, float hy, float hz, int oct, float &tnear) {
+  const bool nx = (oct & 1) != 0, ny = (oct & 2) != 0, nz = (oct & 4) != 0;
+  const float ax = nx ? hx : lx, bx = nx ? lx : hx, ay = ny ? hy : ly, by = ny ? ly : hy, az = nz ? hz : lz, bz = nz ? lz : hz;
+  float tmin = fmaf(ax, r.rcp.x, -r.orcp.x), tmax = fmaf(bx, r.rcp.x, -r.orcp.x);
+  tmin = fmaxf(tmin, fmaf(ay, r.rcp.y, -r.orcp.y)); tmax = fminf(tmax, fmaf(by, r.rcp.y, -r.orcp.y));
+  tmin = fmaxf(tmin, fmaf(az, r.rcp.z, -r.orcp.z)); tmax = fminf(tmax, fmaf(bz, r.rcp.z, -r.orcp.z));
+  tmax *= 1.0000004f;
+  tnear = tmin;
+  return r.active && (tmax >= 0.0f) && (tmax >= tmin) && (tmin <= r.best);
 }
 
 AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
 
-// Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k holds entry k (depth <= 64 > 30
-// Morton bits + log2(T) tie bits of the LBVH).  Votes of conjunctions are mask arithmetic on the votes of their terms (the
-// ballot of ONE comparison is the comparison's own mask).
-template <bool ANY, int UPID>
-AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+#if AGX_RAY_WIDE
+// EXPERIMENT (profiles/wide_probe.py; built only with -DAGX_RAY_WIDE=1): 4-wide nodes.  A record is 32 floats: box k = 0..3 at
+// [6 k .. 6 k + 5] (lo xyz, hi xyz), its reference at [24 + k] (>= 0: record index, < 0: leaf ~triangle, INT_MIN: no entry),
+// the second triangle of a two-triangle leaf at [28 + k].  Entries 0, 1 come from the binary node's left child, 2, 3 from its
+// right child (a leaf child occupies the first entry of its pair), so the visiting order can follow the binary tree's votes.
+constexpr int kNoEntry = (int)0x80000000;
+template <bool ANY = false>
+AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  int upid = -1;
+  {
+    const int pid = r.kz * 2 + (r.swap ? 1 : 0);
+    const unsigned long long act = vote(r.active);
+    if (act) {
+      const int p0 = __builtin_amdgcn_readlane(pid, __ffsll((long long)act) - 1);
+      if (vote(r.active && pid != p0) == 0ull) upid = p0;
+    }
+  }
   if (nt == 1) {
-    test_leaf_pair<ANY, UPID>(r, tris, 0, -1, r.active);
+    test_leaf<ANY>(r, tris, 0, r.active, upid);
+    return;
+  }
+  int sp = 0, node = 0, stack = 0;
+  const int lane = threadIdx.x & 63;
+  AGX_STAT(0, 1);
+  while (true) {
+    AGX_STAT(1, 1);
+    const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 32);
+    const float4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3], w4 = nd[4], w5 = nd[5], w6 = nd[6], w7 = nd[7];
+    const int r0 = __float_as_int(w6.x), r1 = __float_as_int(w6.y), r2 = __float_as_int(w6.z), r3 = __float_as_int(w6.w);
+    const int s0 = __float_as_int(w7.x), s1 = __float_as_int(w7.y), s2 = __float_as_int(w7.z), s3 = __float_as_int(w7.w);
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    bool h0 = false, h1 = false, h2 = false, h3 = false;
+    if (r0 != kNoEntry) h0 = ray_box(r, w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, t0);
+    if (r1 != kNoEntry) h1 = ray_box(r, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, t1);
+    if (r2 != kNoEntry) h2 = ray_box(r, w3.x, w3.y, w3.z, w3.w, w4.x, w4.y, t2);
+    if (r3 != kNoEntry) h3 = ray_box(r, w4.z, w4.w, w5.x, w5.y, w5.z, w5.w, t3);
+    unsigned long long m0 = vote(h0), m1 = vote(h1), m2 = vote(h2), m3 = vote(h3);
+    // leaves first, in entry order; whatever comes after a leaf test votes again with the shortened rays
+    bool shortened = false;
+#define AGX_WIDE_LEAF(R, S, H, T, M)                                   \
+  if (R < 0 && R != kNoEntry) {                                         \
+    if (shortened && M) {                                               \
+      H = H && (T <= r.best) && r.active;                               \
+      M = vote(H);                                                      \
+    }                                                                   \
+    if (M) {                                                            \
+      test_leaf<ANY>(r, tris, ~R, H, upid);                             \
+      if (S >= 0) test_leaf<ANY>(r, tris, S, H, upid);                  \
+      AGX_STAT(2, S >= 0 ? 2 : 1);                                      \
+      shortened = true;                                                 \
+    }                                                                   \
+    M = 0;                                                              \
+    H = false;                                                          \
+  }
+    AGX_WIDE_LEAF(r0, s0, h0, t0, m0)
+    AGX_WIDE_LEAF(r1, s1, h1, t1, m1)
+    AGX_WIDE_LEAF(r2, s2, h2, t2, m2)
+    AGX_WIDE_LEAF(r3, s3, h3, t3, m3)
+#undef AGX_WIDE_LEAF
+    if (shortened) {
+      if (m0) { h0 = h0 && (t0 <= r.best) && r.active; m0 = vote(h0); }
+      if (m1) { h1 = h1 && (t1 <= r.best) && r.active; m1 = vote(h1); }
+      if (m2) { h2 = h2 && (t2 <= r.best) && r.active; m2 = vote(h2); }
+      if (m3) { h3 = h3 && (t3 <= r.best) && r.active; m3 = vote(h3); }
+    }
+    // order: within each pair and between the pairs, the nearer first by majority among the lanes that hit both
+    bool a_swap = false, b_swap = false;  // entry 1 before entry 0 / entry 3 before entry 2
+    if (m0 && m1) {
+      const unsigned long long both = vote(h0 && h1), first = vote(h0 && h1 && t0 <= t1);
+      a_swap = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(m0) < __popcll(m1));
+    } else {
+      a_swap = m0 == 0ull;
+    }
+    if (m2 && m3) {
+      const unsigned long long both = vote(h2 && h3), first = vote(h2 && h3 && t2 <= t3);
+      b_swap = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(m2) < __popcll(m3));
+    } else {
+      b_swap = m2 == 0ull;
+    }
+    const unsigned long long ma = m0 | m1, mb = m2 | m3;
+    bool b_first = false;
+    if (ma && mb) {
+      const bool ha = h0 || h1, hb = h2 || h3;
+      const float ta = fminf(h0 ? t0 : 3.0e38f, h1 ? t1 : 3.0e38f), tb = fminf(h2 ? t2 : 3.0e38f, h3 ? t3 : 3.0e38f);
+      const unsigned long long both = vote(ha && hb), first = vote(ha && hb && ta <= tb);
+      b_first = both ? (2 * __popcll(first) < __popcll(both)) : (__popcll(ma) < __popcll(mb));
+    } else {
+      b_first = ma == 0ull;
+    }
+    // the four entries near -> far: (reference, hit by anybody)
+    const int a0r = a_swap ? r1 : r0, a1r = a_swap ? r0 : r1, b0r = b_swap ? r3 : r2, b1r = b_swap ? r2 : r3;
+    const bool a0h = (a_swap ? m1 : m0) != 0ull, a1h = (a_swap ? m0 : m1) != 0ull, b0h = (b_swap ? m3 : m2) != 0ull, b1h = (b_swap ? m2 : m3) != 0ull;
+    const int e0 = b_first ? b0r : a0r, e1 = b_first ? b1r : a1r, e2 = b_first ? a0r : b0r, e3 = b_first ? a1r : b1r;
+    const bool g0 = b_first ? b0h : a0h, g1 = b_first ? b1h : a1h, g2 = b_first ? a0h : b0h, g3 = b_first ? a1h : b1h;
+    int next = -1;
+    // push far -> near everything behind the first hit entry
+    const bool before3 = g0 || g1 || g2, before2 = g0 || g1, before1 = g0;
+    if (g3) {
+      if (before3) { stack = (lane == (sp & (kStackDepth - 1))) ? e3 : stack; ++sp; } else next = e3;
+    }
+    if (g2) {
+      if (before2) { stack = (lane == (sp & (kStackDepth - 1))) ? e2 : stack; ++sp; } else next = e2;
+    }
+    if (g1) {
+      if (before1) { stack = (lane == (sp & (kStackDepth - 1))) ? e1 : stack; ++sp; } else next = e1;
+    }
+    if (g0) next = e0;
+    if (next < 0) {
+      if (sp == 0) break;
+      --sp;
+      next = __builtin_amdgcn_readlane(stack, sp & (kStackDepth - 1));
+    }
+    node = __builtin_amdgcn_readfirstlane(next);
+  }
+}
+#else
+// Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k
+// holds entry k (depth <= 64 > 30 Morton bits + log2(T) tie bits of the LBVH).
+template <bool ANY, int CUPID, bool OCT = false>
+AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt, int upid, int oct = 0) {
+  if (nt == 1) {
+    test_leaf<ANY, CUPID>(r, tris, 0, r.active, upid);
     return;
   }
   int sp = 0;
   int node = 0;
   int stack = 0;
   const int lane = threadIdx.x & 63;
+  AGX_STAT(0, 1);  // packets
   while (true) {
+    AGX_STAT(1, 1);  // node visits
+#if AGX_RAY_ADDR32
     // 32-bit byte offsets from the env's node block (< 2^31 bytes): a scalar load with a register offset, no 64-bit address arithmetic
     const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)node << 6));
+#else
+    const float4 *nd = reinterpret_cast<const float4 *>(nodes + (size_t)node * 16);
+#endif
     float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
     int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
     const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
+#if AGX_RAY_PREFETCH_LEAF
+    TriPair PL;  // a leaf on the left: its triangles are requested before the box tests run
+    constexpr bool kPrefetch = CUPID != -2;
+    if (kPrefetch && cl < 0) PL = load_tri_pair(tris, ~cl, cl2);
+#endif
     float tl, tr;
-    bool hl = ray_box<UPID>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
-    bool hr = ray_box<UPID>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    bool hl, hr;
+    if (OCT) {
+      hl = ray_box_oct(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, oct, tl);
+      hr = ray_box_oct(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, oct, tr);
+    } else {
+      hl = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
+      hr = ray_box<AGX_RAY_BOX_AXIS ? CUPID : -1>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+    }
     unsigned long long ml = vote(hl), mr = vote(hr);
     if (cl < 0) {
-      if (ml) test_leaf_pair<ANY, UPID>(r, tris, ~cl, cl2, hl);
+      if (ml) {
+#if AGX_RAY_PREFETCH_LEAF
+        if (kPrefetch) test_tri_pair<ANY, CUPID>(r, PL, ~cl, cl2, hl);
+        else
+#endif
+        test_leaf_pair<ANY, CUPID>(r, tris, ~cl, cl2, hl, upid);
+        AGX_STAT(2, cl2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(ml));
+      }
       ml = 0;
     }
     if (cr < 0) {
       if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
-        mr &= vote(tr <= r.best);
+#if AGX_RAY_VOTEMASK && AGX_RAY_NOACTIVE
+        mr &= vote(tr <= r.best);  // (the ballot of ONE comparison is the comparison's own mask; a conjunction goes through a VGPR)
         hr = hr && (tr <= r.best);
+#else
+        hr = hr && (tr <= r.best) && (AGX_RAY_NOACTIVE || r.active);
+        mr = vote(hr);
+#endif
       }
-      if (mr) test_leaf_pair<ANY, UPID>(r, tris, ~cr, cr2, hr);
+      if (mr) {
+        test_leaf_pair<ANY, CUPID>(r, tris, ~cr, cr2, hr, upid);
+        AGX_STAT(2, cr2 >= 0 ? 2 : 1); AGX_STAT(3, __popcll(mr));
+      }
       mr = 0;
     }
     int next = -1;
     if (ml && mr) {
       // majority vote on which child is nearer among lanes that hit both
+#if AGX_RAY_VOTEMASK
       const unsigned long long both = ml & mr;
       const unsigned long long lfirst = both & vote(tl <= tr);
       const bool left_first = both ? (2 * (int)__popcll(lfirst) >= (int)__popcll(both)) : ((int)__popcll(ml) >= (int)__popcll(mr));
+#else
+      unsigned long long both = vote(hl && hr);
+      unsigned long long lfirst = vote(hl && hr && tl <= tr);
+      bool left_first = both ? (2 * __popcll(lfirst) >= __popcll(both)) : (__popcll(ml) >= __popcll(mr));
+#endif
       next = left_first ? cl : cr;
       int far = left_first ? cr : cl;
       stack = (lane == (sp & (kStackDepth - 1))) ? far : stack;  // push: entry sp lives in lane sp
@@ -297,7 +601,7 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
   }
 }
 
-// ANY: occlusion query -- the first accepted hit retires the lane
+
 template <bool ANY = false>
 AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
   // do all active rays of the packet share the dominant axis and its orientation?
@@ -310,17 +614,44 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
       if (vote(r.active && pid != p0) == 0ull) upid = p0;
     }
   }
+#if AGX_RAY_NOACTIVE
   if (!r.active) r.best = -INFINITY;  // (a lane outside the image: nobody reads its `best`)
-  switch (upid) {  // wave-uniform, once per packet: seven copies of the loop (-2 % vs a switch in front of every triangle test)
-    case 0: traverse_impl<ANY, 0>(r, nodes, tris, nt); break;
-    case 1: traverse_impl<ANY, 1>(r, nodes, tris, nt); break;
-    case 2: traverse_impl<ANY, 2>(r, nodes, tris, nt); break;
-    case 3: traverse_impl<ANY, 3>(r, nodes, tris, nt); break;
-    case 4: traverse_impl<ANY, 4>(r, nodes, tris, nt); break;
-    case 5: traverse_impl<ANY, 5>(r, nodes, tris, nt); break;
-    default: traverse_impl<ANY, -1>(r, nodes, tris, nt); break;
+#endif
+#if AGX_RAY_HOIST_UPID && AGX_RAY_BOX_OCTANT
+  // ... and the same octant?  (sign bits of the clamped reciprocals: 1 / +0 counts as positive, 1 / -0 as negative, like ray_box)
+  int oct = -1;
+  if (upid >= 0) {
+    const int sb = (int)(__float_as_uint(r.rcp.x) >> 31) | ((int)(__float_as_uint(r.rcp.y) >> 31) << 1) | ((int)(__float_as_uint(r.rcp.z) >> 31) << 2);
+    const unsigned long long act = vote(r.active);
+    const int s0 = __builtin_amdgcn_readlane(sb, __ffsll((long long)act) - 1);
+    if (vote(r.active && sb != s0) == 0ull) oct = s0;
   }
+  if (oct >= 0) {
+    switch (upid) {
+      case 0: traverse_impl<ANY, 0, true>(r, nodes, tris, nt, upid, oct); return;
+      case 1: traverse_impl<ANY, 1, true>(r, nodes, tris, nt, upid, oct); return;
+      case 2: traverse_impl<ANY, 2, true>(r, nodes, tris, nt, upid, oct); return;
+      case 3: traverse_impl<ANY, 3, true>(r, nodes, tris, nt, upid, oct); return;
+      case 4: traverse_impl<ANY, 4, true>(r, nodes, tris, nt, upid, oct); return;
+      default: traverse_impl<ANY, 5, true>(r, nodes, tris, nt, upid, oct); return;
+    }
+  }
+#endif
+#if AGX_RAY_HOIST_UPID
+  switch (upid) {  // wave-uniform, once per packet: seven copies of the loop
+    case 0: traverse_impl<ANY, 0>(r, nodes, tris, nt, upid); break;
+    case 1: traverse_impl<ANY, 1>(r, nodes, tris, nt, upid); break;
+    case 2: traverse_impl<ANY, 2>(r, nodes, tris, nt, upid); break;
+    case 3: traverse_impl<ANY, 3>(r, nodes, tris, nt, upid); break;
+    case 4: traverse_impl<ANY, 4>(r, nodes, tris, nt, upid); break;
+    case 5: traverse_impl<ANY, 5>(r, nodes, tris, nt, upid); break;
+    default: traverse_impl<ANY, -1>(r, nodes, tris, nt, upid); break;
+  }
+#else
+  traverse_impl<ANY, -2>(r, nodes, tris, nt, upid);
+#endif
 }
+#endif  // AGX_RAY_WIDE
 
 struct CamArgs {
   int n, ns, width, height;
@@ -367,29 +698,36 @@ constexpr float kInvalidPixel = -1.0f;  // warp_stereo_camera_kernels.py:3
 #ifndef AGX_RAY_STEREO_WAVES
 #define AGX_RAY_STEREO_WAVES 6
 #endif
-template <bool LIDAR, int VARIANT>
+template <bool LIDAR, bool USE_LDS, int VARIANT>
 __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAVES : AGX_RAY_WAVES) k_raycast(CamArgs CA, LidarArgs LA, RangeEpilogue RL, const float *__restrict__ ray_vectors,
                                                           const float *__restrict__ sensor_pos,
                                                           const float *__restrict__ sensor_quat,
                                                           const float *__restrict__ tri_world,
                                                           const int32_t *__restrict__ tri_seg,
                                                           const float *__restrict__ nodes_g, int nt,
-                                                          float *__restrict__ pixels, int32_t *__restrict__ seg, int split) {
-  // XCD-aware workgroup -> (env, sensor, part) mapping.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs,
-  // and each XCD has its own 4 MB L2.  An (env, sensor) image is cut into `split` parts (workgroups); the parts of ONE image get
-  // ids that are 8 apart and consecutive in their XCD's queue, so they run side by side on the SAME XCD: the XCD's L2 then holds
-  // the trees of (resident workgroups / split) envs instead of one env per workgroup (127 KB each on configs[2]: 256 resident
-  // workgroups = 32 MB of trees against 4 MB of L2 when split = 1 -- every node visit an L2 miss).
+                                                          float *__restrict__ pixels, int32_t *__restrict__ seg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int env = blockIdx.x, s = blockIdx.y;
   const int ns = LIDAR ? LA.ns : CA.ns;
-  const unsigned wg = blockIdx.x, xcd = wg & 7u, q = wg >> 3;
-  const unsigned part = q % (unsigned)split, image = (q / (unsigned)split) * 8u + xcd;
-  if (image >= (unsigned)((LIDAR ? LA.n : CA.n) * ns)) return;  // (the last group of 8 images may be short)
-  const int env = (int)(image / (unsigned)ns), s = (int)(image % (unsigned)ns);
   const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
   const int mode = LIDAR ? LA.mode : CA.mode;
   const float far_plane = LIDAR ? LA.far_plane : CA.far_plane;
-  const float *nodes = nodes_g + (size_t)env * (nt - 1) * 16;  // traversed straight from L2 through wave-uniform loads
-  const float *tris = tri_world + (size_t)env * nt * 9;
+  const int n_nodes = nt - 1;
+  const float *g_nodes = nodes_g + (size_t)env * n_nodes * (AGX_RAY_WIDE ? 32 : 16);
+  const float *g_tris = tri_world + (size_t)env * nt * 9;
+  const float *nodes = g_nodes, *tris = g_tris;
+  if (USE_LDS) {
+    float *l_nodes = reinterpret_cast<float *>(smem);
+    float *l_tris = l_nodes + (size_t)n_nodes * 16;
+    // 16-byte coalesced staging (node block is 64 B aligned, triangle block 4-float padded)
+    const float4 *src = reinterpret_cast<const float4 *>(g_nodes);
+    float4 *dst = reinterpret_cast<float4 *>(l_nodes);
+    for (int i = threadIdx.x; i < n_nodes * 4; i += kRayThreads) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nt * 9; i += kRayThreads) l_tris[i] = g_tris[i];
+    __syncthreads();
+    nodes = l_nodes;
+    tris = l_tris;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t sidx = (size_t)env * ns + s;
   const V3 ro = V3{sensor_pos[sidx * 3], sensor_pos[sidx * 3 + 1], sensor_pos[sidx * 3 + 2]};
@@ -404,7 +742,8 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
   if (VARIANT == RAY_STEREO) partner = ro + wp_quat_rotate(sq, V3{-CA.baseline, 0.0f, 0.0f});
   constexpr int kTileW = Tile<LIDAR>::W, kTileH = Tile<LIDAR>::H;
   const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
-  for (int tile = (int)part * (kRayThreads / 64) + wave; tile < tiles_x * tiles_y; tile += split * (kRayThreads / 64)) {
+  // gridDim.z workgroups share the tiles of one (env, sensor): small batches still fill the GPU
+  for (int tile = blockIdx.z * (kRayThreads / 64) + wave; tile < tiles_x * tiles_y; tile += gridDim.z * (kRayThreads / 64)) {
     const int x = (tile % tiles_x) * kTileW + (lane % kTileW), y = (tile / tiles_x) * kTileH + (lane / kTileW);
     const bool active = x < width && y < height;
     V3 local = V3{0.0f, 0.0f, 1.0f};
@@ -567,31 +906,8 @@ __global__ void __launch_bounds__(256) k_image_min(int n, int ppe, const float *
   if (lane == 0) out[env] = m;
 }
 
-// How many workgroups share one (env, sensor) image.  Two rules, the larger wins:
-//   * small batches: 256 CUs x 32 waves = 8192 resident waves, and tails want ~2x that in the grid (256 envs:
-//     profiles/r01_small_batch.txt);
-//   * locality (round 4, profiles/r04_raycast_variants.txt): with the XCD-aware mapping of k_raycast the parts of an image run
-//     side by side on one XCD, so the more parts, the fewer distinct trees compete for that XCD's L2 and its CUs' scalar caches
-//     (configs[2], 8192 envs: L2 misses 9.1 M -> 4.8 M per frame, HBM read requests 8.8 M -> 4.6 M, scalar-cache hit rate 29 % ->
-//     40 %).  Measured optimum: ~4 tiles per wave for the pinhole camera (64 x 48: 3 parts, frame -8 %), ~2 for the 360-degree
-//     LiDAR whose every bundle walks the whole tree (32 x 512: 32 parts, frame -16 %).
-static int ray_split_policy(int images, int tiles, bool lidar) {
-  const int waves_per_wg = kRayThreads / 64;
-  const int fill = (16384 + images * waves_per_wg - 1) / (images * waves_per_wg);
-  const int local = tiles / (waves_per_wg * (lidar ? 2 : 4));
-  return fill > local ? fill : local;
-}
-
-// -> workgroups of the launch; *split = workgroups per image (see the kernel's mapping comment)
-static unsigned ray_launch_shape(int images, int width, int height, bool lidar, int *split_out) {
-  const int tw = lidar ? Tile<true>::W : Tile<false>::W, th = 64 / tw;
-  const int tiles = ((width + tw - 1) / tw) * ((height + th - 1) / th), waves_per_wg = kRayThreads / 64;
-  const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
-  int split = ray_split_policy(images, tiles, lidar);
-  if (const char *e = getenv("AGX_RAY_SPLIT")) split = atoi(e);  // tuning knob (profiles/raycast_split_probe.py)
-  split = split < 1 ? 1 : (split > max_split ? max_split : split);
-  *split_out = split;
-  return (((unsigned)images + 7u) / 8u) * 8u * (unsigned)split;
+static size_t ray_lds_bytes(int nt) {
+  return (size_t)(nt - 1) * 64 + (size_t)nt * 36 + 16;
 }
 
 template <bool LIDAR, int VARIANT>
@@ -604,11 +920,34 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const AgxRange
     AGX_REQUIRE((LIDAR ? LA.mode : CA.mode) <= AGX_RAY_DEPTH, "range limits are fused for scalar images only (modes RANGE / DEPTH)");
     RL = RangeEpilogue{1, limits->min_range, limits->max_range, limits->far_oor, limits->near_oor, limits->normalize};
   }
+  size_t lds = ray_lds_bytes(nt);
+#if AGX_RAY_USE_LDS
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_raycast<LIDAR, true, VARIANT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+#endif
+  // 256 CUs x 32 waves = 8192 resident waves, and tails want ~2x that in the grid: split an image's 8x8 tiles over several workgroups when the
+  // batch alone cannot provide them (256 envs: 199 -> see profiles/r01_small_batch.txt us per frame)
   const int width = LIDAR ? LA.width : CA.width, height = LIDAR ? LA.height : CA.height;
-  int split;
-  dim3 grid(ray_launch_shape(n * ns, width, height, LIDAR, &split));
-  hipLaunchKernelGGL((k_raycast<LIDAR, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, RL, ray_vectors, pos, quat, tri_world,
-                     tri_seg, nodes, nt, pixels, seg, split);
+  constexpr int kTileW = Tile<LIDAR>::W, kTileH = Tile<LIDAR>::H;
+  const int tiles = ((width + kTileW - 1) / kTileW) * ((height + kTileH - 1) / kTileH), waves_per_wg = kRayThreads / 64;
+  int split = (16384 + n * ns * waves_per_wg - 1) / (n * ns * waves_per_wg);
+  const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
+  split = split < 1 ? 1 : (split > max_split ? max_split : split);
+  dim3 grid(n, ns, AGX_RAY_USE_LDS ? 1 : split);
+#if AGX_RAY_USE_LDS  // experimental builds only: the LDS-staged kernels are not instantiated otherwise
+  if (lds <= 160 * 1024) {
+    hipLaunchKernelGGL((k_raycast<LIDAR, true, VARIANT>), grid, dim3(kRayThreads), lds, (hipStream_t)stream, CA, LA, RL, ray_vectors,
+                       pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
+    return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
+  }
+#endif
+  (void)lds;  // default: traverse from L2 with wave-uniform loads
+  hipLaunchKernelGGL((k_raycast<LIDAR, false, VARIANT>), grid, dim3(kRayThreads), 0, (hipStream_t)stream, CA, LA, RL, ray_vectors,
+                     pos, quat, tri_world, tri_seg, nodes, nt, pixels, seg);
   return check_launch(LIDAR ? "agx_raycast_lidar" : "agx_raycast_camera");
 }
 
@@ -616,13 +955,16 @@ static int launch_raycast(const CamArgs &CA, const LidarArgs &LA, const AgxRange
 
 using namespace agx;
 
-extern "C" int agx_raycast_kernel(int n, int ns, int width, int height, int lidar, int variant, char *out, int cap) {
-  AGX_REQUIRE(out && cap > 0 && n > 0 && ns > 0 && width > 0 && height > 0 && variant >= 0 && variant <= 2, "bad arguments");
-  int split;
-  const unsigned wgs = ray_launch_shape(n * ns, width, height, lidar != 0, &split);
-  snprintf(out, (size_t)cap, "k_raycast<%s,%d>_%llu", lidar ? "true" : "false", variant, (unsigned long long)wgs * kRayThreads);
-  return AGX_OK;
+#ifdef AGX_RAY_STATS
+extern "C" int agx_debug_ray_stats(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(g_ray_stats));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z));
+  }
+  return 0;
 }
+#endif
 
 extern "C" int agx_sensor_pose(const AgxEnvBuffers *B, int n, int ns, const float *local_pos, const float *local_quat,
                                const float *frame_quat, float *pos, float *quat, void *stream) {
