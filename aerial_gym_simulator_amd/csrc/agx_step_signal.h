@@ -27,10 +27,24 @@ __device__ __forceinline__ int step_index(const AgxEnvBuffers &B) {
   return B.step_counter_dev ? *B.step_counter_dev : B.step_counter;
 }
 
+// Stores into ANOTHER device's memory (a peer's receive buffer, mapped through HIP IPC and reached over xGMI): system scope,
+// write-through (`sc0 sc1`) -- the data leaves this device's L2 with the store itself instead of waiting for an end-of-kernel
+// write-back.  The arrival flags are raised by the FIRST kernel of the next step on the same stream, i.e. after this kernel
+// has drained; the runtime may order two kernels of one stream with an AGENT-scope release only (enough for this device's own
+// L2s, not a promise about lines bound for a peer), so the visibility of the rows at the peer must not depend on that release:
+// with write-through stores it depends only on the stores being complete when the kernel ends, which every release scope
+// guarantees.  (was a plain store + the assumption of a system-scope release between back-to-back kernels.)
+__device__ __forceinline__ void store_peer(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+typedef float agx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_peer4(float *p, float a, float b, float c, float d) {
+  const agx_f4v v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // One element of an exchange row.  Without peer push: a write-through store (agent scope) that the wave later waits on before the
-// launch publishes step_signal.  With peer push (AgxEnvBuffers.push_world > 0): a PLAIN store at this rank's own slice and at
-// the same offset in every peer's receive buffer (another device's memory, reached over xGMI) -- nothing waits for it inside the
-// kernel: the end of the kernel makes its stores visible at system scope, and the arrival flags are raised by the FIRST kernel
+// launch publishes step_signal.  With peer push (AgxEnvBuffers.push_world > 0): a PLAIN store at this rank's own slice (local
+// memory: made visible to the next kernel by the kernel boundary) and a system-scope write-through store at the same offset in
+// every peer's receive buffer -- nothing waits for either inside the kernel; the arrival flags are raised by the FIRST kernel
 // of the next step (push_publish_previous), which the stream runs behind this one.  (Write-through stores + an in-kernel
 // s_waitcnt + the flags at the tail of this kernel cost 4.4 us per step even with every destination in local HBM:
 // profiles/r03_exchange_experiments.txt.)
@@ -39,7 +53,7 @@ __device__ __forceinline__ void row_store(const AgxEnvBuffers &B, float *p, floa
     *p = v;
 #pragma unroll
     for (int j = 0; j < 7; ++j)
-      if (j < B.push_world - 1) *(float *)((char *)p + B.push_delta[j]) = v;
+      if (j < B.push_world - 1) store_peer((float *)((char *)p + B.push_delta[j]), v);
   } else {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -50,11 +64,10 @@ __device__ __forceinline__ void row_store(const AgxEnvBuffers &B, float *p, floa
 // quarters of a 64-byte row, the lane-quad observation kernel -- whole-line writes, and a rank with seven peers issues 8 store
 // instructions per row quarter instead of 32.  Callers check B.push_world > 0 (the other modes need the write-through stores).
 __device__ __forceinline__ void row_store4_push(const AgxEnvBuffers &B, float *p, float a, float b, float c, float d) {
-  const float4 v = make_float4(a, b, c, d);
-  *reinterpret_cast<float4 *>(p) = v;
+  *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
 #pragma unroll
   for (int j = 0; j < 7; ++j)
-    if (j < B.push_world - 1) *reinterpret_cast<float4 *>((char *)p + B.push_delta[j]) = v;
+    if (j < B.push_world - 1) store_peer4((float *)((char *)p + B.push_delta[j]), a, b, c, d);
 }
 
 // peer push: the rows of the PREVIOUS step are complete at every destination (the kernel that stored them has ended); lanes

@@ -93,7 +93,10 @@ __global__ void __launch_bounds__(256) k_action_transform(int kind, int n, const
   if (i >= n) return;
   float a[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) a[c] = fminf(fmaxf(a_in[(size_t)i * 4 + c], -1.0f), 1.0f);  // torch.clamp(action, -1, 1)
+  for (int c = 0; c < 4; ++c) {  // torch.clamp(action, -1, 1): a NaN action stays NaN (fminf / fmaxf alone would turn it into -1)
+    const float x = a_in[(size_t)i * 4 + c];
+    a[c] = (x != x) ? x : fminf(fmaxf(x, -1.0f), 1.0f);
+  }
   if (kind == AGX_ACTION_NAV_VELOCITY) {  // (speed, inclination, yaw rate) -> vehicle-frame velocity command
     const float speed = a[0] + 1.0f;
     const float inclination = 0.785398185253143310546875f * a[1];  // float(pi / 4) * a1

@@ -350,6 +350,14 @@ class EnvManager(BaseManager):
             g.on_read(key, refresh)
         for key in ("robot_actions", "robot_prev_actions"):
             g.on_read(key, refuse)
+        # A tensor reference taken from the dict BEFORE this point (or kept across steps) bypasses the hooks: the tensors the lean
+        # step no longer maintains are poisoned once, so that such a reference shows NaN instead of plausible stale numbers
+        # (the body-frame velocities stay maintained; a dict read re-fills the derived ones from the current state).
+        for key in ("robot_euler_angles", "robot_vehicle_orientation", "robot_vehicle_linvel", "robot_actions", "robot_prev_actions"):
+            t = dict.get(g, key)
+            if t is not None and t.is_floating_point():
+                t.fill_(float("nan"))
+        self._derived_stale = True
 
     def _require_device(self):
         if self._buffers is None:

@@ -115,8 +115,15 @@ class StepGather:
         self.backend = ("peer_push" if self._push else "rccl_thread") if self._native is not None else ("process_group" if self.collective else "none")
         self.lag = 1            # exchange(overlap=True) returns the rows of `lag` steps ago
         self._kernel_push = False
+        kernel_push_forced = kernel_push is True
         if kernel_push is None:
             kernel_push = obs_dim + 3 <= self.KERNEL_PUSH_MAX_ROW
+        # kernel push covers one node (8 ranks: AgxEnvBuffers.push_delta[7]) and keeps slot / sequence number in host-side kernel
+        # arguments, which a captured step graph would freeze: both cases go through the copy-kernel push instead
+        if kernel_push and (self.world > 8 or bool(getattr(env, "step_graph_mode", False))):
+            if kernel_push_forced:
+                raise ValueError("kernel_push=True needs world <= 8 and an eagerly stepped task (not hipGraph replay)")
+            kernel_push = False
         if env is not None and self._push and kernel_push and not getattr(env, "rows_written_twice_per_step", False):
             # the observation kernels store their rows at every destination themselves: nothing per step on the host, no
             # launch, no worker thread; the buffer of TWO steps ago is complete by construction when a step's kernels ran
@@ -256,12 +263,16 @@ class StepGather:
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
 
-    def close(self):
-        """Drains and frees the library-side communicator (collective-free, but call it on every rank)."""
+    def close(self, collective=True):
+        """Drains and frees the library-side exchange.  COLLECTIVE with the kernel-push path (call it on every rank: a barrier
+        keeps any rank from unmapping a buffer a peer's kernels may still be storing into); `collective=False` -- what the
+        finalizer uses -- skips the barrier: a rank that is torn down alone (garbage collection, an exception path) must
+        never enter a collective its peers will not join.  After close() the gathered buffer is gone (`self.gathered` is None:
+        every slice exchange() handed out aliased the library's allocation, which is freed here -- copy what you keep)."""
         h, self._native = self._native, None
         if h is not None and self._kernel_push:
             torch.cuda.synchronize(self.device)
-            if dist.is_initialized():
+            if collective and dist.is_initialized():
                 try:
                     dist.barrier(group=self.group)  # no rank unmaps a buffer a peer's kernels may still be storing into
                 except Exception:  # noqa: BLE001  (a peer that is already gone)
@@ -269,6 +280,9 @@ class StepGather:
             self._env.unbind_peer_push()
             self._kernel_push = False
         if h is not None:
+            if self._push:
+                self.gathered = None  # views of the library's receive buffer (freed by the next line) must fail loudly, not read freed memory
+                self._push_mem = None
             self._lib.agx_exchange_destroy(h)  # drains the communication stream
             if self.signal is not None and self._env is not None:
                 self._env.bind_step_rows(self.rows, self._env._step_rows[1], None)
@@ -276,7 +290,7 @@ class StepGather:
 
     def __del__(self):
         try:
-            self.close()
+            self.close(collective=False)
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -316,6 +330,8 @@ class StepGather:
 
             _lib.check(self._lib.agx_exchange_check(self._native), "agx_exchange_check")
         if not overlap:
+            if seq == 0:
+                return None  # nothing has been pushed yet (no step ran since the exchange was bound)
             from . import _lib
 
             _lib.check(self._lib.agx_exchange_push_wait_seq(self._native, seq & 0xFFFFFFFF, self._env._stream()), "agx_exchange_push_wait_seq")

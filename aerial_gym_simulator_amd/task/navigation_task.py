@@ -88,6 +88,7 @@ class NavigationTask(BaseTask):
 
         want = cfg.args.get("step_graph") if isinstance(cfg.args, dict) else None
         self._graph_wanted = bool(want) if want is not None else os.environ.get("AGX_STEP_GRAPH", "0") == "1"
+        self.sim_env.step_graph_mode = self._graph_wanted  # (sharding.StepGather: no kernel-side push inside a replayed graph)
         self._min_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_min_ratio])
         self._max_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_max_ratio])
         self._fuse_with_env()

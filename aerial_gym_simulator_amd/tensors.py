@@ -43,3 +43,25 @@ class TensorDict(dict):
         if key in self:
             return self[key]
         return default
+
+    # every other way of getting at the values goes through the hooks too: values() / items() / copy(), and -- because __iter__
+    # is overridden, CPython takes the keys() + __getitem__ path instead of copying the hash table -- dict(g) and **g
+    def __iter__(self):
+        return dict.__iter__(self)
+
+    def _bulk(self, key):
+        """bulk access (values / items / copy): a key whose hook REFUSES (the lean step's action history) is handed out as it is
+        stored -- NaN-poisoned by whoever installed the hook -- instead of failing the whole iteration"""
+        try:
+            return self[key]
+        except RuntimeError:
+            return dict.__getitem__(self, key)
+
+    def values(self):
+        return [self._bulk(k) for k in dict.keys(self)]
+
+    def items(self):
+        return [(k, self._bulk(k)) for k in dict.keys(self)]
+
+    def copy(self):
+        return {k: self._bulk(k) for k in dict.keys(self)}

@@ -254,3 +254,32 @@ def test_sharded_gather_world2_gloo():
     for p in procs:
         p.join(120)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_tensor_dict_hooks_cover_every_access_path():
+    """values() / items() / copy() / dict(g) / **g of the global tensor dict run the read hooks too (the lean step
+    recomputes derived tensors on read); a refusing hook fails a direct read, not a bulk one."""
+    from aerial_gym_simulator_amd.tensors import TensorDict
+
+    g = TensorDict(a=1, b=2, c=3)
+    seen = []
+    g.on_read("a", lambda k: seen.append(k))
+
+    def refuse(k):
+        raise RuntimeError("refused " + k)
+
+    g.on_read("c", refuse)
+    assert g["a"] == 1 and g.get("a") == 1 and seen == ["a", "a"]
+    del seen[:]
+    assert sorted(g.values()) == [1, 2, 3] and seen == ["a"]
+    assert dict(g.items()) == {"a": 1, "b": 2, "c": 3} and seen == ["a", "a"]
+    assert g.copy() == {"a": 1, "b": 2, "c": 3} and len(seen) == 3
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        g["c"]
+    with pytest.raises(RuntimeError):
+        dict(g)  # dict(g) / **g go through __getitem__ (no silent bypass); the refusal is loud
+    g2 = TensorDict(a=1)
+    g2.on_read("a", lambda k: seen.append("g2"))
+    assert dict(g2) == {"a": 1} and (lambda **kw: kw)(**g2) == {"a": 1} and seen[-2:] == ["g2", "g2"]

@@ -461,6 +461,16 @@ def test_builtin_action_transformations_as_one_launch():
             want = np.stack([an[:, 0] * f32(5), an[:, 1] * f32(5), an[:, 2] * f32(2.5), np.zeros(n, f32), np.zeros(n, f32),
                              np.sin(half.astype(np.float64)).astype(f32), np.cos(half.astype(np.float64)).astype(f32)], axis=1)
         assert np.array_equal(got, want.astype(f32)), (kind, np.abs(got - want).max())
+        # a NaN action (a diverged policy) stays NaN wherever torch.clamp + the torch function leave it NaN -- the fused launch
+        # must not turn it into a valid command (fminf / fmaxf alone map NaN to -1)
+        bad = a[:8].clone()
+        for c in range(4):
+            bad[2 * (c % 4):2 * (c % 4) + 2, c] = float("nan")
+        outb = torch.zeros(8, width, device=DEV)
+        _lib.check(lib.agx_action_transform(kind[0], 8, _lib.dptr(bad), _lib.dptr(outb), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        refb = cfg.action_transformation_function(bad)
+        assert torch.equal(torch.isnan(outb), torch.isnan(refb)), (kind, outb, refb)
+        assert torch.isnan(refb).any()
 
 
 def test_action_transformation_forms_agree_on_the_device():
