@@ -32,6 +32,7 @@ _FILE_EXPORTS = {
     "controller_config.lee_controller_config": {"control": "lee_controller_config"},
     "controller_config.lee_controller_config_octarotor": {"control": "lee_controller_config_octarotor"},
     "controller_config.magpie_controller_config": {"control": "magpie_controller_config"},
+    "controller_config.lmf2_controller_config": {"control": "lmf2_controller_config"},
     "controller_config.fully_actuated_controller_rov": {"control": "fully_actuated_controller_config"},
     "controller_config.no_control_config": {"control": "no_control_config"},
 }

@@ -234,6 +234,7 @@ _SIGNATURES = {
     "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
     "agx_env_step": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.POINTER(AgxTaskArgs), _P]),
     "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),
+    "agx_collide_spheres_boxes": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P]),
     "agx_controller_wrench": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, _P]),
     "agx_reward_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "agx_obs_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P]),

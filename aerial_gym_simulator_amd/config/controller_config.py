@@ -37,6 +37,17 @@ class magpie_controller_config:  # magpie_controller_config.py:4-43
     randomize_params = True
 
 
+class lmf2_controller_config:  # lmf2_controller_config.py:4-43 (K_vel z: max 1.3 < min 1.7 in the reference, kept as written)
+    num_actions = 4
+    max_inclination_angle_rad = np.pi / 3.0
+    max_yaw_rate = np.pi / 3.0
+    K_pos_tensor_max, K_pos_tensor_min = [2.0, 2.0, 1.0], [2.0, 2.0, 1.0]
+    K_vel_tensor_max, K_vel_tensor_min = [3.3, 3.3, 1.3], [2.7, 2.7, 1.7]
+    K_rot_tensor_max, K_rot_tensor_min = [1.85, 1.85, 0.4], [1.6, 1.6, 0.25]
+    K_angvel_tensor_max, K_angvel_tensor_min = [0.5, 0.5, 0.09], [0.4, 0.4, 0.075]
+    randomize_params = True
+
+
 class fully_actuated_controller_config:  # fully_actuated_controller_rov.py
     num_actions = 7
     max_inclination_angle_rad = np.pi / 3.0

@@ -287,3 +287,78 @@ class MagpieCfg:  # magpie_config.py:15-176, resources/robots/magpie/model.urdf
             max_thrust_rate = 1000000.0
             thrust_to_torque_ratio = 0.02
             use_discrete_approximation = True
+
+
+class LMF2Cfg(MagpieCfg):  # lmf2_config.py:18-180, resources/robots/lmf2/model.urdf -- the robot of the reference's default navigation recipe
+    """The reference's `navigation_task` default (navigation_task_config.py:9-10: lmf2 + lmf2_velocity_control).  Same airframe
+    layout as magpie in the URDF (base 1.2 kg + four 10 g props at (+-0.1, +-0.1, 0), fixed joints kept: 5 bodies); the
+    allocator applies the combined wrench at the root body (force_application_level "base_link": anything but "motor_link",
+    control_allocation.py:53-65).  Pinned by tests/golden/robot_lmf2.npz (composite of the reference's URDF)."""
+
+    class init_config:
+        min_init_state = [0.1, 0.15, 0.15, 0, 0, -_PI / 6, 1.0, -0.2, -0.2, -0.2, -0.2, -0.2, -0.2]
+        max_init_state = [0.2, 0.85, 0.85, 0, 0, _PI / 6, 1.0, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2]
+
+    class sensor_config:
+        enable_camera = True
+        camera_config = BaseDepthCameraConfig  # 135 x 240 depth + segmentation
+        enable_lidar = False
+        lidar_config = BaseLidarConfig
+        enable_imu = False
+        imu_config = None
+
+    class robot_model(MagpieCfg.robot_model):
+        # the URDF collision shape is a 0.5 m cube; the collision model here is a sphere of half its width (DESIGN.md "Collision")
+        collision_sphere_radius = 0.25
+
+    class control_allocator_config:
+        num_motors = 4
+        force_application_level = "base_link"
+        application_mask = [1 + 4 + i for i in range(4)]
+        motor_directions = [1, -1, 1, -1]
+        allocation_matrix = [
+            [0.0, 0.0, 0.0, 0.0],
+            [0.0, 0.0, 0.0, 0.0],
+            [1.0, 1.0, 1.0, 1.0],
+            [-0.13, -0.13, 0.13, 0.13],
+            [-0.13, 0.13, 0.13, -0.13],
+            [-0.07, 0.07, -0.07, 0.07],
+        ]
+
+        class motor_model_config:
+            use_rps = True
+            motor_thrust_constant_min, motor_thrust_constant_max = 0.00000926312, 0.00001826312
+            motor_time_constant_increasing_min, motor_time_constant_increasing_max = 0.05, 0.08
+            motor_time_constant_decreasing_min, motor_time_constant_decreasing_max = 0.005, 0.005
+            max_thrust, min_thrust = 10.0, 0.1
+            max_thrust_rate = 100000.0
+            thrust_to_torque_ratio = 0.07
+            use_discrete_approximation = True
+
+
+class LMF2With64x48CameraCfg(LMF2Cfg):
+    """lmf2 with the 64 x 48 camera of BASELINE configs[2] instead of its 135 x 240 one"""
+
+    class sensor_config(LMF2Cfg.sensor_config):
+        camera_config = DepthCamera64x48Config
+
+
+class BaseQuadRootLinkControlCfg(BaseQuadCfg):  # base_quad_root_link_control_config.py:18-53
+    """base_quadrotor with the allocator's wrench applied at the root link.  (The reference points this config at
+    resources/robots/quad/model.urdf -- the lmf2-style 1.2 kg body; the rigid-body constants here are that URDF's.)"""
+
+    class robot_asset(BaseQuadCfg.robot_asset):
+        file = "model.urdf"
+        collapse_fixed_joints = False
+
+    class robot_model(MagpieCfg.robot_model):
+        collision_sphere_radius = 0.2  # the URDF collision shape is a 0.4 m cube
+
+    class control_allocator_config(BaseQuadCfg.control_allocator_config):
+        force_application_level = "root_link"
+
+        class motor_model_config(BaseQuadCfg.control_allocator_config.motor_model_config):
+            motor_thrust_constant_min, motor_thrust_constant_max = 0.00001826312, 0.00001826312
+            motor_time_constant_increasing_min, motor_time_constant_increasing_max = 0.01, 0.03
+            motor_time_constant_decreasing_min, motor_time_constant_decreasing_max = 0.005, 0.005
+            max_thrust, min_thrust = 10, 0

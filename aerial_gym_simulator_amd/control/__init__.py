@@ -3,6 +3,7 @@ from ..config.controller_config import (
     fully_actuated_controller_config,
     lee_controller_config,
     lee_controller_config_octarotor,
+    lmf2_controller_config,
     magpie_controller_config,
     no_control_config,
 )
@@ -38,6 +39,7 @@ def register_robot_controllers(robot_name=None, controller_config=None):
 register_robot_controllers("lee", lee_controller_config)
 register_robot_controllers("octarotor", lee_controller_config_octarotor)
 register_robot_controllers("magpie", magpie_controller_config)
+register_robot_controllers("lmf2", lmf2_controller_config)  # control/__init__.py:91-93
 controller_registry.register_controller(
     "lee_velocity_steering_angle_control", LeeVelocitySteeringAngleController, lee_controller_config
 )

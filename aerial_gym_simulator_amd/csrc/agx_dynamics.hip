@@ -1218,6 +1218,27 @@ __global__ void __launch_bounds__(256) k_update_states(AgxEnvBuffers B, int n) {
   store_derived(B.derived, n, i, update_states(s));
 }
 
+// EnvManager.compute_observations (env_manager.py:358-362) on its own: crashes[i] |= the robot's collision sphere at its CURRENT
+// position overlaps an obstacle box -- the predicate of the fused step (sphere_hits_box) without a trajectory.
+__global__ void __launch_bounds__(256) k_collide_spheres_boxes(AgxEnvBuffers B, int n, float radius) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V3 p = V3{AGX_AT(B.state, 0), AGX_AT(B.state, 1), AGX_AT(B.state, 2)};
+  const float r2 = radius * radius;
+  bool hit = false;
+  for (int b = 0; b < B.num_boxes; ++b) {
+    const float *bx = B.boxes + (size_t)b * 11 * n + i;
+    const V3 c = V3{bx[0], bx[(size_t)n], bx[2 * (size_t)n]};
+    const float reach = bx[10 * (size_t)n] + radius + 1.0e-3f;  // the box's bounding radius: conservative cull, the flag is exact
+    const float dx = p.x - c.x, dy = p.y - c.y, dz = p.z - c.z;
+    if (dx * dx + dy * dy + dz * dz > reach * reach) continue;
+    const Q4 q = Q4{bx[3 * (size_t)n], bx[4 * (size_t)n], bx[5 * (size_t)n], bx[6 * (size_t)n]};
+    const V3 h = V3{bx[7 * (size_t)n], bx[8 * (size_t)n], bx[9 * (size_t)n]};
+    hit = hit || sphere_hits_box(p, c, q, h, r2);
+  }
+  if (hit) B.crashes[i] = 1;
+}
+
 __global__ void __launch_bounds__(256) k_controller_wrench(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ action) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -2018,6 +2039,13 @@ extern "C" int agx_update_states(const AgxEnvBuffers *B, int n, void *stream) {
   const int block = pick_block(n);
   hipLaunchKernelGGL(k_update_states, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *B, n);
   return check_launch("agx_update_states");
+}
+
+extern "C" int agx_collide_spheres_boxes(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, void *stream) {
+  AGX_REQUIRE(P && B && B->state && B->crashes && n > 0, "bad arguments");
+  if (!B->boxes || B->num_boxes <= 0) return AGX_OK;  // no obstacles: nothing can be hit
+  hipLaunchKernelGGL(k_collide_spheres_boxes, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, P->collision_radius);
+  return check_launch("agx_collide_spheres_boxes");
 }
 
 extern "C" int agx_controller_wrench(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *action,

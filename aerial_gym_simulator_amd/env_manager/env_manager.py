@@ -456,8 +456,22 @@ class EnvManager(BaseManager):
     def reset_robots(self, env_ids):
         self.reset_idx(env_ids)
 
-    def randomize_controller_gains(self, env_ids):
-        pass  # folded into agx_reset_masked (u_gains)
+    def randomize_controller_gains(self, env_ids=None):
+        """BaseLeeController.randomize_params(env_ids) called on its own (base_lee_controller.py:101-118): K_pos, K_linvel, K_rot,
+        K_angvel of `env_ids` re-drawn uniformly between their configured bounds, four rand draws of [len(env_ids), 3] through the
+        random source, in the reference's order (the tags of the strict reset path: gains0..3).  Inside a reset the same draw is
+        part of agx_reset_masked (u_gains / the device stream): this entry point is for callers that randomise between resets.
+        No-op unless the controller config has randomize_params (the reference returns early too)."""
+        ctrl = self.robot_manager.robot.controller
+        if not self._randomize_gains:
+            return
+        ids = torch.arange(self.num_envs, device=self.device) if env_ids is None else torch.as_tensor(env_ids, device=self.device, dtype=torch.long)
+        if ids.numel() == 0:
+            return
+        lo, hi = torch.tensor(ctrl.gains_min, device=self.device), torch.tensor(ctrl.gains_max, device=self.device)
+        for k, cur in enumerate((ctrl.K_pos_tensor_current, ctrl.K_linvel_tensor_current, ctrl.K_rot_tensor_current, ctrl.K_angvel_tensor_current)):
+            u = self.random_source.rand(int(ids.numel()), 3, tag="gains%d" % k)
+            cur[ids] = (hi[3 * k:3 * k + 3] - lo[3 * k:3 * k + 3]) * u + lo[3 * k:3 * k + 3]  # torch_rand_float_tensor: (upper - lower) * rand + lower
 
     def reset(self):
         self.reset_idx(torch.arange(self.num_envs, device=self.device))
@@ -588,7 +602,11 @@ class EnvManager(BaseManager):
         self.step_counter += 1
 
     def compute_observations(self):
-        pass  # the collision flag is accumulated inside agx_dynamics_substeps
+        """env_manager.py:358-362: collision_tensor |= contact.  The fused step (step / simulate) has already accumulated the flag
+        over its sub-step positions; this is the stand-alone form for callers that drive simulate() and compute_observations()
+        themselves (same predicate on the current position: calling it after a fused step changes nothing)."""
+        self._require_device()
+        _lib.check(self._lib.agx_collide_spheres_boxes(self._params, self._buffers, self.num_envs, self._stream()), "agx_collide_spheres_boxes")
 
     @roctx.ranged("EnvManager.post_reward_calculation_step")
     def post_reward_calculation_step(self):

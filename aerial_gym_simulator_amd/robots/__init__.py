@@ -3,6 +3,7 @@ from ..config.robot_config import (
     BaseOctarotorCfg,
     BaseOctarotorWithLidar32x512Cfg,
     BaseQuadCfg,
+    BaseQuadRootLinkControlCfg,
     BaseQuadWithCamera64x48Cfg,
     BaseQuadWithCameraCfg,
     BaseQuadWithCameraImuCfg,
@@ -10,6 +11,8 @@ from ..config.robot_config import (
     BaseQuadWithFaceIDNormalCameraCfg,
     BaseQuadWithLidarCfg,
     BaseQuadWithStereoCameraCfg,
+    LMF2Cfg,
+    LMF2With64x48CameraCfg,
     MagpieCfg,
 )
 from ..registry.robot_registry import robot_registry
@@ -26,3 +29,6 @@ robot_registry.register("base_quadrotor_with_stereo_camera", BaseMultirotor, Bas
 robot_registry.register("magpie", BaseMultirotor, MagpieCfg)
 robot_registry.register("base_quadrotor_with_imu", BaseMultirotor, BaseQuadWithImuCfg)
 robot_registry.register("base_quadrotor_with_camera_imu", BaseMultirotor, BaseQuadWithCameraImuCfg)
+robot_registry.register("lmf2", BaseMultirotor, LMF2Cfg)
+robot_registry.register("lmf2_with_camera_64x48", BaseMultirotor, LMF2With64x48CameraCfg)
+robot_registry.register("base_quad_root_link_control", BaseMultirotor, BaseQuadRootLinkControlCfg)

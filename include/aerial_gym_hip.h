@@ -244,6 +244,12 @@ int agx_env_step(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num
 int agx_env_step_kernel(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, int k_substeps,
                         const AgxTaskArgs *task, char *out, int out_capacity);
 
+/* EnvManager.compute_observations alone (env_manager.py:358-362; SURVEY 8b's minimum export set): crashes[i] |= the robot's
+ * collision sphere (params->collision_radius) at its CURRENT position overlaps one of the env's obstacle boxes (buf->boxes,
+ * the layout agx_boxes_from_assets writes).  The fused step accumulates the same predicate over its sub-step positions; this
+ * entry point is for callers that drive simulate() / compute_observations() themselves.  No boxes bound: no-op.            */
+int agx_collide_spheres_boxes(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, void *stream);
+
 /* BaseMultirotor.update_states alone (base_multirotor.py:287-294). */
 int agx_update_states(const AgxEnvBuffers *buf, int num_envs, void *stream);
 

@@ -45,6 +45,31 @@ def magpie_constants(cfg):
                 motor_pos=np.array([links[p]["xyz"] for p in props]), collision_radius=np.float64(0.35))
 
 
+def root_mode_constants(folder, cfg, collision_radius):
+    """composite rigid body of resources/robots/<folder>/model.urdf + the config's allocation matrix (root-link allocators)"""
+    links = gg.parse_urdf(os.path.join(ref_shells.REFERENCE_ROOT, "resources", "robots", folder, "model.urdf"))
+    mass, com, J = gg.composite(links)
+    props = [n for n in links if n != "base_link"]
+    ca = cfg.control_allocator_config
+    mm = ca.motor_model_config
+    return dict(mass=np.float64(mass), com=com, inertia=J, alloc=np.array(ca.allocation_matrix, np.float64),
+                base_mass=np.float64(links["base_link"]["mass"]), base_inertia=links["base_link"]["inertia"],
+                motor_mass=np.float64(links[props[0]]["mass"]), motor_pos=np.array([links[p]["xyz"] for p in props]),
+                collision_radius=np.float64(collision_radius), force_application_level=np.array(ca.force_application_level),
+                motor_model=np.array([mm.motor_thrust_constant_min, mm.motor_thrust_constant_max, mm.motor_time_constant_increasing_min,
+                                      mm.motor_time_constant_increasing_max, mm.motor_time_constant_decreasing_min,
+                                      mm.motor_time_constant_decreasing_max, mm.max_thrust, mm.min_thrust, mm.max_thrust_rate,
+                                      mm.thrust_to_torque_ratio], np.float64),
+                min_init_state=np.array(cfg.init_config.min_init_state, np.float64), max_init_state=np.array(cfg.init_config.max_init_state, np.float64),
+                disturbance=np.array([float(cfg.disturbance.enable_disturbance), cfg.disturbance.prob_apply_disturbance]
+                                     + list(cfg.disturbance.max_force_and_torque_disturbance), np.float64))
+
+
+def controller_gain_table(ctrl):
+    return np.array([ctrl.K_pos_tensor_min, ctrl.K_pos_tensor_max, ctrl.K_vel_tensor_min, ctrl.K_vel_tensor_max, ctrl.K_rot_tensor_min,
+                     ctrl.K_rot_tensor_max, ctrl.K_angvel_tensor_min, ctrl.K_angvel_tensor_max], np.float64)
+
+
 def gen_step_root_mode(cfg, consts, n=64, K=6, seed=11):
     """gen_golden.gen_step for a robot whose allocator applies the combined wrench at the root body."""
     rng = torch.Generator().manual_seed(seed)
@@ -220,6 +245,13 @@ def main():
     np.savez(os.path.join(OUT, "robot_magpie.npz"), **consts)
     print("magpie mass", consts["mass"], "J diag", np.diag(consts["inertia"]), "com", consts["com"])
     gen_step_root_mode(MagpieCfg, consts)
+    # the robot / controller of the reference's DEFAULT navigation recipe (navigation_task_config.py:9-10) and the root-link quad
+    LMF2Cfg = ref_shells.ref("config.robot_config.lmf2_config").LMF2Cfg
+    lmf2_ctrl = ref_shells.ref("config.controller_config.lmf2_controller_config").control
+    np.savez(os.path.join(OUT, "robot_lmf2.npz"), gains=controller_gain_table(lmf2_ctrl), randomize_params=np.array(lmf2_ctrl.randomize_params),
+             **root_mode_constants("lmf2", LMF2Cfg, 0.25))
+    RootCfg = ref_shells.ref("config.robot_config.base_quad_root_link_control_config").BaseQuadRootLinkControlCfg
+    np.savez(os.path.join(OUT, "robot_base_quad_root_link_control.npz"), **root_mode_constants("quad", RootCfg, 0.2))
     lt = ref_shells.ref("task.lidar_navigation_task.lidar_navigation_task")
     gen_reward(rng, lt, cfg)
     gen_image_obs(rng, lt)

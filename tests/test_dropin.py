@@ -195,8 +195,14 @@ def test_per_file_config_module_paths_of_the_reference_resolve(monkeypatch):
     assert isinstance(tc.position_setpoint_task_config, type)  # not replaced by the per-file module of the same name
     for name in ("base_sim", "base_sim_headless", "base_sim_2ms", "base_sim_4ms"):  # aerial_gym/sim/__init__.py:13-16
         assert sim_config_registry.get_sim_config(name) is not None
+    from aerial_gym.config.controller_config.lmf2_controller_config import control as lmf2_control  # the default navigation recipe's
+    from aerial_gym.config.robot_config.lmf2_config import LMF2Cfg                                   # robot and controller
+
+    import aerial_gym_simulator_amd.config.robot_config as rc
+
+    assert LMF2Cfg is rc.LMF2Cfg and lmf2_control is cc.lmf2_controller_config
     with pytest.raises(ImportError):  # a robot this repo does not build: fails loudly, no empty stand-in
-        from aerial_gym.config.robot_config.lmf2_config import LMF2Cfg  # noqa: F401
+        from aerial_gym.config.robot_config.x500_config import X500Cfg  # noqa: F401
     with pytest.raises(ModuleNotFoundError):
         importlib.import_module("aerial_gym.config.sim_config.not_a_reference_file")
     # aliasing leaves the implementation modules' identity alone (importlib.reload / pkgutil / inspect keep working)

@@ -186,6 +186,20 @@ def test_collision_flags_bit_exact(orc):
     orc.collide_sphere_boxes(pd["collision_radius"], H.get("state"), boxes, crashes)
     assert np.array_equal(got, crashes.astype(bool))
     assert 0.1 < crashes.mean() < 0.9
+    # the stand-alone entry point (EnvManager.compute_observations, env_manager.py:358-362): OR-accumulates from the current state
+    from aerial_gym_simulator_amd import _lib
+
+    state2 = H.get("state").copy()
+    state2[:, 0:3] = rng.uniform(-2, 2, (n, 3))
+    H.set(state=state2)
+    pre = (rng.random(n) < 0.2)
+    H.crashes.copy_(torch.from_numpy(pre).to(H.crashes.dtype))
+    _lib.check(H.lib.agx_collide_spheres_boxes(H.P, H.B, n, H.stream()))
+    torch.cuda.synchronize()
+    want = pre.astype(np.uint8)
+    orc.collide_sphere_boxes(pd["collision_radius"], state2, boxes, want)
+    assert np.array_equal(H.crashes.cpu().numpy().astype(bool), want.astype(bool))
+    assert (want.astype(bool) & ~pre).any() and (pre & want.astype(bool)).any()  # new hits and kept flags
 
 
 def test_reward_obs_position(orc):

@@ -162,6 +162,45 @@ def test_magpie_robot_model_matches_urdf():
     assert np.array_equal(np.array(MagpieCfg.control_allocator_config.allocation_matrix), r["alloc"])
 
 
+@pytest.mark.parametrize("name,cfg_name,ctrl_name", [("lmf2", "LMF2Cfg", "lmf2_controller_config"),
+                                                    ("base_quad_root_link_control", "BaseQuadRootLinkControlCfg", None)])
+def test_root_link_robot_configs_match_the_reference(name, cfg_name, ctrl_name):
+    """lmf2 (the robot of the reference's default navigation recipe, navigation_task_config.py:9-10) and
+    base_quad_root_link_control as config data: rigid-body constants == composite of the reference's URDF, allocation matrix,
+    motor model, init state, disturbance and controller gain ranges == the reference's config classes (tests/golden/robot_*.npz,
+    written by oracle/gen_golden_lidar_nav.py from /root/reference)."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import controller_config, robot_config
+    from aerial_gym_simulator_amd.registry.controller_registry import controller_registry
+    from aerial_gym_simulator_amd.registry.robot_registry import robot_registry
+    from aerial_gym_simulator_amd.robots.robot_model import composite_body
+
+    r = load_golden("robot_" + name)
+    cfg = getattr(robot_config, cfg_name)
+    mass, com, J = composite_body(cfg.robot_model)
+    assert abs(mass - r["mass"]) < 1e-12 and np.abs(com - r["com"]).max() < 1e-12 and np.abs(J - r["inertia"]).max() < 1e-12
+    ca, mm = cfg.control_allocator_config, cfg.control_allocator_config.motor_model_config
+    assert np.array_equal(np.array(ca.allocation_matrix, np.float64), r["alloc"])
+    assert ca.force_application_level == str(r["force_application_level"]) != "motor_link"
+    assert abs(cfg.robot_model.collision_sphere_radius - float(r["collision_radius"])) < 1e-12
+    got = [mm.motor_thrust_constant_min, mm.motor_thrust_constant_max, mm.motor_time_constant_increasing_min, mm.motor_time_constant_increasing_max,
+           mm.motor_time_constant_decreasing_min, mm.motor_time_constant_decreasing_max, mm.max_thrust, mm.min_thrust, mm.max_thrust_rate,
+           mm.thrust_to_torque_ratio]
+    assert np.array_equal(np.array(got, np.float64), r["motor_model"])
+    assert np.array_equal(np.array(cfg.init_config.min_init_state, np.float64), r["min_init_state"])
+    assert np.array_equal(np.array(cfg.init_config.max_init_state, np.float64), r["max_init_state"])
+    d = cfg.disturbance
+    assert np.array_equal(np.array([float(d.enable_disturbance), d.prob_apply_disturbance] + list(d.max_force_and_torque_disturbance), np.float64), r["disturbance"])
+    assert robot_registry.get_robot_config(name) is cfg
+    if ctrl_name:
+        c = getattr(controller_config, ctrl_name)
+        table = np.array([c.K_pos_tensor_min, c.K_pos_tensor_max, c.K_vel_tensor_min, c.K_vel_tensor_max, c.K_rot_tensor_min, c.K_rot_tensor_max,
+                          c.K_angvel_tensor_min, c.K_angvel_tensor_max], np.float64)
+        assert np.array_equal(table, r["gains"]) and bool(c.randomize_params) == bool(r["randomize_params"])
+        for kind in ("position", "velocity", "attitude", "rates", "acceleration"):  # control/__init__.py:91-93
+            assert controller_registry.get_controller_config(f"lmf2_{kind}_control") is c
+
+
 def test_magpie_root_link_substep_matches_reference(orc):
     """BaseMultirotor.step with force_application_level = "base_link": the allocator's wrench A u is
     applied to the root body (base_multirotor.py:152-159, control_allocation.py:53-79)."""
