@@ -31,6 +31,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 #   fused: k_env_step moves 152 + 4 (reward) + 2 (flags) = 158 B, k_reset_masked<.., obs> the 52 B observation
 BYTES_DYNAMICS_KERNEL = 158
 BYTES_ENV_STEP = 210
+# the reset / observation launch on its own (kernel view): reads 13 state + 6 body-frame velocity + 3 target floats + 3 flag bytes,
+# writes the 13-float observation: 4 * (13 + 6 + 3 + 13) + 3 = 143 B per env (52 of them are the step's algorithmic observation bytes)
+BYTES_RESET_OBS_KERNEL = 143
 
 
 def parse():
@@ -38,6 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--regions", type=int, default=5, help="timed regions of --steps steps each; `value` is their median")
     ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default: 8192; 4096 for the LiDAR workloads, BASELINE configs[3])")
     ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar", "lidar_velocity", "lidar_nav"])
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
@@ -221,7 +225,7 @@ def valu_roofline(kernel_key, launch_s):
                 valu_wave_instructions_per_launch=n_valu, stale=pmc_stale())
 
 
-def roofline_block(kernel, launch_s, algorithmic_bytes, key, copy_gbs=None, timing=None, note=None, **extra):
+def roofline_block(kernel, launch_s, algorithmic_bytes, key, copy_gbs=None, timing=None, note=None, bound="hbm", **extra):
     """The contract's `roofline` object for one kernel: bound "hbm" -- achieved = algorithmic bytes per launch / average launch
     duration measured live with HIP events on the launch stream, peak = 8 TB/s (specification), traffic = HBM bytes per launch
     from the committed PMC passes -- with the achievable copy rate of this box and the kernel's vector-instruction issue rate
@@ -245,6 +249,18 @@ def roofline_block(kernel, launch_s, algorithmic_bytes, key, copy_gbs=None, timi
     if note:
         blk["note"] = note
     blk.update(extra)
+    if bound == "valu" and blk["valu"].get("achieved") is not None:
+        # the bound that BINDS this kernel is vector-instruction issue, not HBM: the object's headline numbers are the VALU ones
+        # (instructions per launch from the committed PMC pass over the live launch time, against the guide's issue ceiling);
+        # the byte view stays next to it under "hbm"
+        v = blk["valu"]
+        hbm = {k: blk[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch",
+                                   "traffic_over_algorithmic", "traffic_rate_gbs", "peak_measured_copy", "frac_of_measured_copy",
+                                   "traffic_rate_over_measured_copy") if k in blk}
+        blk.update(bound="valu", achieved=v["achieved"], peak=v["peak_guide"], unit=v["unit"], frac=v["frac_of_guide"],
+                   frac_of_measured_peak=v["frac_of_measured"], counters_stale=v.get("stale"), hbm=hbm)
+    elif bound == "valu":
+        blk["bound_note"] = "vector-issue bound by design; no instruction count for this kernel instance in profiles/pmc_traffic.json, the byte view is shown"
     return blk
 
 
@@ -275,15 +291,31 @@ def raycast_key(task):
 
 
 def cpu_baseline_reference():
-    """The reference's own torch CPU path (oracle/time_reference_cpu.py), timed where the reference tree exists."""
-    try:
-        path = os.path.join(ROOT, "profiles", "r03_cpu_baseline_reference.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r02_cpu_baseline_reference.json")
-        d = json.load(open(path))
-        return {k: d[k] for k in ("value", "unit", "cores", "kind", "sample", "host", "cpu_model", "what")}
-    except Exception:  # noqa: BLE001
-        return None
+    """The reference's own torch CPU path (oracle/time_reference_cpu.py).  Where the reference tree is present on THIS box
+    (AERIAL_GYM_REFERENCE_ROOT, default /root/reference) it is timed here and now, on this box's host cores -- the comparison
+    north_star names; otherwise the committed measurement of the build container is echoed (its `host` field says so)."""
+    root = os.environ.get("AERIAL_GYM_REFERENCE_ROOT", "/root/reference")
+    keys = ("value", "unit", "cores", "kind", "sample", "host", "cpu_model", "what")
+    if os.path.isdir(os.path.join(root, "aerial_gym")):
+        import subprocess
+        import tempfile
+
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                dst = os.path.join(tmp, "ref.json")
+                subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference_cpu.py"), "--out", dst, "--seconds", "12",
+                                "--host", "this box (the bench host's cores)"], check=True, capture_output=True, timeout=300)
+                d = json.load(open(dst))
+            return dict({k: d[k] for k in keys}, measured_here=True)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] the reference tree is present but could not be timed ({type(e).__name__}: {e})", file=sys.stderr)
+    for name in ("r04_cpu_baseline_reference.json", "r03_cpu_baseline_reference.json", "r02_cpu_baseline_reference.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return dict({k: d[k] for k in keys}, measured_here=False, source="profiles/" + name)
+        except Exception:  # noqa: BLE001
+            continue
+    return None
 
 
 def live_parity(device):
@@ -384,8 +416,9 @@ def kernel_time_dynamics(task, actions, reps=400):
     # its env-step call is wrapped so that every launch sits between two events
     m = min(reps, 300)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
-    real_env_step = lib.agx_env_step
-    idx = [0]
+    evs2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
+    real_env_step, real_post = lib.agx_env_step, lib.agx_post_step_position
+    idx, idx2 = [0], [0]
 
     class _Timed:
         def __getattr__(self, name):
@@ -397,6 +430,14 @@ def kernel_time_dynamics(task, actions, reps=400):
             rc = real_env_step(*args)
             e1.record()
             idx[0] += 1
+            return rc
+
+        def agx_post_step_position(self, *args):  # the step's second launch: reset of the flagged envs + observation (+ exchange rows)
+            e0, e1 = evs2[idx2[0]]
+            e0.record()
+            rc = real_post(*args)
+            e1.record()
+            idx2[0] += 1
             return rc
 
     plan, task._plan = getattr(task, "_plan", None), None  # general path: env.step + reward + post_reward_calculation_step
@@ -417,6 +458,13 @@ def kernel_time_dynamics(task, actions, reps=400):
         out["in_step_min"], out["in_step_median"], out["in_step_max"] = d[0] * 1e-3, d[len(d) // 2] * 1e-3, d[-1] * 1e-3
         out["in_step_samples"] = len(d)
     out["primary"] = out.get("in_step", out["back_to_back"])
+    d2 = sorted(e0.elapsed_time(e1) for e0, e1 in evs2[: idx2[0]])
+    post = None
+    if d2:
+        post = {"in_step": sum(d2) / len(d2) * 1e-3, "in_step_min": d2[0] * 1e-3, "in_step_median": d2[len(d2) // 2] * 1e-3,
+                "in_step_max": d2[-1] * 1e-3, "in_step_samples": len(d2), "event_pair": out["event_pair"]}
+        post["primary"] = post["in_step"]
+    out["_post_step"] = post
     return out, k
 
 
@@ -774,7 +822,13 @@ def main():
               file=sys.stderr, flush=True)
         if comm_ranks != max(world, 1) or comm_rank != rank:
             raise SystemExit(f"the step exchange's communicator reports rank {comm_rank} of {comm_ranks}; the job is rank {rank} of {world}")
-    dt = timed_steps(task, actions, args.steps, args.warmup, world, gather_buf, overlap=not args.sync_gather)
+    # `value` = the MEDIAN of `--regions` timed regions of exactly `--steps` steps each (each bracketed by barrier + device
+    # synchronize, maximum over ranks); minimum and maximum are reported next to it.  One region of the driver's 20 steps lasts
+    # 0.25 ms: a single scheduler hiccup is +-30 % of it.
+    dts = [timed_steps(task, actions, args.steps, args.warmup if r == 0 else 0, world, gather_buf, overlap=not args.sync_gather)
+           for r in range(max(1, args.regions))]
+    dts_sorted = sorted(dts)
+    dt = dts_sorted[len(dts_sorted) // 2]
     value = n_gpus * N * args.steps / dt
     exchange = exchange_diagnostics(task, actions, args, world, gather_buf, dt) if use_dist else None
     out = {
@@ -785,6 +839,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
+        "timed_regions": {"count": len(dts), "steps_each": args.steps, "value_is": "median",
+                          "ms_per_step": [1e3 * x / args.steps for x in dts],
+                          "value_min": n_gpus * N * args.steps / dts_sorted[-1], "value_max": n_gpus * N * args.steps / dts_sorted[0]},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -807,12 +864,28 @@ def main():
     copy_gbs = hbm_copy_gbs(device) if rank == 0 else None
     if rank == 0 and args.workload == "dynamics":
         timing, k = kernel_time_dynamics(task, actions)
+        post_timing = timing.pop("_post_step", None)
         ekey = env_step_key(task, k)
         out["roofline"] = roofline_block(
             ekey.rsplit("_", 1)[0] + " (sub-step(s) + reward epilogue)", timing["primary"], BYTES_DYNAMICS_KERNEL * k * N, ekey, copy_gbs, timing,
             note="8192 envs = 512 one-wave workgroups on 1024 SIMDs, 1.3 MB per launch: neither HBM nor the vector ALUs can be filled, the "
                  "launch is latency bound (one wave's instruction stream + two memory round trips); roofline_at_scale prices the "
                  "one-lane-per-env kernel at 2^21 envs")
+    if rank == 0 and args.workload == "dynamics" and post_timing:
+        post = post_timing
+        out["roofline_reset_obs"] = roofline_block(
+            "k_reset_masked_quad_obs (reset of the flagged envs + observation: the step's second launch)", post["primary"],
+            BYTES_RESET_OBS_KERNEL * N, "k_reset_masked_quad_obs_%d" % (4 * N), copy_gbs, post,
+            note="per env: 52 B state + 24 B body-frame velocities + 12 B target + 3 flag bytes read, 52 B observation written "
+                 "(+ a 64 B exchange row per destination when a step exchange is bound: not in this run); the reset branch moves "
+                 "nothing on a step without resets.  Latency bound like the env-step launch (512 waves, one dependent chain).")
+        out["roofline_step"] = {"launches": 2, "kernel_us_sum": (timing["primary"] + post["primary"]) * 1e6,
+                                "share_env_step": timing["primary"] / (timing["primary"] + post["primary"]),
+                                "share_reset_obs": post["primary"] / (timing["primary"] + post["primary"]),
+                                "algorithmic_bytes_per_step": BYTES_ENV_STEP * N,
+                                "achieved_gbs_over_kernel_time": BYTES_ENV_STEP * N / (timing["primary"] + post["primary"]) / 1e9,
+                                "achieved_gbs_over_step_time": BYTES_ENV_STEP * N / (dt / args.steps) / 1e9,
+                                "frac_over_step_time": BYTES_ENV_STEP * N / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
     if exchange is not None:
         exchange["communicator_ranks"] = exchange["ranks_seen"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
         exchange["backend_of_first_leg"] = gather_buf.backend
@@ -822,7 +895,7 @@ def main():
         kt = kernel_time_raycast(task)
         cfgs = task.sim_env.robot_manager.warp_sensor.cfg
         out["roofline"] = roofline_block(
-            "k_raycast (one frame, all envs)", kt, raycast_bytes_per_env(task) * N, raycast_key(task), copy_gbs,
+            "k_raycast (one frame, all envs)", kt, raycast_bytes_per_env(task) * N, raycast_key(task), copy_gbs, bound="valu",
             note="packet traversal is bound by vector-instruction issue, not by HBM: the scene (127 KB/env) is read once per frame",
             rays_per_s=N * cfgs.num_sensors * cfgs.height * cfgs.width / kt)
     if rank == 0 and args.workload == "dynamics" and world == 1:
@@ -835,6 +908,7 @@ def main():
             for _ in range(3):
                 big.step(ab[0])
             timing2, k2 = kernel_time_dynamics(big, ab, reps=30)
+            timing2.pop("_post_step", None)
             ekey2 = env_step_key(big, k2)
             out["roofline_at_scale"] = roofline_block(
                 ekey2.rsplit("_", 1)[0], timing2["primary"], BYTES_DYNAMICS_KERNEL * k2 * (1 << 21), ekey2, copy_gbs, timing2,
@@ -853,6 +927,7 @@ def main():
             for _ in range(3):
                 big.step(ab[0])
             timing3, k3 = kernel_time_dynamics(big, ab, reps=30)
+            timing3.pop("_post_step", None)
             ekey3 = env_step_key(big, k3)
             out["roofline_at_scale_lean"] = roofline_block(
                 ekey3.rsplit("_", 1)[0] + " with AGX_LAUNCH_LEAN", timing3["primary"], BYTES_DYNAMICS_KERNEL * k3 * nl, ekey3, copy_gbs, timing3,
@@ -863,10 +938,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["roofline_at_scale"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "dynamics":
-        out["cpu_baseline"] = cpu_baseline_dynamics(N)
+        port = cpu_baseline_dynamics(N)
         ref = cpu_baseline_reference()
-        if ref is not None:
-            out["cpu_baseline_reference"] = ref
+        if ref is not None and ref.get("measured_here"):  # the reference itself, on this box's cores: THE cpu baseline
+            out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
+        else:
+            out["cpu_baseline"] = port
+            if ref is not None:
+                out["cpu_baseline_reference"] = ref
     if rank == 0 and world == 1 and args.workload == "dynamics":
         try:
             out["parity"] = live_parity(device)
@@ -892,10 +971,12 @@ def main():
         if use_dist:
             gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards,
                              backend=primary_backend)
-        dt2 = timed_steps(t2, a2, s2, max(args.warmup // 10, 5), world, gb2, overlap=not args.sync_gather)
+        dts2 = sorted(timed_steps(t2, a2, s2, max(args.warmup // 10, 5) if r == 0 else 0, world, gb2, overlap=not args.sync_gather)
+                      for r in range(max(1, min(args.regions, 3))))
+        dt2 = dts2[len(dts2) // 2]
         if rank == 0:
             out["plus_depth"] = {"value": n_gpus * N * s2 / dt2, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": s2,
-                                 "ms_per_step": 1e3 * dt2 / s2,
+                                 "ms_per_step": 1e3 * dt2 / s2, "timed_regions_ms_per_step": [1e3 * x / s2 for x in dts2],
                                  "workload": "navigation_task, 8192 envs per GPU, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step"
                                              + (" (BASELINE configs[4] sharding, 1 all_gather/step)" if world > 1 else "")}
         if rank == 0 and world == 1:
@@ -903,7 +984,9 @@ def main():
             per_env = raycast_bytes_per_env(t2)
             out["plus_depth"].update({
                 "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                "raycast_roofline": roofline_block("k_raycast (one frame, all envs)", kt2, per_env * N, raycast_key(t2), copy_gbs)})
+                "raycast_roofline": roofline_block("k_raycast (one frame, all envs)", kt2, per_env * N, raycast_key(t2), copy_gbs, bound="valu",
+                                                   note="packet traversal: bound by vector-instruction issue and by the latency of its dependent "
+                                                        "node fetches (profiles/r04_raycast_variants.txt), not by HBM bytes")})
             if not args.no_cpu_baseline:
                 out["plus_depth"]["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
                 out["plus_depth"]["gpu_frames_per_s_kernel"] = N / kt2

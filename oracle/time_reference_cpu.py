@@ -5,7 +5,8 @@ BaseMultirotor.step (update_states, clip, Lee position controller, allocation, m
 robots/base_multirotor.py:296-307 + control/**), the oracle's rigid-body integrator in place of Isaac Gym's CPU
 PhysX (not installable), and the reference's compute_reward (position_setpoint_task.py:245-282) for BASELINE
 configs[0] (64 envs) and configs[1] (8192 envs), torch.set_num_threads(nproc).  /root/reference exists only here, so the
-result is written to profiles/r03_cpu_baseline_reference.json and echoed by bench.py (`cpu_baseline_reference`).
+result is written to profiles/r04_cpu_baseline_reference.json and echoed by bench.py (`cpu_baseline_reference`); where the
+reference tree IS present on the bench box (AERIAL_GYM_REFERENCE_ROOT), bench.py runs this script there and reports it as `cpu_baseline`.
 
     python oracle/time_reference_cpu.py
 """
@@ -70,6 +71,13 @@ def run(n, seconds, consts):
 
 
 def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "profiles", "r04_cpu_baseline_reference.json"))
+    ap.add_argument("--host", default="build container (the reference tree is not on the GPU box)")
+    ap.add_argument("--seconds", type=float, default=15.0, help="budget of the 8192-env leg (the 64-env leg gets half)")
+    args = ap.parse_args()
     ref_shells.install()
     from aerial_gym.config.robot_config.base_quad_config import BaseQuadCfg
 
@@ -80,18 +88,17 @@ def main():
         "kind": "reference",
         "unit": "env-steps/s",
         "cores": threads,
-        "host": "build container (the reference tree is not on the GPU box)",
+        "host": args.host,
         "cpu_model": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"),
         "what": "reference BaseMultirotor.step + Lee position controller + allocation + motor model (torch %s, %d threads) + "
                 "restated rigid-body integrator (Isaac Gym's CPU PhysX is not installable) + reference compute_reward; no reset, "
                 "no observation packing" % (torch.__version__, threads),
-        "configs": {"configs[0] 64 envs": run(64, 8.0, consts), "configs[1] 8192 envs": run(8192, 15.0, consts)},
+        "configs": {"configs[0] 64 envs": run(64, args.seconds / 2, consts), "configs[1] 8192 envs": run(8192, args.seconds, consts)},
     }
     out["value"] = out["configs"]["configs[1] 8192 envs"]["value"]
     out["sample"] = "%d env steps of 8192 envs (%.1f s)" % (out["configs"]["configs[1] 8192 envs"]["steps"],
                                                            out["configs"]["configs[1] 8192 envs"]["seconds"])
-    dst = os.path.join(os.path.dirname(HERE), "profiles", "r03_cpu_baseline_reference.json")
-    json.dump(out, open(dst, "w"), indent=1)
+    json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -31,7 +31,9 @@ def load(path, counter):
             m = re.search(r"k_raycast<([^>]*)>", name)  # <lidar, variant>
             key = ("k_raycast<%s>" % m.group(1).replace(" ", "") if m else "k_raycast", int(r["Grid_Size"]))
         elif "k_reset_masked" in name:
-            key = ("k_reset_masked", int(r["Grid_Size"]))
+            import re
+
+            key = (re.search(r"k_reset_masked\w*", name).group(0), int(r["Grid_Size"]))  # k_reset_masked<..> | k_reset_masked_quad_obs
         if key:
             acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
@@ -100,7 +102,7 @@ def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None):
                               "write_true_bytes": wr_true, "write_correction": cw}
     else:
         cf = cw = 1.0
-    for (name, grid) in sorted(k for k in fetch if k[0].startswith("k_env_step")):
+    for (name, grid) in sorted(k for k in fetch if k[0].startswith(("k_env_step", "k_reset_masked"))):
         tag = "%s_%d" % (name, grid)
         if (name, grid) in fetch and (name, grid) in write:
             raw = fetch[(name, grid)] * KB + write[(name, grid)] * KB
