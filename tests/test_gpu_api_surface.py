@@ -23,7 +23,7 @@ def test_reference_default_navigation_recipe_builds_by_name_and_steps():
         task = task_registry.make_task("navigation_task", seed=2, num_envs=n, headless=True)
         env = task.sim_env
         robot = env.robot_manager.robot
-        assert robot.params_dict["root_link_mode"] == 1 and abs(robot.params_dict["mass"] - 1.24) < 1e-9
+        assert robot.params_dict["root_link_mode"] == 1 and abs(robot.params_dict["mass"] - 1.24) < 1e-6
         sensor = env.robot_manager.warp_sensor
         assert (sensor.cfg.height, sensor.cfg.width) == (135, 240)
         ctrl = robot.controller
@@ -31,8 +31,10 @@ def test_reference_default_navigation_recipe_builds_by_name_and_steps():
         task.reset()
         g = env.global_tensor_dict
         z0 = g["robot_position"][:, 2].clone()
+        ever_reset = torch.zeros(n, dtype=torch.bool, device=DEV)
         for _ in range(8):
             obs, rew, term, trunc, info = task.step(torch.zeros(n, 4, device=DEV))  # speed 1 m/s forward, level, no yaw rate
+            ever_reset |= term | trunc
         torch.cuda.synchronize()
         assert obs["observations"].shape == (n, cfg.observation_space_dim) and torch.isfinite(obs["observations"]).all()
         assert torch.isfinite(rew).all() and torch.isfinite(g["robot_state_tensor"]).all()
@@ -42,8 +44,8 @@ def test_reference_default_navigation_recipe_builds_by_name_and_steps():
         kr = ctrl.K_rot_tensor_current.cpu().numpy()
         assert kr[:, 0].min() >= 1.6 - 1e-6 and kr[:, 0].max() <= 1.85 + 1e-6 and kr[:, 0].std() > 0
         # the velocity controller holds altitude within centimetres over 8 steps of 10 sub-steps (a 1.24 kg airframe on 4 x 10 N motors)
-        alive = ~(term | trunc)
-        assert float((g["robot_position"][:, 2] - z0)[alive].abs().max()) < 0.5
+        alive = ~ever_reset  # (an env that crashed was re-placed; disturbances of up to 4.75 N are on for this robot)
+        assert int(alive.sum()) >= n // 2 and float((g["robot_position"][:, 2] - z0)[alive].abs().max()) < 0.5
     finally:
         cfg.robot_name, cfg.controller_name, cfg.device, cfg.args = old
 
