@@ -16,7 +16,7 @@ import bench  # noqa: E402
 
 dev = "cuda:0"
 for n in (8192, 1 << 21):
-    task = bench.make_task("dynamics", n, dev, False)
+    task = bench.make_task("dynamics", n, dev, False, lean=False)  # every dict tensor maintained (the key of this grid size)
     task.reset()
     a = torch.rand(n, 4, device=dev) * 2 - 1
     for _ in range(5):

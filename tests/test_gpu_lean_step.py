@@ -73,3 +73,30 @@ def test_lean_step_is_refused_where_it_cannot_hold():
         assert t.obs_dict["robot_prev_actions"].shape == (4096, 4)
     finally:
         cfg.args, cfg.device = old
+
+
+def test_lean_step_is_the_position_tasks_default_above_65536_envs_and_poisons_cached_references():
+    """round 4: at-scale default (the step is bound by the bytes it moves there); args={"lean_step": False} opts out.  A tensor
+    reference that bypasses the dict shows NaN instead of plausible stale numbers; the dict recomputes on read."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    old = (cfg.args, cfg.device, cfg.controller_name)
+    try:
+        cfg.device, cfg.args, cfg.controller_name = DEV, {}, "lee_position_control"
+        small = task_registry.make_task("position_setpoint_task", seed=2, num_envs=8192, headless=True)
+        assert not small.sim_env._lean
+        big = task_registry.make_task("position_setpoint_task", seed=2, num_envs=70000, headless=True)
+        assert big.sim_env._lean and big.sim_env._buffers.launch_flags == 4
+        raw = dict.__getitem__(big.obs_dict, "robot_euler_angles")  # a reference taken behind the dict's back
+        big.reset()
+        big.step(torch.zeros(70000, 4, device=DEV))
+        assert torch.isnan(raw).all()
+        fresh = big.obs_dict["robot_euler_angles"]  # a dict read recomputes from the current state, into the same tensor
+        assert fresh.data_ptr() == raw.data_ptr() and torch.isfinite(fresh).all()
+        cfg.args = {"lean_step": False}
+        full = task_registry.make_task("position_setpoint_task", seed=2, num_envs=70000, headless=True)
+        assert not full.sim_env._lean
+    finally:
+        cfg.args, cfg.device, cfg.controller_name = old
