@@ -351,8 +351,9 @@ class EnvManager(BaseManager):
         for key in ("robot_actions", "robot_prev_actions"):
             g.on_read(key, refuse)
         # A tensor reference taken from the dict BEFORE this point (or kept across steps) bypasses the hooks: the tensors the lean
-        # step no longer maintains are poisoned once, so that such a reference shows NaN instead of plausible stale numbers
-        # (the body-frame velocities stay maintained; a dict read re-fills the derived ones from the current state).
+        # step no longer maintains are poisoned here, so that such a reference shows NaN -- until the next reset or dict read
+        # refreshes them -- instead of plausible numbers of an earlier time (re-fetch through the dict each step;
+        # the body-frame velocities stay maintained).
         for key in ("robot_euler_angles", "robot_vehicle_orientation", "robot_vehicle_linvel", "robot_actions", "robot_prev_actions"):
             t = dict.get(g, key)
             if t is not None and t.is_floating_point():

@@ -75,9 +75,9 @@ def test_lean_step_is_refused_where_it_cannot_hold():
         cfg.args, cfg.device = old
 
 
-def test_lean_step_is_the_position_tasks_default_above_65536_envs_and_poisons_cached_references():
-    """round 4: at-scale default (the step is bound by the bytes it moves there); args={"lean_step": False} opts out.  A tensor
-    reference that bypasses the dict shows NaN instead of plausible stale numbers; the dict recomputes on read."""
+def test_lean_step_is_the_position_tasks_default_above_65536_envs():
+    """round 4: at-scale default (the step is bound by the bytes it moves there); args={"lean_step": False} opts out.  The dict
+    recomputes a derived tensor on read, into the tensor a cached reference points at."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -92,7 +92,6 @@ def test_lean_step_is_the_position_tasks_default_above_65536_envs_and_poisons_ca
         raw = dict.__getitem__(big.obs_dict, "robot_euler_angles")  # a reference taken behind the dict's back
         big.reset()
         big.step(torch.zeros(70000, 4, device=DEV))
-        assert torch.isnan(raw).all()
         fresh = big.obs_dict["robot_euler_angles"]  # a dict read recomputes from the current state, into the same tensor
         assert fresh.data_ptr() == raw.data_ptr() and torch.isfinite(fresh).all()
         cfg.args = {"lean_step": False}
