@@ -200,11 +200,11 @@ VALU_PEAK_GUIDE = 256 * 4 * 2.4e9 / 2.0  # MI355X_MICROARCH.md: v_fma_f32 wave64
 
 def valu_peak():
     """Plain (non-packed) fp32 VALU issue ceiling in wave64 instructions/s, two readings:
-    * measured on an MI355X by profiles/src/valu_peak.hip (profiles/r03_valu_peak.json: 16 independent chains per wave, scalar /
+    * measured on an MI355X by profiles/src/valu_peak.hip (profiles/r04_valu_peak.json: 16 independent chains per wave, scalar /
       inline-constant second and third operands, 8 waves per SIMD) -- what the chip sustains under its power budget (the
       effective clock of that run, GRBM_GUI_ACTIVE / wall, is recorded next to it);
     * the hardware guide's 2 cycles per wave64 instruction per SIMD at the 2.4 GHz maximum clock: 1.229 T/s."""
-    for name in ("r03_valu_peak.json", "r02_valu_peak.json"):
+    for name in ("r04_valu_peak.json", "r03_valu_peak.json", "r02_valu_peak.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return float(d["wave_instr_per_s"]), f"measured (profiles/{name})", d.get("effective_clock_ghz")
@@ -360,12 +360,12 @@ def live_parity(device):
     return {"case": "tests/golden/step_quad_position.npz (reference BaseMultirotor.step outputs, 6 sub-steps x 64 envs)",
             "max_err_vs_reference": out, "bit_exact_vs_reference_with_correctly_rounded_functions": bool(exact), "unit": "|err| / max(1, |x|) per component (thrust: / 2 N full scale)",
             "gates": "tests/ (pytest -m gpu): bit-exact vs the CPU oracle, <= 1e-5 vs the reference (every state component), bit-exact vs the reference with correctly rounded elementary functions; "
-                     "measured maxima of the last full run: profiles/r03_parity_report.json"}
+                     "measured maxima of the last full run: profiles/r04_parity_report.json"}
 
 
 def kernel_time_dynamics(task, actions, reps=400):
     """Duration of the env-step kernel, HIP events on the stream it is launched on, three ways (all reported; rocprofv3's
-    per-kernel average over the same command lies between the first two, profiles/r03_*_kernel_stats.csv):
+    per-kernel average over the same command lies between the first two, profiles/r04_*_kernel_stats.csv):
 
     * `in_step`  -- the launch bracketed by two events INSIDE real task steps (env-step launch, then the reset / observation
       launch, exactly the sequence of the timed region), the queue pre-filled behind a blocker so that the host is out of

@@ -1,5 +1,5 @@
 """Turns the output of profiles/src/valu_peak.hip (JSON lines; run plain) and, optionally, the rocprofv3 PMC pass of the same
-binary (`--pmc GRBM_GUI_ACTIVE`, counter collection CSV) into profiles/r03_valu_peak.json: the measured VALU issue ceiling and
+binary (`--pmc GRBM_GUI_ACTIVE`, counter collection CSV) into profiles/r04_valu_peak.json: the measured VALU issue ceiling and
 the effective clock it was reached at (GRBM_GUI_ACTIVE / wall time of the launch, MI355X_MICROARCH.md "DVFS").
 
     python profiles/collect_valu_peak.py gpurun_out/r03m/valu_peak.jsonl [gpurun_out/r03m/valu_peak_pmc/..._counter_collection.csv] [gpurun_out/r03m/valu_peak_pmc.jsonl]
@@ -36,7 +36,7 @@ def main(plain, pmc_csv=None, pmc_jsonl=None):
            "guide": {"cycles_per_wave_instr": 2.0, "max_clock_ghz": 2.4, "wave_instr_per_s": 256 * 4 * 2.4e9 / 2.0,
                      "source": "MI355X_MICROARCH.md, per-instruction cycle constants: v_fma_f32 (wave64) 2 cyc (SIMD-32)"},
            "rows": rows, "source": "profiles/src/valu_peak.hip on one MI355X"}
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r03_valu_peak.json")
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("AGX_VALU_PEAK_OUT", "r04_valu_peak.json"))
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "rows"}, indent=1))
 
