@@ -748,9 +748,20 @@ def ensure_ranks(args):
     import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import random
+
+    port = None
+    for _ in range(200):  # below the kernel's ephemeral range: a port from bind(0) can be taken again before the launcher listens on it
+        cand = random.randrange(15000, 30000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+        port = cand
+        break
+    if port is None:
+        raise SystemExit("bench.py: no free rendezvous port on 127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} rank(s): {' '.join(cmd)}", file=sys.stderr, flush=True)

@@ -24,6 +24,24 @@ def _run_world2(mode, steps, extra_env=None, timeout=420):
             print(f"[world-2 exchange] attempt {attempt + 1} did not finish, repeating (AGX_WORLD2_RETRIES):\n{e}", flush=True)
 
 
+def _rendezvous_port():
+    """a port BELOW the kernel's ephemeral range (32768+): `bind(0)` hands out an ephemeral port that an outgoing connection of
+    any process may take again between our close() and rank 0's listen() -- seen once in round 4 as EADDRINUSE in rank 0 and a
+    420-s wait for rank 1"""
+    import random
+
+    rng = random.Random(os.getpid() ^ int(time.time() * 1000))
+    for _ in range(200):
+        port = rng.randrange(15000, 30000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    raise RuntimeError("no free rendezvous port")
+
+
 def _run_world2_once(mode, steps, extra_env, timeout):
     import subprocess
     import sys
@@ -35,10 +53,7 @@ def _run_world2_once(mode, steps, extra_env, timeout):
     fake_build = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fake_build)
     lib = fake_build.build()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = _rendezvous_port()
     # (the double's rendezvous bound is generous here: on a loaded box one rank's set-up can trail the other's by tens of
     #  seconds; the failure-path test sets its own, short one)
     env = dict(os.environ, AGX_RCCL_PATH=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", AGX_FAKERCCL_TIMEOUT_S="150")
@@ -46,22 +61,33 @@ def _run_world2_once(mode, steps, extra_env, timeout):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_world2_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), mode, str(steps)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = []
+    outs = [None] * len(procs)
     t0 = time.time()
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=max(1.0, timeout - (time.time() - t0)))
-        except subprocess.TimeoutExpired:
+    dead_since = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        # a rank that died on its own leaves its peer waiting inside a rendezvous or a collective: give the peer a moment to
+        # notice (the library's own bounds are shorter than this harness's), then end the run with what both said
+        if any(c not in (None, 0) for c in codes):
+            dead_since = dead_since or time.time()
+        expired = time.time() - t0 > timeout or (dead_since is not None and time.time() - dead_since > 60)
+        if expired:
             for q in procs:
-                q.kill()
+                if q.poll() is None:
+                    q.kill()
             tails = []
             for r, q in enumerate(procs):  # what each rank printed before it was killed (a rank that died leaves its peer waiting)
                 try:
-                    tails.append(f"--- rank {r} (exit code {q.poll()}):\n" + (q.communicate(timeout=10)[0] or "")[-2500:])
+                    tails.append(f"--- rank {r} (exit code {codes[r]}):\n" + (q.communicate(timeout=10)[0] or "")[-2500:])
                 except Exception as e:  # noqa: BLE001
                     tails.append(f"--- rank {r}: no output ({e})")
-            raise TimeoutError(f"world-2 exchange ({mode}) did not finish within {timeout} s\n" + "\n".join(tails))
-        outs.append(out)
+            why = f"did not finish within {timeout} s" if dead_since is None else "lost a rank (its peer was ended after 60 s)"
+            raise TimeoutError(f"world-2 exchange ({mode}) {why}\n" + "\n".join(tails))
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        outs[r] = p.communicate()[0]
     return [p.returncode for p in procs], outs
 
 
