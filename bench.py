@@ -296,7 +296,8 @@ def cpu_baseline_reference():
     """The reference's own torch CPU path (oracle/time_reference_cpu.py).  Where the reference tree is present on THIS box
     (AERIAL_GYM_REFERENCE_ROOT, default /root/reference) it is timed here and now, on this box's host cores -- the comparison
     north_star names; otherwise the committed measurement of the build container is echoed (its `host` field says so)."""
-    root = os.environ.get("AERIAL_GYM_REFERENCE_ROOT", "/root/reference")
+    root = os.environ.get("AERIAL_GYM_REFERENCE_ROOT") or os.environ.get("AERIAL_GYM_REFERENCE") or "/root/reference"
+    os.environ["AERIAL_GYM_REFERENCE_ROOT"] = root  # (what oracle/ref_shells.py reads, in the child process below)
     keys = ("value", "unit", "cores", "kind", "sample", "host", "cpu_model", "what")
     if os.path.isdir(os.path.join(root, "aerial_gym")):
         import subprocess
