@@ -8,7 +8,8 @@ SOURCE: the unmodified kernel bodies of
 launched by the reference's own classes (WarpSensor -> WarpCam / WarpLidar / WarpStereoCam / WarpNormalFaceIDCam /
 WarpNormalFaceIDLidar: intrinsics, ray table, graph capture, pose composition, noise / range limits / normalisation) under
 the `warp` emulation of oracle/wp_emul.py (read its header for what is emulated and how: builtins restated from Warp's
-headers as single binary32 operations, mesh_query_ray answered by the C oracle's brute-force closest hit).  The only edits
+headers as single binary32 operations, mesh_query_ray answered by that module's own brute-force loop -- the C oracle takes no part
+in producing these fixtures, it is checked against them).  The only edits
 to the reference at run time: its sensor classes are constructed with device="cpu" (their default is "cuda:0").
 
     python oracle/gen_golden_warp_kernels.py        (in the build container: needs /root/reference)
@@ -32,12 +33,11 @@ wp_emul.install()  # `import warp` now finds the emulation -- before any referen
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-import oracle as orc  # noqa: E402
 import ref_shells  # noqa: E402
 
 OUT = os.path.normpath(os.path.join(_HERE, "..", "tests", "golden"))
 
-wp_emul.set_mesh_query(lambda o, d, max_t, tris: orc.mesh_query_ray(o, d, max_t, tris))
+# (mesh_query_ray is answered by wp_emul's own brute-force loop: nothing of oracle/*.c takes part in producing these fixtures)
 
 # a box as a closed indexed mesh: 8 corners, 12 outward-facing triangles
 BOX_V = np.array([[x, y, z] for x in (-0.5, 0.5) for y in (-0.5, 0.5) for z in (-0.5, 0.5)], np.float32)

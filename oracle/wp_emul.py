@@ -22,12 +22,13 @@ reference's code is given instead:
     `capture_begin / capture_end / capture_launch` record and replay launches like the CUDA graph the reference captures;
   * `wp.from_torch / wp.to_torch`: views of the caller's torch tensors (shared memory, like Warp);
   * `wp.Mesh(points, indices, velocities)` + `wp.mesh_get`: the three arrays the reference hands over;
-  * `wp.mesh_query_ray`: the closest hit is supplied by the C oracle's BRUTE-FORCE loop over the mesh's triangles
-    (oracle_raycast.c orc_mesh_query_ray: Woop watertight test of warp/native/intersect.h, 0 <= t < max_t, smallest t,
-    ties -> smallest face index) -- this is the one part of the path that is still a restatement of Warp, and it is the
-    part Warp itself leaves unspecified (its answer on exact ties depends on its BVH).  The normal it reports is
-    normalize(cross(b - a, c - a)) of the hit face (intersect.h / mesh.h); u, v, sign are returned as 0 (no kernel of the
-    reference reads them).
+  * `wp.mesh_query_ray`: a BRUTE-FORCE loop over the mesh's triangles with Warp's watertight test (warp/native/intersect.h
+    intersect_ray_tri_woop, restated in THIS module in numpy float32 with a correctly rounded fmaf -- `_query_brute_force`),
+    0 <= t < max_t, smallest t, ties -> smallest face index.  This is the one part of the path that is a restatement of Warp,
+    and the part Warp itself leaves unspecified (its answer on exact ties depends on its BVH).  It is written independently of the
+    C oracle (oracle_raycast.c), which is then CHECKED against the frames produced here; `set_mesh_query(orc.mesh_query_ray)`
+    swaps the C loop in (tests compare the two queries ray by ray).  The normal reported is normalize(cross(b - a, c - a)) of the
+    hit face (intersect.h / mesh.h); u, v, sign are returned as 0 (no kernel of the reference reads them).
 
 Used by oracle/gen_golden_warp_kernels.py (writes tests/golden/warp_kernels_*.npz) in the build container only.
 Never imported by the product package.
@@ -333,11 +334,92 @@ def to_torch(a):
 # meshes
 # ---------------------------------------------------------------------------------------------------------------------
 _MESHES = {}
-_QUERY = [None]  # (o, d, max_t, tris [T, 9] float32) -> (hit, t, face); installed by the generator: the C oracle's brute force
 _TRI_CACHE = {}
 
 
+def _fma32(a, b, c):
+    """fmaf(a, b, c) on float32 arrays, correctly rounded: the product is exact in float64 (24 + 24 bits), the sum is rounded to ODD
+    in float64 (TwoSum gives the exact error) and then once to float32 -- round-to-odd with 53 >= 24 + 2 bits makes the double
+    rounding innocuous."""
+    r = a.astype(np.float64) * b.astype(np.float64)
+    c = c.astype(np.float64)
+    with np.errstate(**_ERR):
+        s = r + c
+        bb = s - r
+        e = (r - (s - bb)) + (c - bb)
+    fix = (e != 0.0) & np.isfinite(s) & ((s.view(np.int64) & 1) == 0)
+    if fix.any():
+        si = s.view(np.int64).copy()
+        away = (e > 0.0) == (s > 0.0)  # the exact sum lies further from zero than s: next representable magnitude up, else down
+        si[fix & away] += 1
+        si[fix & ~away] -= 1
+        s = si.view(np.float64)
+    return s.astype(np.float32)
+
+
+def _diff_product(a, b, c, d):
+    """intersect.h diff_product(): a b - c d with FMA error compensation (Kahan)"""
+    with np.errstate(**_ERR):
+        cd = c * d
+        diff = _fma32(a, b, -cd)
+        error = _fma32(-c, d, cd)
+        return diff + error
+
+
+def _query_brute_force(o, d, max_t, tris):
+    """wp.mesh_query_ray's closest hit by a loop over ALL triangles of the mesh (vectorised over the triangles): Warp's watertight
+    test, warp/native/intersect.h intersect_ray_tri_woop -- dominant axis kz = first strict maximum of |dir|, kx / ky the next two
+    (swapped when dir[kz] < 0), shear S = (dir[kx], dir[ky], 1) / dir[kz], vertices translated by the origin and sheared, the
+    three edge functions by diff_product with a DOUBLE-precision fallback when one is exactly 0, rejection on mixed signs, on a zero
+    determinant and on sign(T) != sign(det), t = T * (1 / det) -- accepting 0 <= t < max_t, keeping the smallest t and on an exact
+    tie the smallest face index (mesh.h keeps whichever its BVH visits first; see the module docstring).
+    Written here from Warp's published source, independently of oracle/oracle_raycast.c: the fixtures this module produces are what
+    the C oracle is CHECKED against (tests/test_oracle_warp_kernels.py)."""
+    d = [f32(x) for x in d]
+    o = [f32(x) for x in o]
+    ax, ay, az = abs(d[0]), abs(d[1]), abs(d[2])
+    kz = (0 if ax > az else 2) if ax > ay else (1 if ay > az else 2)
+    kx = 0 if kz == 2 else kz + 1
+    ky = 0 if kx == 2 else kx + 1
+    if d[kz] < f32(0.0):
+        kx, ky = ky, kx
+    with np.errstate(**_ERR):
+        Sx, Sy, Sz = d[kx] / d[kz], d[ky] / d[kz], f32(1.0) / d[kz]
+        A = tris[:, 0:3] - np.array(o, np.float32)
+        B = tris[:, 3:6] - np.array(o, np.float32)
+        Cc = tris[:, 6:9] - np.array(o, np.float32)
+        Ax, Ay = A[:, kx] - Sx * A[:, kz], A[:, ky] - Sy * A[:, kz]
+        Bx, By = B[:, kx] - Sx * B[:, kz], B[:, ky] - Sy * B[:, kz]
+        Cx, Cy = Cc[:, kx] - Sx * Cc[:, kz], Cc[:, ky] - Sy * Cc[:, kz]
+        U = _diff_product(Cx, By, Cy, Bx)
+        V = _diff_product(Ax, Cy, Ay, Cx)
+        W = _diff_product(Bx, Ay, By, Ax)
+        z = (U == 0.0) | (V == 0.0) | (W == 0.0)
+        if z.any():
+            f64 = np.float64
+            U = np.where(z, (Cx.astype(f64) * By.astype(f64) - Cy.astype(f64) * Bx.astype(f64)).astype(np.float32), U)
+            V = np.where(z, (Ax.astype(f64) * Cy.astype(f64) - Ay.astype(f64) * Cx.astype(f64)).astype(np.float32), V)
+            W = np.where(z, (Bx.astype(f64) * Ay.astype(f64) - By.astype(f64) * Ax.astype(f64)).astype(np.float32), W)
+        mixed = ((U < 0.0) | (V < 0.0) | (W < 0.0)) & ((U > 0.0) | (V > 0.0) | (W > 0.0))
+        det = U + V + W
+        Az, Bz, Cz = Sz * A[:, kz], Sz * B[:, kz], Sz * Cc[:, kz]
+        T = U * Az + V * Bz + W * Cz
+        # xorf(T, sign(det)) < 0  <=>  T != 0 and T, det of opposite sign (a zero of either sign passes)
+        behind = (np.signbit(T) != np.signbit(det)) & (T != 0.0)
+        t = T * (f32(1.0) / det)
+        ok = ~mixed & (det != 0.0) & ~behind & (t >= 0.0) & (t < f32(max_t))
+    if not ok.any():
+        return False, f32(0.0), -1
+    tt = np.where(ok, t, np.float32(np.inf))
+    face = int(np.argmin(tt))  # the first minimum: smallest face index on an exact tie
+    return True, f32(tt[face]), face
+
+
+_QUERY = [_query_brute_force]  # (o, d, max_t, tris [T, 9] float32) -> (hit, t, face)
+
+
 def set_mesh_query(fn):
+    """replace the closest-hit query (e.g. by the C oracle's brute force, to time the generator or to cross-check this module)"""
     _QUERY[0] = fn
 
 

@@ -116,3 +116,52 @@ def test_warp_kernel_goldens_are_reproducible_from_the_reference(tmp_path):
         assert sorted(new.files) == sorted(old.files)
         for k in new.files:
             assert (str(new[k]) == str(old[k])) if new[k].dtype.kind in "US" else np.array_equal(new[k], old[k], equal_nan=True), (kind, k)
+
+
+def test_emulator_query_equals_the_c_oracle_query_ray_by_ray(orc):
+    """The fixtures' closest hits come from oracle/wp_emul.py's own brute-force loop (numpy float32, correctly rounded fmaf emulation),
+    written from Warp's intersect.h independently of oracle_raycast.c.  Ray by ray the two restatements agree -- hit / miss, t to the
+    bit, face index -- on random rays, on rays aimed EXACTLY at vertices and edge midpoints (edge functions that are exactly 0: the
+    double-precision fallback; shared edges: the tie rule), on axis-parallel rays, and on rays that start inside a box."""
+    import wp_emul  # noqa: PLC0415  (oracle/ is on sys.path: conftest)
+
+    g = load("camera")
+    rng = np.random.default_rng(5)
+    n_checked = n_hits = n_zero_edge = 0
+    for env in range(3):
+        tris = np.ascontiguousarray(g["tri_world"][env])
+        verts = tris.reshape(-1, 3)
+        rays = []
+        for _ in range(250):  # random origin / direction
+            rays.append((rng.uniform(-4, 4, 3), rng.normal(size=3), rng.choice([3.0, 10.0, 50.0])))
+        for _ in range(150):  # through a vertex, or the midpoint of a triangle edge, exactly representable targets
+            o = rng.uniform(-4, 4, 3).astype(np.float32)
+            f = rng.integers(0, tris.shape[0])
+            a, b = tris[f, 0:3], tris[f, 3:6]
+            tgt = a if rng.random() < 0.5 else (a + b) * np.float32(0.5)
+            rays.append((o, (tgt - o), 50.0))
+        for ax in range(3):  # axis-parallel rays (two direction components exactly 0)
+            for _ in range(30):
+                d = np.zeros(3); d[ax] = rng.choice([-1.0, 1.0])
+                rays.append((rng.uniform(-4, 4, 3), d, 20.0))
+        for _ in range(90):  # axis-parallel THROUGH a vertex, exactly: two of its sheared coordinates are 0, edge functions vanish
+            v = verts[rng.integers(0, verts.shape[0])]
+            ax = int(rng.integers(0, 3))
+            d = np.zeros(3, np.float32); d[ax] = rng.choice([-1.0, 1.0])
+            o = v.copy(); o[ax] = v[ax] - np.float32(3.0) * d[ax]  # (the two other coordinates equal the vertex's bit for bit)
+            rays.append((o, d, 20.0))
+        for k in range(30):  # from inside an obstacle
+            c = g["asset_pose"][env][k % g["asset_pose"].shape[1], 0:3]
+            rays.append((c + rng.normal(scale=0.01, size=3), rng.normal(size=3), 10.0))
+        for o, d, max_t in rays:
+            o = np.asarray(o, np.float32)
+            d = np.asarray(d, np.float32)
+            d = (d / np.sqrt((d * d).sum(dtype=np.float32))).astype(np.float32)
+            h1, t1, f1 = wp_emul._query_brute_force(o, d, np.float32(max_t), tris)
+            h2, t2, f2 = orc.mesh_query_ray(o, d, np.float32(max_t), tris)
+            assert h1 == h2, (env, o, d)
+            if h1:
+                assert np.float32(t1).view(np.uint32) == np.float32(t2).view(np.uint32) and f1 == f2, (env, o, d, t1, t2, f1, f2)
+                n_hits += 1
+            n_checked += 1
+    assert n_checked > 1700 and n_hits > 500
