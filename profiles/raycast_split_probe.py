@@ -24,6 +24,8 @@ torch.cuda.synchronize()
 sensor = task.sim_env.robot_manager.warp_sensor
 g = task.sim_env.global_tensor_dict
 splits = [1, 2, 3, 4, 6, 12] if which == "depth" else [1, 2, 4, 8, 16, 32, 64]
+if os.environ.get("AGX_PROBE_SPLITS"):  # e.g. a build with another workgroup size (AGX_LIB_PATH): "6,8,12,16,24,48"
+    splits = [int(x) for x in os.environ["AGX_PROBE_SPLITS"].split(",")]
 
 
 def use(sp):
