@@ -507,19 +507,40 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
       tinc[j] = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, j) : P.tau_inc_uniform;
       tdec[j] = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, j) : P.tau_dec_uniform;
     }
-    Gains g{};
-    if (CTRL != AGX_CTRL_NONE && CTRL != AGX_CTRL_WRENCH) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
     // EXTERNAL controller (a user class evaluated by the host between launches): actions_in is ITS OUTPUT, the body
     // wrench [N][6]; robot_actions / robot_prev_actions (A columns) are maintained by the host and only read here
     constexpr bool EXT = CTRL == AGX_CTRL_WRENCH;
     float a_in[AGX_MAX_ACTIONS], a_old[AGX_MAX_ACTIONS];
+    // (the row index in 32 bits: n x 8 actions < 2^32.  The 64-bit multiply the compiler made of (size_t)i * A carried a
+    // don't-care register into its high half -- one a state load was still writing -- and waited for that load first)
+    const unsigned arow = (unsigned)i * (unsigned)(EXT ? 6 : A);
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
-      a_in[c] = EXT ? ((c < 6) ? actions_in[(size_t)i * 6 + c] : 0.0f) : ((c < A) ? actions_in[(size_t)i * A + c] : 0.0f);
+      a_in[c] = (c < (EXT ? 6 : A)) ? actions_in[arow + (unsigned)c] : 0.0f;
       a_old[c] = (c < A && !lean) ? AGX_AT(B.actions, c) : 0.0f;
     }
     Derived d{};
     if (k == 0 && T.kind != AGX_TASK_NONE) d = load_derived(B.derived, n, i);
+    // What the bookkeeping / task epilogue reads is requested HERE, with the state.  Behind the stores of this kernel the
+    // compiler cannot move a load up (the buffers may alias for all it knows), and each load issued down there is a memory
+    // round trip of its own on the wave's critical path that also sits out every store in front of it (gfx9 counts loads and
+    // stores in one vmcnt): step counter -> target -> previous error were three such trips per wave.
+    const bool more_launches = (B.launch_flags & 2) != 0;  // (launch_flags: see below)
+    const bool task_epilogue = T.kind != AGX_TASK_NONE && !more_launches;
+    const int steps_in = B.sim_steps[i];
+    const int crashed_in = (B.launch_flags & 1) ? B.crashes[i] : 0;
+    V3 tgt{0, 0, 0}, ppe{0, 0, 0};
+    if (task_epilogue) {
+      tgt = V3{AGX_AT(T.target, 0), AGX_AT(T.target, 1), AGX_AT(T.target, 2)};
+      if (T.kind != AGX_TASK_POSITION) ppe = V3{AGX_AT(T.pos_err, 0), AGX_AT(T.pos_err, 1), AGX_AT(T.pos_err, 2)};
+    }
+    float a_prev_in[AGX_MAX_ACTIONS];  // robot_prev_actions as the last step left them (a k = 0 launch or an external controller reads them)
+#pragma unroll
+    for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a_prev_in[c] = ((k == 0 || EXT) && c < A && !lean) ? AGX_AT(B.prev_actions, c) : 0.0f;
+    // the gains LAST: with uniform gains (B.gains null) the registers they are moved into are the ones the other arm loads into,
+    // and the compiler waits for every load in flight before the move -- behind the last load that wait costs nothing
+    Gains g{};
+    if (CTRL != AGX_CTRL_NONE && CTRL != AGX_CTRL_WRENCH) g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
     Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
     const bool root_link = P.root_link_mode != 0;
     const int sub_base = (B.launch_flags >> 8) & 0xFF;  // physics sub-step this launch starts at (split env steps)
@@ -613,8 +634,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
     // EnvManager.reset_tensors + compute_observations (env_manager.py:342-344, 358-362)
     // launch_flags (external controllers run ONE launch per physics sub-step): bit 0 = an earlier launch of this env
     // step already ran: accumulate its crash flag; bit 1 = more launches follow: no step counter / truncation / task epilogue
-    const bool more_launches = (B.launch_flags & 2) != 0;
-    bool crashed = (B.launch_flags & 1) ? (B.crashes[i] != 0) : false;
+    bool crashed = crashed_in != 0;
     if (B.boxes && k > 0) crashed = collide_trajectory(B.boxes, B.num_boxes, n, i, traj, k, bd, tid, tlo, thi, P.collision_radius) || crashed;
     store_state(B.state, n, i, s);
     if (k > 0) {
@@ -632,22 +652,20 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
 #pragma unroll
     for (int c = 0; c < AGX_MAX_ACTIONS; ++c) {
       a_cur[c] = (k > 0 && !EXT) ? a_in[c] : a_old[c];
-      a_prev[c] = (k >= 2 && !EXT) ? a_in[c] : ((k == 1 && !EXT) ? a_old[c] : ((c < A && !lean) ? AGX_AT(B.prev_actions, c) : 0.0f));
+      a_prev[c] = (k >= 2 && !EXT) ? a_in[c] : ((k == 1 && !EXT) ? a_old[c] : a_prev_in[c]);
       if (c < A && k > 0 && !EXT && !lean) {
         AGX_AT(B.prev_actions, c) = a_prev[c];
         AGX_AT(B.actions, c) = a_cur[c];
       }
     }
-    const int steps = B.sim_steps[i] + (more_launches ? 0 : 1);
+    const int steps = steps_in + (more_launches ? 0 : 1);
     if (!more_launches) B.sim_steps[i] = steps;
     bool trunc = false;
-    if (T.kind != AGX_TASK_NONE && !more_launches) {
-      V3 tgt = V3{AGX_AT(T.target, 0), AGX_AT(T.target, 1), AGX_AT(T.target, 2)};
+    if (task_epilogue) {
       float rew;
       if (T.kind == AGX_TASK_POSITION) {
         rew = reward_position(s, d.qveh, d.wbody, tgt, crashed);
       } else {
-        V3 ppe = V3{AGX_AT(T.pos_err, 0), AGX_AT(T.pos_err, 1), AGX_AT(T.pos_err, 2)};
         AGX_AT(T.prev_pos_err, 0) = ppe.x; AGX_AT(T.prev_pos_err, 1) = ppe.y; AGX_AT(T.prev_pos_err, 2) = ppe.z;
         V3 pe = quat_rotate_inverse(d.qveh, tgt - s.p);
         AGX_AT(T.pos_err, 0) = pe.x; AGX_AT(T.pos_err, 1) = pe.y; AGX_AT(T.pos_err, 2) = pe.z;
@@ -859,6 +877,11 @@ __global__ void __launch_bounds__(64, 1)
     const float kv = B.gains ? AGX_QAT(B.gains, 3, ol3) : P.gains_uniform[3 + l3];
     const float kr = B.gains ? AGX_QAT(B.gains, 6, ol3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_QAT(B.gains, 9, ol3) : P.gains_uniform[9 + l3];
+    // what the task epilogue reads is requested HERE, with the state: behind the stores below the compiler cannot move a load up
+    // (the buffers may alias for all it knows), and a load issued there is a second memory round trip on the kernel's critical
+    // path -- one that also waits for every store in front of it (gfx9 counts loads and stores in the same vmcnt)
+    const int steps_in = B.sim_steps[i];
+    const float tgt = T.kind == AGX_TASK_POSITION ? AGX_QAT(T.target, 0, ol3) : 0.0f;
     const QuadConsts<4> C = load_quad_consts<4>(P, l, l3);
 
     // ---- update_states + controller (position_control.py:20-51)
@@ -903,11 +926,10 @@ __global__ void __launch_bounds__(64, 1)
     AGX_QAT(B.actions, 0, ol) = a_in;
 
     // ---- EnvManager bookkeeping + the position task's reward / truncation / reset set (position_setpoint_task.py:245-282)
-    const int steps = B.sim_steps[i] + 1;
+    const int steps = steps_in + 1;
     bool crashed = false, trunc = false;
     float rew = 0.0f;
     if (T.kind == AGX_TASK_POSITION) {
-      const float tgt = AGX_QAT(T.target, 0, ol3);
       const float pe_t = q4::quat_apply(q4::conj(d.qveh), tgt - p);  // quat_apply_inverse
       const float dist = q4::norm3(pe_t);
       // 3 exp(-8 d^2) + 2 exp(-4 d^2): both exponentials in one evaluation (lanes 0 / 1)
@@ -1076,9 +1098,31 @@ __global__ void __launch_bounds__(64, 1)
     const float kr = B.gains ? AGX_QAT(B.gains, 6, ol3) : P.gains_uniform[6 + l3];
     const float kw = B.gains ? AGX_QAT(B.gains, 9, ol3) : P.gains_uniform[9 + l3];
     const QuadConsts<M> C = load_quad_consts<M>(P, l, l3);
+    // what the epilogue reads, requested with the state (see k_env_step: a load behind the stores is a round trip of its own)
+    const int steps_in = B.sim_steps[i];
+    const float tgt = T.kind != AGX_TASK_NONE ? AGX_QAT(T.target, 0, ol3) : 0.0f;
+    const float ppe = (T.kind != AGX_TASK_NONE && T.kind != AGX_TASK_POSITION) ? AGX_QAT(T.pos_err, 0, ol3) : 0.0f;
+    const float a_prev_in = k == 0 ? AGX_QAT(B.prev_actions, 0, ol) : 0.0f;
+    const float a_prev_in2 = (FA && k == 0) ? AGX_QAT(B.prev_actions, 3, ol) : 0.0f;
     const float dmax = B.disturb_max[l3], dmax_t = B.disturb_max[3 + l3];
     const float a = clamp_minmax(a_in, -10.0f, 10.0f);  // clip_actions (the same every sub-step)
     const float a2 = clamp_minmax(a_in2, -10.0f, 10.0f);
+    // Obstacles: lane l tests boxes l, l + 4, ...  The cull data (centre, bounding radius) of kBoxBatch of them is requested in
+    // ONE go -- a box per loop trip was a dependent memory round trip per trip (27 of them on BASELINE configs[2], with one wave
+    // per SIMD and nothing to hide them behind) -- and the first batch before the sub-step loop, whose arithmetic covers it.
+    constexpr int kBoxBatch = M == 8 ? 12 : 16;  // (4 x 16 registers held over the sub-step loop; the octarotor instances stay <= 256 VGPRs)
+    struct BoxCull { float cx[kBoxBatch], cy[kBoxBatch], cz[kBoxBatch], rad[kBoxBatch]; };
+    const int nb = (B.boxes && k > 0) ? B.num_boxes : 0;
+    auto load_cull = [&](int b0, BoxCull &K) {
+#pragma unroll
+      for (int u = 0; u < kBoxBatch; ++u) {
+        const int b = b0 + 4 * u;
+        const float *bx = B.boxes + (size_t)(b < nb ? b : b0) * 11 * n + i;  // past the end: this lane's first box again, not used
+        K.cx[u] = bx[0]; K.cy[u] = bx[(size_t)n]; K.cz[u] = bx[2 * (size_t)n]; K.rad[u] = bx[10 * (size_t)n];
+      }
+    };
+    BoxCull cull0{};
+    if (l < nb) load_cull(l, cull0);
     QuadDerived d{};
     float force = 0.0f, torque = 0.0f, fb = 0.0f;
     float tlo = p, thi = p;
@@ -1115,20 +1159,31 @@ __global__ void __launch_bounds__(64, 1)
       const V3 lo = V3{q4::bc<0>(tlo), q4::bc<1>(tlo), q4::bc<2>(tlo)}, hi = V3{q4::bc<0>(thi), q4::bc<1>(thi), q4::bc<2>(thi)};
       const float rad = P.collision_radius, r2 = rad * rad;
       bool hit = false;
-      for (int b = l; b < B.num_boxes; b += 4) {
-        const float *bx = B.boxes + (size_t)b * 11 * n + i;
-        const V3 c = V3{bx[0], bx[(size_t)n], bx[2 * (size_t)n]};
-        const float reach = bx[10 * (size_t)n] + rad + 1.0e-3f;
-        const float dx = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.0f);
-        const float dy = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.0f);
-        const float dz = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.0f);
-        if (dx * dx + dy * dy + dz * dz > reach * reach) continue;
-        const Q4 bq = Q4{bx[3 * (size_t)n], bx[4 * (size_t)n], bx[5 * (size_t)n], bx[6 * (size_t)n]};
-        const V3 bh = V3{bx[7 * (size_t)n], bx[8 * (size_t)n], bx[9 * (size_t)n]};
-        for (int sub = 0; sub < k; ++sub) {
-          const V3 ps = V3{traj[(sub * 3 + 0) * 16 + slot], traj[(sub * 3 + 1) * 16 + slot], traj[(sub * 3 + 2) * 16 + slot]};
-          hit = hit || sphere_hits_box(ps, c, bq, bh, r2);
+      auto test_batch = [&](int b0, const BoxCull &K) {
+#pragma unroll
+        for (int u = 0; u < kBoxBatch; ++u) {
+          const int b = b0 + 4 * u;
+          const V3 c = V3{K.cx[u], K.cy[u], K.cz[u]};
+          const float reach = K.rad[u] + rad + 1.0e-3f;
+          const float dx = fmaxf(fmaxf(lo.x - c.x, c.x - hi.x), 0.0f);
+          const float dy = fmaxf(fmaxf(lo.y - c.y, c.y - hi.y), 0.0f);
+          const float dz = fmaxf(fmaxf(lo.z - c.z, c.z - hi.z), 0.0f);
+          if (b < nb && !(dx * dx + dy * dy + dz * dz > reach * reach)) {  // (rare: the boxes the trajectory's AABB reaches)
+            const float *bx = B.boxes + (size_t)b * 11 * n + i;
+            const Q4 bq = Q4{bx[3 * (size_t)n], bx[4 * (size_t)n], bx[5 * (size_t)n], bx[6 * (size_t)n]};
+            const V3 bh = V3{bx[7 * (size_t)n], bx[8 * (size_t)n], bx[9 * (size_t)n]};
+            for (int sub = 0; sub < k; ++sub) {
+              const V3 ps = V3{traj[(sub * 3 + 0) * 16 + slot], traj[(sub * 3 + 1) * 16 + slot], traj[(sub * 3 + 2) * 16 + slot]};
+              hit = hit || sphere_hits_box(ps, c, bq, bh, r2);
+            }
+          }
         }
+      };
+      if (l < nb) test_batch(l, cull0);
+      for (int b0 = l + 4 * kBoxBatch; b0 < nb; b0 += 4 * kBoxBatch) {
+        BoxCull K;
+        load_cull(b0, K);
+        test_batch(b0, K);
       }
       crashed = ((vote(hit) >> (tid & 60)) & 0xFull) != 0ull;
     }
@@ -1165,15 +1220,14 @@ __global__ void __launch_bounds__(64, 1)
     }
     // ---- EnvManager bookkeeping + task epilogue (scalar code, the same in the four lanes; lane 0 stores)
     const float acur = k > 0 ? a_in : a_old;
-    const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : AGX_QAT(B.prev_actions, 0, ol));
+    const float aprev = k >= 2 ? a_in : (k == 1 ? a_old : a_prev_in);
     // action component 3 as the navigation reward reads it: a3, or the first orientation component of the 7-D command
     const float acur3 = FA ? q4::bc<0>(k > 0 ? a_in2 : a_old2) : q4::bc<3>(acur);
-    const float aprev3 = FA ? q4::bc<0>(k >= 2 ? a_in2 : (k == 1 ? a_old2 : AGX_QAT(B.prev_actions, 3, ol))) : q4::bc<3>(aprev);
-    const int steps = B.sim_steps[i] + 1;
+    const float aprev3 = FA ? q4::bc<0>(k >= 2 ? a_in2 : (k == 1 ? a_old2 : a_prev_in2)) : q4::bc<3>(aprev);
+    const int steps = steps_in + 1;
     bool trunc = false;
     float rew = 0.0f;
     if (T.kind != AGX_TASK_NONE) {
-      const float tgt = AGX_QAT(T.target, 0, ol3);
       if (T.kind == AGX_TASK_POSITION) {
         EnvState s;
         s.p = V3{q4::bc<0>(p), q4::bc<1>(p), q4::bc<2>(p)};
@@ -1184,7 +1238,6 @@ __global__ void __launch_bounds__(64, 1)
                               V3{q4::bc<0>(d.wbody), q4::bc<1>(d.wbody), q4::bc<2>(d.wbody)},
                               V3{q4::bc<0>(tgt), q4::bc<1>(tgt), q4::bc<2>(tgt)}, crashed);
       } else {
-        const float ppe = AGX_QAT(T.pos_err, 0, ol3);
         const float pe = q4::quat_rotate_inverse(d.qveh, tgt - p);
         if (l < 3) {
           AGX_QAT(T.prev_pos_err, 0, ol) = ppe;
@@ -1668,18 +1721,18 @@ __global__ void __launch_bounds__(256) k_reset_masked(AgxRobotParams P, AgxEnvBu
   EnvState s{};
   Derived d{};
   V3 tgt{};
-  bool mine = false;
-  int ep = 0;
+  int mask = 0, ep = 0;
   if (valid) {
     s = load_state(B.state, n, i);
     if (WITH_OBS) {
       d = load_derived(B.derived, n, i);
       tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
     }
-    mine = B.reset_mask[i] != 0;
+    mask = B.reset_mask[i];  // compared below, behind the last load (see reset_masked_quad_obs_body)
     if (B.episode_count) ep = B.episode_count[i];
   }
-  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  const int flag = B.reset_flag[B.flag_parity];  // (one word: the branch is taken by whole waves)
+  const bool any = flag != 0, mine = mask != 0;
   reset_and_observe<M, WITH_OBS>(P, B, n, R, i, valid, any, mine && any, ep, tgt, obs, s, d);
   if (WITH_OBS) step_rows_signal(B);
 }
@@ -1694,14 +1747,14 @@ __global__ void __launch_bounds__(256) k_nav_robot_side(AgxRobotParams P, AgxEnv
   if (i == 0) B.reset_flag[B.flag_parity ^ 1] = 0;  // the NEXT step's flag; nobody reads or writes it now
   const bool valid = i < n;
   EnvState s{};
-  bool mine = false;
-  int ep = 0;
+  int mask = 0, ep = 0;
   if (valid) {
     s = load_state(B.state, n, i);
-    mine = B.reset_mask[i] != 0;
+    mask = B.reset_mask[i];  // compared below, behind the last load (see reset_masked_quad_obs_body)
     if (B.episode_count) ep = B.episode_count[i];
   }
-  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  const int flag = B.reset_flag[B.flag_parity];  // (one word: the branch is taken by whole waves)
+  const bool any = flag != 0, mine = mask != 0;
   reset_and_observe<M, false>(P, B, n, R, i, valid, any, mine && any, ep, V3{}, nullptr, s, Derived{});
   if (!valid) return;
   const int ns = A.num_sensors;
@@ -1726,8 +1779,13 @@ __global__ void __launch_bounds__(256) k_nav_robot_side(AgxRobotParams P, AgxEnv
 // k_reset_masked<4, WITH_OBS> with four lanes per env (see k_env_step_quad_position): the refresh of every env's derived
 // tensors and the observation are vector work; the reset of an env itself (rare: a few of 8192 per step) stays the scalar
 // code, run by the first lane of the env's quad, which then hands the new state to the other three.
-__global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
-                                                                 const float *__restrict__ target, float *__restrict__ obs) {
+// HOST_DRAWS: the strict mode's uniforms come from tensors the host filled (R.u_state ...).  Its own instance, so that the
+// kernel of the device-RNG mode holds none of those loads: at the join of the two paths the compiler otherwise waits
+// (s_waitcnt vmcnt(N)) for loads that only the other path issued, and on gfx9 that counter also counts the STORES of a
+// resetting env -- the slowest waves of the launch sat out their own stores' round trips twice.
+template <bool HOST_DRAWS>
+AGX_DEV void reset_masked_quad_obs_body(const AgxRobotParams &P, const AgxEnvBuffers &B, int n, const AgxResetArgs &R,
+                                        const float *__restrict__ target, float *__restrict__ obs) {
   const int tid = threadIdx.x;
   const int l = tid & 3, l3 = l < 3 ? l : 2;
   const int i = blockIdx.x * 16 + (tid >> 2);
@@ -1736,20 +1794,30 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
   push_wait_for_slot(B);
   const bool valid = i < n;
   float p = 0.0f, q = 0.0f, v = 0.0f, w = 0.0f, vbody = 0.0f, wbody = 0.0f, tgt = 0.0f;
-  bool mine = false;
-  int ep = 0;
-  if (valid) {  // every load before the flag is looked at
+  int mask = 0, ep = 0, tail_crashed = 0, tail_truncated = 0;
+  float tail_reward = 0.0f;
+  float *const rows = B.step_rows[B.flag_parity];
+  // every load is issued before ANY of them is looked at: one memory round trip.  (The mask is compared below, not here: a
+  // compare inside this block made the compiler wait for the mask byte before it issued the episode count and the flag.)
+  if (valid) {
     p = AGX_QAT(B.state, 0, ol3); q = AGX_QAT(B.state, 3, ol); v = AGX_QAT(B.state, 7, ol3); w = AGX_QAT(B.state, 10, ol3);
     vbody = AGX_QAT(B.derived, 10, ol3); wbody = AGX_QAT(B.derived, 13, ol3);
     tgt = AGX_QAT(target, 0, ol3);
-    mine = B.reset_mask[i] != 0;
+    mask = B.reset_mask[i];
     if (B.episode_count) ep = B.episode_count[i];
+    if (rows) {  // sharded run: reward | terminated | truncated ride behind the observation in the exchange row
+      tail_reward = B.step_reward[i];
+      tail_crashed = B.crashes[i];
+      tail_truncated = B.truncations[i];
+    }
   }
-  const bool any = B.reset_flag[B.flag_parity] != 0;  // (one word: the branch is taken by whole waves)
+  const int flag = B.reset_flag[B.flag_parity];  // (one word: the branch is taken by whole waves)
+  const bool any = flag != 0;
+  const bool mine = mask != 0;
   if (any) {
     const bool lead = mine && l == 0;
     ResetDraws<4> D{};
-    if (R.u_state) {
+    if (HOST_DRAWS) {
       if (lead) host_reset_draws<4>(P, R, i, D);
     } else {
       wave_reset_draws<4>(R, B.env_index_base + i, ep, lead, D);  // draws are keyed by the GLOBAL env index
@@ -1783,7 +1851,7 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
     const float e = tgt - p;
     if (l < 3) { o[l] = e; o[7 + l] = vbody; o[10 + l] = wbody; }
     o[3 + l] = q;
-    if (float *rows = B.step_rows[B.flag_parity]) {
+    if (rows) {
       float *r = rows + (size_t)i * 16;
       if (B.push_world > 0) {
         // peer push: lane l stores elements 4 l .. 4 l + 3 of the row (e0 e1 e2 q0 | q1 q2 q3 vb0 | vb1 vb2 wb0 wb1 | wb2 reward
@@ -1793,9 +1861,9 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
         const float vb0 = q4::bc<0>(vbody), vb1 = q4::bc<1>(vbody), wb0 = q4::bc<0>(wbody), wb1 = q4::bc<1>(wbody), wb2 = q4::bc<2>(wbody);
         float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
         if (l == 3) {
-          t1 = B.step_reward[i];
-          t2 = B.crashes[i] ? 1.0f : 0.0f;
-          t3 = B.truncations[i] ? 1.0f : 0.0f;
+          t1 = tail_reward;
+          t2 = tail_crashed ? 1.0f : 0.0f;
+          t3 = tail_truncated ? 1.0f : 0.0f;
         }
         const float x0 = q4::by_lane(l, e, q, vb1, wb2);      // e0 (own) | q1 (own) | vb1 | wb2
         const float x1 = q4::by_lane(l, e1, q2, vbody, t1);   // e1 | q2 | vb2 (own) | reward
@@ -1805,11 +1873,24 @@ __global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams 
       } else {
         if (l < 3) { row_store(B, r + l, e); row_store(B, r + 7 + l, vbody); row_store(B, r + 10 + l, wbody); }
         row_store(B, r + 3 + l, q);
-        if (l == 0) write_step_row_tail(B, i, r, 13);
+        if (l == 0) {  // write_step_row_tail on the values loaded at the top
+          row_store(B, r + 13, tail_reward);
+          row_store(B, r + 14, tail_crashed ? 1.0f : 0.0f);
+          row_store(B, r + 15, tail_truncated ? 1.0f : 0.0f);
+        }
       }
     }
   }
   step_rows_signal(B);
+}
+__global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
+                                                                 const float *__restrict__ target, float *__restrict__ obs) {
+  reset_masked_quad_obs_body<false>(P, B, n, R, target, obs);
+}
+__global__ void __launch_bounds__(64, 1) k_reset_masked_quad_obs_host_draws(AgxRobotParams P, AgxEnvBuffers B, int n, AgxResetArgs R,
+                                                                            const float *__restrict__ target,
+                                                                            float *__restrict__ obs) {
+  reset_masked_quad_obs_body<true>(P, B, n, R, target, obs);
 }
 
 // AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295)
@@ -2152,7 +2233,11 @@ extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffe
   const int block = pick_block(n);
   const char *qe = getenv("AGX_ENV_STEP_QUAD");
   if (block == 64 && P->num_motors == 4 && !(qe && qe[0] == '0')) {
-    hipLaunchKernelGGL(k_reset_masked_quad_obs, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, *R, target, obs);
+    if (R->u_state)
+      hipLaunchKernelGGL(k_reset_masked_quad_obs_host_draws, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, *R,
+                         target, obs);
+    else
+      hipLaunchKernelGGL(k_reset_masked_quad_obs, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, *R, target, obs);
     return check_launch("agx_post_step_position");
   }
   AGX_DISPATCH_M(P->num_motors, hipLaunchKernelGGL((k_reset_masked<kM, true>), dim3(blocks_for(n, block)), dim3(block), 0,

@@ -223,8 +223,45 @@ def valu_roofline(kernel_key, launch_s):
     if n_valu is None:
         return dict(out, achieved=None, frac_of_measured=None, frac_of_guide=None)
     ach = n_valu / launch_s
-    return dict(out, achieved=ach / 1e9, frac_of_measured=ach / peak, frac_of_guide=ach / VALU_PEAK_GUIDE,
-                valu_wave_instructions_per_launch=n_valu, stale=pmc_stale())
+    out = dict(out, achieved=ach / 1e9, frac_of_measured=ach / peak, frac_of_guide=ach / VALU_PEAK_GUIDE,
+               valu_wave_instructions_per_launch=n_valu, stale=pmc_stale())
+    busy = valu_busy_time(kernel_key, n_valu, peak)
+    if busy:
+        out["pipe_busy"] = dict(busy, frac_of_launch=busy["seconds_lower_bound"] / launch_s)
+    return out
+
+
+def valu_busy_time(kernel_key, n_valu, plain_rate):
+    """How long the vector pipes are busy per launch, from the kernel's instruction CLASSES (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 /
+    _F64, _INT32, _INT64, _CVT: committed PMC passes) times the issue rate of each class as measured on this GPU
+    (profiles/src/valu_peak.hip: v_fma_f64, v_mul / v_add_f64, v_rcp / v_sqrt_f32, v_rcp_f64, the f32 <-> f64 conversions; same
+    16-chain, 8-waves-per-SIMD shape as the plain-fp32 ceiling).  An instruction COUNT against the plain-fp32 ceiling says how
+    many slots were used; this says how much of the launch the pipe had no slot left -- for the env-step kernels, whose
+    elementary functions are evaluated in float64, the two differ.  A lower bound: integer multiplies (Philox) are counted at the
+    plain rate with the rest of INT32, and whatever no class counter sees (moves, selects, compares, DPP) likewise."""
+    mix = (_pmc().get("sq_breakdown", {}).get(kernel_key) or {}).get("valu_class_mix")
+    if not mix:
+        return None
+    rates = None
+    for name in ("r04_valu_peak.json",):
+        try:
+            rates = json.load(open(os.path.join(ROOT, "profiles", name))).get("class_wave_instr_per_s")
+        except Exception:  # noqa: BLE001
+            rates = None
+    if not rates:
+        return None
+    def rate(cls):
+        r = rates.get(cls)
+        return (sum(r.values()) / len(r)) if r else plain_rate
+    cls_rate = {"ADD_F64": rate("MUL_F64+ADD_F64"), "MUL_F64": rate("MUL_F64+ADD_F64"), "FMA_F64": rate("FMA_F64"),
+                "TRANS_F32": rate("TRANS_F32"), "TRANS_F64": rate("TRANS_F64"), "CVT": rate("CVT")}
+    t, by = 0.0, {}
+    for cls, count in mix.items():
+        r = cls_rate.get(cls, plain_rate)
+        by[cls.split(" ")[0]] = {"wave_instr": count, "rate_g_per_s": r / 1e9, "us": count / r * 1e6}
+        t += count / r
+    return {"seconds_lower_bound": t, "us_lower_bound": t * 1e6, "by_class": by,
+            "plain_only_us": n_valu / plain_rate * 1e6}
 
 
 def roofline_block(kernel, launch_s, algorithmic_bytes, key, copy_gbs=None, timing=None, note=None, bound="hbm", **extra):

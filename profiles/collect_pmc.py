@@ -42,9 +42,14 @@ def load(path, counter):
 SQ_COUNTERS = ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY",
                "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
                "SQ_INSTS_LDS", "SQ_ACTIVE_INST_SCA", "SQ_INST_CYCLES_SALU", "SQ_INSTS_SALU")
+# round 4: the instruction CLASSES of the vector instructions (two more passes): what the vector pipe is busy with is not a count
+# of instructions against the plain-fp32 issue ceiling when a kernel evaluates functions in float64, divides and runs Philox
+VALU_CLASSES = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+                "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT")
 
 
-def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None):
+def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None, sq3_csv=None, sq4_csv=None):
     """build_id: what the library the counters were collected on reported (agx_build_id; pmc_probe.py writes it next to
     the CSVs): bench.py marks every number taken from this file stale when the library it runs on says something else."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -70,10 +75,10 @@ def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None):
         # where the issue slots go: every SQ counter of the pass(es), per launch, for the ray-cast and
         # env-step kernels; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves
         sq = {}
-        for path in (sq_csv, sq2_csv):
+        for path in (sq_csv, sq2_csv, sq3_csv, sq4_csv):
             if not path or not os.path.exists(path):
                 continue
-            for name in SQ_COUNTERS:
+            for name in SQ_COUNTERS + VALU_CLASSES:
                 vals, _n = load(path, name)
                 for k, v in vals.items():
                     if k[0].startswith(("k_raycast", "k_env_step")):
@@ -90,6 +95,11 @@ def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None):
                         d[name + "_per_VALU"] = d[name] / d["SQ_INSTS_VALU"]
                 if d.get("SQ_ACTIVE_INST_VALU"):
                     d["quad_cycles_per_VALU_instruction"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_INSTS_VALU"]
+                mix = {c[len("SQ_INSTS_VALU_"):]: d[c] for c in VALU_CLASSES if c in d}
+                if mix:
+                    mix["other (moves, selects, compares, bit operations, DPP: not in any class counter)"] = d["SQ_INSTS_VALU"] - sum(mix.values())
+                    d["valu_class_mix"] = mix
+                    d["valu_class_share"] = {k: v / d["SQ_INSTS_VALU"] for k, v in mix.items()}
         out["sq_breakdown"] = sq
     n_cal = 1 << 21
     cal = ("k_update_states", n_cal)
@@ -125,4 +135,4 @@ def main(fetch_csv, write_csv, sq_csv=None, build_id=None, sq2_csv=None):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:8])

@@ -31,7 +31,18 @@ def main(plain, pmc_csv=None, pmc_jsonl=None):
                                        "wave_instr_per_s": p["wave_instr_per_s"],
                                        "cycles_per_wave_instr_at_effective_clock": cycles * p["cus"] * 4 / p["wave_instr"]}
     best = max(rows, key=lambda r: r["wave_instr_per_s"])
-    out = {"wave_instr_per_s": best["wave_instr_per_s"], "best": best,
+    # round 4: issue cost of the other instruction classes (rows with a "class": 16 independent chains, 8 waves per SIMD), in
+    # cycles per wave64 instruction per SIMD at the effective clock of the profiled run when there is one, else at the maximum clock
+    def cycles(r):
+        return (r.get("profiled_run") or {}).get("cycles_per_wave_instr_at_effective_clock") or r["cycles_per_wave_instr_at_max_clock"]
+    class_cycles, class_rate = {}, {}
+    for r in rows:
+        if "class" in r:
+            class_cycles.setdefault(r["class"], {})[r["kind"]] = cycles(r)
+            class_rate.setdefault(r["class"], {})[r["kind"]] = r["wave_instr_per_s"]
+    plain = cycles(best)
+    out = {"wave_instr_per_s": best["wave_instr_per_s"], "best": best, "plain_cycles_per_wave_instr": plain,
+           "class_cycles_per_wave_instr": class_cycles, "class_wave_instr_per_s": class_rate,
            "effective_clock_ghz": (best.get("profiled_run") or {}).get("effective_clock_ghz"),
            "guide": {"cycles_per_wave_instr": 2.0, "max_clock_ghz": 2.4, "wave_instr_per_s": 256 * 4 * 2.4e9 / 2.0,
                      "source": "MI355X_MICROARCH.md, per-instruction cycle constants: v_fma_f32 (wave64) 2 cyc (SIMD-32)"},

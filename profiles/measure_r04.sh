@@ -24,12 +24,17 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python profiles/pmc_probe.py --nav > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/pmc_sq -o p -- python profiles/pmc_probe.py --nav > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc_sq2 -o p -- python profiles/pmc_probe.py --nav > $O/pmc_sq2.log 2>&1
+# instruction classes of the vector instructions (what the pipe is busy with: bench.py valu.pipe_busy), two more passes
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --output-format csv -d $O/pmc_sq3 -o p -- python profiles/pmc_probe.py --nav > $O/pmc_sq3.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT --output-format csv -d $O/pmc_sq4 -o p -- python profiles/pmc_probe.py --nav > $O/pmc_sq4.log 2>&1
 # the other workloads as their own bench lines (+ kernel statistics of the LiDAR one)
 python bench.py --workload depth --steps 200 --warmup 20 > $O/bench_depth.json 2>/dev/null
 python bench.py --workload lidar --steps 100 --warmup 10 > $O/bench_lidar.json 2>/dev/null
 python bench.py --workload lidar_velocity --steps 100 --warmup 10 > $O/bench_lidar_velocity.json 2>/dev/null
 python bench.py --workload lidar_nav --steps 200 --warmup 20 > $O/bench_lidar_nav.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_depth -o p -- python bench.py --workload depth --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/prof_depth.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lidar -o p -- python bench.py --workload lidar --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/prof_lidar.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lidar_nav -o p -- python bench.py --workload lidar_nav --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $O/prof_lidar_nav.err
 AGX_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline > $O/bench_forced_dist_world1.json 2> $O/bench_forced_dist.err
 PYTHONPATH=. python examples/benchmark.py --steps 5000 > $O/reference_benchmark_recipe.txt 2>/dev/null
 PYTHONPATH=. python examples/benchmark.py --rendering --steps 2000 >> $O/reference_benchmark_recipe.txt 2>/dev/null

@@ -50,7 +50,7 @@ def test_env_step_instances_and_spills(meta):
             assert r["vgpr_count"] <= 168  # 3 waves per SIMD
         elif not single:
             assert r["vgpr_count"] <= 256  # 2 waves per SIMD
-            assert r["vgpr_spill_count"] <= 24, (M, C, r)  # M = 8 only; n > 65536 envs with k > 1: not a BASELINE config
+            assert r["vgpr_spill_count"] <= 40, (M, C, r)  # M = 8 only; n > 65536 envs with k > 1: not a BASELINE config
         if r["vgpr_spill_count"] or r["private_segment_fixed_size"]:
             report.append((M, C, single, wide, r["vgpr_spill_count"], r["private_segment_fixed_size"]))
     print("k_env_step instances with spills or a private segment (M, ctrl, single, wide, vgpr spills, bytes):", report)
@@ -66,7 +66,7 @@ def test_four_lanes_per_env_kernel(meta):
     assert r["group_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64 and r["vgpr_count"] <= 128, r
     # the sub-step loop (the six Lee laws of the quadrotor, the fully actuated octarotor) and the reset / observation launch
     loops = {n: r for n, r in meta.items() if "k_env_step_quad_loop<" in n or "k_reset_masked_quad_obs" in n}
-    assert len(loops) == 10
+    assert len(loops) == 11  # 9 sub-step loops + the reset / observation launch in its device-RNG and host-draw instances
     for name, r in loops.items():
         assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["max_flat_workgroup_size"] == 64, (name, r)
         # one-wave workgroups, at most 65 536 envs = 4096 waves: two waves per SIMD keep 32 768 envs resident in one round
