@@ -223,7 +223,7 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 9  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 10  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -278,6 +278,7 @@ _SIGNATURES = {
     "agx_push_advance": (C.c_int, [C.POINTER(AgxEnvBuffers)]),
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "agx_scene_refresh": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_sensor_pose": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_raycast_camera": (
         C.c_int,

@@ -257,6 +257,13 @@ AGX_DEV Q4 quat_from_yaw(float yaw) {
   sincos_bounded(yaw * 0.5f, sy, cy);
   return Q4{0.0f, 0.0f, sy, cy};
 }
+// the yaw of euler_xyz_0_2pi on its own (the lean step needs the vehicle-frame quaternion, not roll and pitch)
+AGX_DEV float yaw_0_2pi(Q4 q) {
+  float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+  float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
+  float yaw = atan2_cw(siny_cosp, cosy_cosp);
+  return pymod(yaw, kTwoPi);
+}
 // utils/math.py:124-146, angles in [0, 2 pi)
 AGX_DEV V3 euler_xyz_0_2pi(Q4 q) {
   float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
@@ -270,10 +277,7 @@ AGX_DEV V3 euler_xyz_0_2pi(Q4 q) {
   } else {
     pitch = asin_cw(sinp);
   }
-  float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
-  float cosy_cosp = q.w * q.w + q.x * q.x - q.y * q.y - q.z * q.z;
-  float yaw = atan2_cw(siny_cosp, cosy_cosp);
-  return V3{pymod(roll, kTwoPi), pymod(pitch, kTwoPi), pymod(yaw, kTwoPi)};
+  return V3{pymod(roll, kTwoPi), pymod(pitch, kTwoPi), yaw_0_2pi(q)};
 }
 
 // pytorch3d matrix_to_quaternion (argmax branch; base_lee_controller.py:188-189 reorders to xyzw)

@@ -172,6 +172,25 @@ AGX_DEV Derived update_states(const EnvState &s) {
   return d;
 }
 
+// The lean step (AGX_LAUNCH_LEAN) does not maintain Euler angles / vehicle-frame velocity, and under the laws that read neither
+// (position, fully actuated; no controller) does not EVALUATE them either: roll and pitch are two of the three float64
+// function evaluations of update_states.  What remains is what the task epilogue and the observation read, the same
+// operations on the same operands: vehicle-frame quaternion (from the yaw), body-frame velocities.
+AGX_DEV Derived update_states_lean(const EnvState &s) {
+  Derived d{};
+  d.qveh = quat_from_yaw(yaw_0_2pi(s.q) * 1.0f);
+  d.vbody = quat_rotate_inverse(s.q, s.v);
+  d.wbody = quat_rotate_inverse(s.q, s.w);
+  return d;
+}
+// ... and the observation behind a reset reads the body-frame velocities only
+AGX_DEV Derived update_states_body(const EnvState &s) {
+  Derived d{};
+  d.vbody = quat_rotate_inverse(s.q, s.v);
+  d.wbody = quat_rotate_inverse(s.q, s.w);
+  return d;
+}
+
 // base_lee_controller.py:120-134
 // ZERO_VEL: the caller's velocity set-point is the constant 0 (position / fully actuated control): rotating it gives 0
 template <bool ZERO_VEL = false>
@@ -550,8 +569,9 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_
       has_drag = has_drag || P.lin_drag_linear[c] != 0.0f || P.lin_drag_quadratic[c] != 0.0f || P.ang_drag_linear[c] != 0.0f ||
                  P.ang_drag_quadratic[c] != 0.0f;
     V3 tlo = s.p, thi = s.p;
+    constexpr bool kLawReadsNoAngles = CTRL == AGX_CTRL_POSITION || CTRL == AGX_CTRL_FULLY_ACTUATED || CTRL == AGX_CTRL_NONE || CTRL == AGX_CTRL_WRENCH;
     for (int sub = 0; sub < k; ++sub) {
-      d = update_states(s);
+      d = (kLawReadsNoAngles && lean) ? update_states_lean(s) : update_states(s);
       float a[AGX_MAX_ACTIONS];
 #pragma unroll
       for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a[c] = clamp_minmax(a_in[c], -10.0f, 10.0f);  // clip_actions
@@ -1703,8 +1723,10 @@ AGX_DEV void reset_and_observe(const AgxRobotParams &P, const AgxEnvBuffers &B, 
   if (valid) {
     EnvState s2 = mine ? reset_env<M>(P, B, n, R, i, ep, D) : s;
     // BaseMultirotor.reset_idx ends with an un-indexed update_states(): every env is refreshed
-    Derived d2 = update_states(s2);
-    if ((B.launch_flags & 4) == 0) store_derived(B.derived, n, i, d2);  // lean: nobody reads them before the next env step rewrites them
+    // (lean: nobody reads the derived tensors before the next env step rewrites them; the observation reads the body velocities)
+    const bool lean = (B.launch_flags & 4) != 0;
+    Derived d2 = lean ? update_states_body(s2) : update_states(s2);
+    if (!lean) store_derived(B.derived, n, i, d2);
     if (WITH_OBS) write_obs_position(B, n, i, tgt, obs, s2, d2);
   }
 }

@@ -18,14 +18,9 @@ constexpr float kBoxEps = 1.0e-3f;
 constexpr int kBvhThreads = 512;
 constexpr int kBvhMaxTris = 2048;
 
-__global__ void __launch_bounds__(256) k_scene_transform(int n, int nt, int na, const float *__restrict__ tri_local,
-                                                          const int32_t *__restrict__ tri_asset,
-                                                          const float *__restrict__ asset_state,
-                                                          const uint8_t *__restrict__ mask, float *__restrict__ tri_world) {
-  const int env = blockIdx.y;
-  if (mask && !mask[env]) return;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nt) return;
+// triangle f of env: local frame -> world frame through its asset's pose
+AGX_DEV void transform_triangle(int env, int f, int nt, int na, const float *__restrict__ tri_local, const int32_t *__restrict__ tri_asset,
+                                const float *__restrict__ asset_state, float *__restrict__ tri_world) {
   const float *as = asset_state + ((size_t)env * na + tri_asset[f]) * 13;
   const V3 t = V3{as[0], as[1], as[2]};
   const Q4 q = Q4{as[3], as[4], as[5], as[6]};
@@ -38,6 +33,20 @@ __global__ void __launch_bounds__(256) k_scene_transform(int n, int nt, int na, 
   }
 }
 
+__global__ void __launch_bounds__(256) k_scene_transform(int n, int nt, int na, const float *__restrict__ tri_local,
+                                                          const int32_t *__restrict__ tri_asset,
+                                                          const float *__restrict__ asset_state,
+                                                          const uint8_t *__restrict__ mask, float *__restrict__ tri_world) {
+  const int env = blockIdx.y;
+  if (mask && !mask[env]) return;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nt) return;
+  transform_triangle(env, f, nt, na, tri_local, tri_asset, asset_state, tri_world);
+}
+
+AGX_DEV void box_from_asset(int env, int k, int n, int na, const float *__restrict__ asset_state, const float *__restrict__ half_extents,
+                            float *__restrict__ boxes);
+
 __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const float *__restrict__ asset_state,
                                                             const float *__restrict__ half_extents,
                                                             const uint8_t *__restrict__ mask, float *__restrict__ boxes) {
@@ -45,6 +54,12 @@ __global__ void __launch_bounds__(256) k_boxes_from_assets(int n, int na, const 
   const int k = blockIdx.y;
   if (env >= n) return;
   if (mask && !mask[env]) return;
+  box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
+}
+
+// collision box k of env (SoA rows [k][11][n]): pose, half extents, bounding-sphere radius
+AGX_DEV void box_from_asset(int env, int k, int n, int na, const float *__restrict__ asset_state, const float *__restrict__ half_extents,
+                            float *__restrict__ boxes) {
   const float *as = asset_state + ((size_t)env * na + k) * 13;
   const float *he = half_extents + ((size_t)env * na + k) * 3;
   float *bx = boxes + (size_t)k * 11 * n + env;
@@ -545,6 +560,33 @@ __global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int np
   }
 }
 
+// The masked refresh of a navigation step in ONE persistent launch: the workgroup that pulls a dirty env from the work list
+// writes that env's world-frame triangles and collision boxes itself, then builds its tree.  As three launches the two small
+// ones cost a dispatch over ALL envs each (40 960 and 3 392 workgroups at 8192 envs x 106 obstacles that look at the mask and
+// leave: 22 + 9 us per step for a few dozen dirty envs).  Same device functions, same arithmetic.
+__global__ void __launch_bounds__(kBvhThreads) k_scene_refresh(int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
+                                                                const int32_t *__restrict__ tri_asset,
+                                                                const float *__restrict__ asset_state,
+                                                                const float *__restrict__ half_extents, float *tri_world,
+                                                                float *__restrict__ boxes, int32_t *__restrict__ work,
+                                                                float *__restrict__ nodes) {
+  __shared__ int next;
+  const int count = work[0];
+  while (true) {
+    if (threadIdx.x == 0) next = atomicAdd(&work[1], 1);
+    __syncthreads();
+    const int idx = next;
+    __syncthreads();  // everybody has read `next` before thread 0 overwrites it; also fences LDS reuse
+    if (idx >= count) break;
+    const int env = work[2 + idx];
+    for (int f = threadIdx.x; f < nt; f += kBvhThreads) transform_triangle(env, f, nt, na, tri_local, tri_asset, asset_state, tri_world);
+    if (boxes)
+      for (int k = threadIdx.x; k < na; k += kBvhThreads) box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
+    __syncthreads();  // the env's triangles are in memory (workgroup scope) before the build reads them
+    bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
+  }
+}
+
 static size_t bvh_lds_bytes(int nt, int npad) {
   const size_t box_floats = (size_t)(nt - 1) * 6 > (size_t)6 * kBvhThreads ? (size_t)(nt - 1) * 6 : (size_t)6 * kBvhThreads;
   return (size_t)npad * 8 + box_floats * 4 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 + 64;
@@ -600,31 +642,65 @@ extern "C" int agx_assets_integrate(int n, int num_assets, float *asset_state, c
   return check_launch("agx_assets_integrate");
 }
 
-extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *tri_world, const uint8_t *mask, float *nodes,
-                             int32_t *work, void *stream) {
-  AGX_REQUIRE(n > 0, "bad num_envs");
+// argument checks and launch shape shared by the two LBVH builders; `kernel`'s dynamic LDS limit is raised once (*attr_set)
+static int bvh_launch_shape(int nt, int prims_per_object, int *npad_out, size_t *lds_out, const void *kernel, bool *attr_set) {
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
-  AGX_REQUIRE(tri_world && nodes, "null buffer");
-  AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
-  const int force_full_sort = prims_per_object & AGX_BVH_FULL_SORT;  // test hook (include/aerial_gym_hip.h)
-  prims_per_object &= ~AGX_BVH_FULL_SORT;
-  AGX_REQUIRE(prims_per_object == 0 || (prims_per_object >= 9 && nt % prims_per_object == 0),
+  const int ppo = prims_per_object & ~AGX_BVH_FULL_SORT;  // (AGX_BVH_FULL_SORT: test hook, include/aerial_gym_hip.h)
+  AGX_REQUIRE(ppo == 0 || (ppo >= 9 && nt % ppo == 0),
               "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;
   while (npad < nt) npad <<= 1;
-  size_t lds = bvh_lds_bytes(nt, npad);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = bvh_lds_bytes(nt, npad);
+  if (!*attr_set) {
     // the kernel also owns 4 bytes of static LDS: the dynamic maximum must leave room for them
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bvh_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024 - 256);
-    AGX_REQUIRE(e == hipSuccess, "hipFuncSetAttribute(k_bvh_build): %s", hipGetErrorString(e));
-    attr_set = true;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    AGX_REQUIRE(e == hipSuccess, "hipFuncSetAttribute(LBVH build): %s", hipGetErrorString(e));
+    *attr_set = true;
   }
   AGX_REQUIRE(lds <= 160 * 1024 - 256, "LBVH build needs %zu bytes of LDS (> 160 KiB)", lds);
+  *npad_out = npad;
+  *lds_out = lds;
+  return AGX_OK;
+}
+
+// AssetManager's geometry refresh behind a reset (asset_manager.py:51-71 -> warp mesh refit, warp_env ...): world-frame
+// triangles, collision boxes and the tree of the envs flagged in `mask`; mask == nullptr: every env (the three stand-alone
+// launches).  One C call; with a mask, two launches (compaction + the persistent k_scene_refresh).
+extern "C" int agx_scene_refresh(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset, const float *asset_state,
+                                 const float *half_extents, int prims_per_object, const uint8_t *mask, float *tri_world,
+                                 float *boxes, float *nodes, int32_t *work, void *stream) {
+  AGX_REQUIRE(n > 0 && nt > 0 && na > 0, "bad sizes n=%d nt=%d na=%d", n, nt, na);
+  AGX_REQUIRE(tri_local && tri_asset && asset_state && tri_world && nodes, "null buffer");
+  AGX_REQUIRE(!boxes || half_extents, "collision boxes need the half extents");
+  if (!mask) {
+    if (int e = agx_scene_transform(n, nt, na, tri_local, tri_asset, asset_state, nullptr, tri_world, stream)) return e;
+    if (int e = agx_bvh_build(n, nt, prims_per_object, tri_world, nullptr, nodes, work, stream)) return e;
+    return boxes ? agx_boxes_from_assets(n, na, asset_state, half_extents, nullptr, boxes, stream) : AGX_OK;
+  }
+  AGX_REQUIRE(work, "a masked refresh needs the work buffer (int32[num_envs + 2])");
+  static bool attr_set = false;
+  int npad = 0;
+  size_t lds = 0;
+  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_scene_refresh), &attr_set)) return e;
+  hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
+  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
+  hipLaunchKernelGGL(k_scene_refresh, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na,
+                     tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes);
+  return check_launch("agx_scene_refresh");
+}
+
+extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *tri_world, const uint8_t *mask, float *nodes,
+                             int32_t *work, void *stream) {
+  AGX_REQUIRE(n > 0, "bad num_envs");
+  AGX_REQUIRE(tri_world && nodes, "null buffer");
+  AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
+  static bool attr_set = false;
+  int npad = 0;
+  size_t lds = 0;
+  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_bvh_build), &attr_set)) return e;
   if (mask) hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
   const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
   hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad,
-                     prims_per_object | force_full_sort, tri_world, mask ? work : nullptr, nodes);
+                     prims_per_object, tri_world, mask ? work : nullptr, nodes);  // (with the AGX_BVH_FULL_SORT bit, if set)
   return check_launch("agx_bvh_build");
 }

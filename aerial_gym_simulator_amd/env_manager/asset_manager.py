@@ -101,8 +101,7 @@ class AssetManager:
             _lib.check(lib.agx_prims_from_assets(N, KP, K, p(sc.prim_asset), p(st), p(sc.prim_local_pos), p(sc.prim_local_quat), mk,
                                                  p(sc.prim_state), stream), "agx_prims_from_assets")
             st = sc.prim_state
-        _lib.check(lib.agx_scene_transform(N, sc.num_tris, KP, p(sc.tri_local), p(sc.tri_asset), p(st), mk, p(sc.tri_world), stream),
-                   "agx_scene_transform")
-        _lib.check(lib.agx_bvh_build(N, sc.num_tris, int(getattr(env, 'bvh_prims_per_object', 12)), p(sc.tri_world), mk,
-                                     p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_bvh_build")
-        _lib.check(lib.agx_boxes_from_assets(N, KP, p(st), p(sc.half_extents), mk, p(sc.boxes_soa), stream), "agx_boxes_from_assets")
+        # triangles -> world frame, collision boxes, LBVH: one call (masked: one persistent launch over the dirty envs)
+        _lib.check(lib.agx_scene_refresh(N, sc.num_tris, KP, p(sc.tri_local), p(sc.tri_asset), p(st), p(sc.half_extents),
+                                         int(getattr(env, 'bvh_prims_per_object', 12)), mk, p(sc.tri_world), p(sc.boxes_soa),
+                                         p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_scene_refresh")

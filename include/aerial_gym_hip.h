@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 9
+#define AGX_ABI_VERSION 10
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -528,6 +528,17 @@ int agx_bvh_build(int num_envs, int num_tris, int prims_per_object, const float 
 int agx_boxes_from_assets(int num_envs, int num_assets, const float *asset_state,
                           const float *half_extents, const uint8_t *mask, float *boxes,
                           void *stream);
+
+/* The three calls above as ONE, for the geometry refresh behind a reset (asset_manager.py:51-71 moves the obstacles of the
+ * envs that reset; env_manager.py:283-295; the reference then refits its Warp meshes: warp_env.py / `mesh.refit()`):
+ * world-frame triangles, collision boxes (boxes may be NULL) and the tree of the envs flagged in `mask`.  With a mask: the
+ * dirty env ids are compacted into `work` and ONE persistent launch transforms, boxes and builds per dirty env -- as three
+ * launches the two small ones are a dispatch over every env each (22 + 9 us per step at 8192 envs x 106 obstacles for a few
+ * dozen dirty envs).  mask == NULL: every env, through the three stand-alone kernels.  Same arithmetic either way.          */
+int agx_scene_refresh(int num_envs, int num_tris, int num_assets, const float *tri_local,
+                      const int32_t *tri_asset, const float *asset_state, const float *half_extents,
+                      int prims_per_object, const uint8_t *mask, float *tri_world, float *boxes,
+                      float *nodes, int32_t *work, void *stream);
 
 /* WarpSensor.update pose composition (warp_sensor.py:177-187).
  * local_pos [N][S][3], local_quat [N][S][4], frame_quat [4] -> pos [N][S][3], quat [N][S][4] */

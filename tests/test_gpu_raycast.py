@@ -243,6 +243,44 @@ def test_rebuild_after_reset_is_idempotent_and_masked(orc):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
 
 
+@pytest.mark.parametrize("n,boxes,mask", [(5, 50, [0, 1, 0, 1, 1]), (3, 106, [1, 1, 1]), (6, 20, [0, 0, 0, 0, 0, 0]), (4, 50, None)])
+def test_scene_refresh_in_one_call_equals_the_three_launches(n, boxes, mask):
+    """agx_scene_refresh (what AssetManager calls behind a reset: one persistent launch over the dirty envs) against
+    agx_scene_transform + agx_bvh_build + agx_boxes_from_assets: world-frame triangles, tree and collision boxes bit for bit,
+    clean envs untouched."""
+    sc = random_box_scene(n, boxes, seed=5)
+    sc2 = random_box_scene(n, boxes, seed=77)
+    I = lambda t: t.view(torch.int32)  # noqa: E731
+    out = []
+    for one_call in (False, True):
+        S = Scene(sc)
+        p, L = S.L.dptr, S.L
+        bx = torch.full((S.na, 11, n), -7.0, device=DEV)
+        S.build()  # every env, from the first poses
+        L.check(S.lib.agx_boxes_from_assets(n, S.na, p(S.asset_state), p(S.half), None, p(bx), S.stream))
+        S.asset_state.copy_(T(sc2["asset_state"]))  # every obstacle moves; only the flagged envs may follow
+        mt = T(np.array(mask, np.uint8)) if mask is not None else None
+        mk = p(mt) if mt is not None else None
+        if one_call:
+            L.check(S.lib.agx_scene_refresh(n, S.nt, S.na, p(S.tri_local), p(S.tri_asset), p(S.asset_state), p(S.half), S.ppo, mk,
+                                            p(S.tri_world), p(bx), p(S.nodes), p(S.work), S.stream))
+        else:
+            L.check(S.lib.agx_scene_transform(n, S.nt, S.na, p(S.tri_local), p(S.tri_asset), p(S.asset_state), mk, p(S.tri_world), S.stream))
+            L.check(S.lib.agx_bvh_build(n, S.nt, S.ppo, p(S.tri_world), mk, p(S.nodes), p(S.work), S.stream))
+            L.check(S.lib.agx_boxes_from_assets(n, S.na, p(S.asset_state), p(S.half), mk, p(bx), S.stream))
+        torch.cuda.synchronize()
+        out.append((S.tri_world.clone(), S.nodes.clone(), bx.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(I(a), I(b))
+    if mask is not None and any(mask) and not all(mask):  # the refresh really was masked
+        S0 = Scene(sc)
+        S0.build()
+        clean = [e for e, m in enumerate(mask) if not m]
+        assert torch.equal(I(out[1][0][clean]), I(S0.tri_world[clean])) and torch.equal(I(out[1][1][clean]), I(S0.nodes[clean]))
+        dirty = [e for e, m in enumerate(mask) if m]
+        assert not torch.equal(I(out[1][0][dirty]), I(S0.tri_world[dirty]))
+
+
 @pytest.mark.parametrize("normalize", [True, False])
 def test_range_limits_fused_into_the_raycast_equal_the_separate_pass(orc, normalize):
     """AgxRangeLimits: the ray-cast kernel stores the limited / normalised pixel == raw ray-cast + agx_sensor_postprocess
