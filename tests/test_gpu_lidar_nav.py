@@ -83,6 +83,17 @@ def test_lidar_image_obs_bit_exact(orc):
     ref_ttc, ref_ds = orc.lidar_image_obs(pc, g["robot_position"], g["robot_linvel"])
     assert np.array_equal(got_ttc, ref_ttc) and np.array_equal(got_ds, ref_ds)     # vs oracle: bit-exact
     assert rel_err(got_ttc, g["clean_ttc"]) < 2e-6 and rel_err(got_ds, g["clean_ds"]) < 2e-6  # vs reference
+    # the kernel reads a 16-byte-aligned cloud with 16-byte loads (four points per three loads); a cloud that starts 4 bytes off
+    # takes the 4-byte path: same bits
+    assert tpc.data_ptr() % 16 == 0
+    shifted = torch.zeros(tpc.numel() + 1, device=DEV)[1:].view_as(tpc)
+    shifted.copy_(tpc)
+    assert shifted.data_ptr() % 16 == 4
+    aligned = tpc
+    tpc = shifted
+    off_ttc, off_ds = run([None] * 5)
+    tpc = aligned
+    assert np.array_equal(off_ttc, got_ttc) and np.array_equal(off_ds, got_ds)
     low = lambda a: np.concatenate([np.zeros((n, 10, 20), np.float32), a], axis=1)  # noqa: E731
     noise_np = [g["noise_mask"], g["noise_val"], g["max_mask"], low(g["low_mask"]), low(g["low_val"])]
     noise_t = [T(a) for a in noise_np]
