@@ -27,6 +27,9 @@
 // need <= 168 VGPRs and fit 3; a limit of 4 (128 VGPRs) spills.  Measured (profiles/r01_soa_addressing.txt).
 #define AGX_DYN_WAVES 3
 #endif
+#ifndef AGX_DYN_WAVES_LEAN_LAWS
+#define AGX_DYN_WAVES_LEAN_LAWS 4  // env_step_single_waves
+#endif
 #ifndef AGX_DYN_WAVES_LOOP
 // the k-loop variants (k > 1 sub-steps per launch) keep the loop-carried motor / action state next to everything the
 // straight-line kernel needs: at 3 waves per SIMD (168 VGPRs) they spilled 24-136 VGPRs to scratch; 2 waves (256) fit.
@@ -91,11 +94,33 @@ struct Wrench {
 
 // SoA element (component c of env i): uniform column base (scalar unit) + one 32-bit byte offset per lane,
 // i.e. the `global_load v, v_off, s[base]` addressing form instead of a 64-bit VGPR address per access.
+// Round 4: as a BUFFER access -- `buffer_load_dword v, v_off, s[descriptor], s_column offen`: the array's base in a 128-bit
+// descriptor (scalar registers, rebuilt where it is used: four scalar instructions), the column offset c n sizeof(T) in a scalar
+// register, the lane's part i sizeof(T) in ONE vector register shared by every access of the kernel.  The pointer form above
+// compiles to that `global_load v, v_off, s[base]` only when the instruction selector finds the offset's 32 -> 64-bit extension
+// in the access's own basic block; behind any run-time condition it does not, and each access cost a 64-bit vector add and a
+// register pair: 288 of the ~2500 vector instructions of k_env_step<4, position, single> and its largest block of live registers
+// (profiles/r04_at_scale_experiments.txt).  n x 16 columns x 4 bytes < 2^32.
 template <class T>
-AGX_DEV T &soa_at(T *base, int c, int n, int i) {
-  T *col = base + (ptrdiff_t)c * (ptrdiff_t)n;
-  return *reinterpret_cast<T *>(reinterpret_cast<char *>(const_cast<typename std::remove_const<T>::type *>(col)) +
-                                (size_t)((unsigned)i * (unsigned)sizeof(T)));
+struct SoaRef {
+  static_assert(sizeof(T) == 4, "32-bit elements");
+  T *base;
+  unsigned col_bytes, lane_bytes;
+  AGX_DEV __amdgpu_buffer_rsrc_t rsrc() const {
+    // raw buffer (stride 0), every offset in range, gfx9 data format word (composable_kernel: CK_BUFFER_RESOURCE_3RD_DWORD)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<typename std::remove_const<T>::type *>(base), 0, -1, 0x00020000);
+  }
+  AGX_DEV operator typename std::remove_const<T>::type() const {
+    return __builtin_bit_cast(typename std::remove_const<T>::type,
+                              __builtin_amdgcn_raw_buffer_load_b32(rsrc(), (int)lane_bytes, (int)col_bytes, 0));
+  }
+  AGX_DEV void operator=(typename std::remove_const<T>::type v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rsrc(), (int)lane_bytes, (int)col_bytes, 0);
+  }
+};
+template <class T>
+AGX_DEV SoaRef<T> soa_at(T *base, int c, int n, int i) {
+  return SoaRef<T>{base, (unsigned)c * (unsigned)n * (unsigned)sizeof(T), (unsigned)i * (unsigned)sizeof(T)};
 }
 #define AGX_AT(p, c) agx::soa_at((p), (c), n, i)
 // The lane-quad kernels index a column by the lane's component (c0 + l): the per-lane part of the address, (l n + i) sizeof(T),
@@ -500,8 +525,15 @@ AGX_DEV float reward_navigation(const float *rp, float cpf, V3 pe, V3 ppe, float
 // WIDE: the launch uses one-wave workgroups (n <= 65536 envs: at most one wave per SIMD is resident anyway), so the
 // kernel is compiled for ONE wave per SIMD and may use the whole 512-entry register file: no spill in any variant.
 // !WIDE: 256-thread workgroups at AGX_DYN_WAVES waves per SIMD for batches that fill the chip several times over.
+// Waves per SIMD a straight-line (SINGLE, 256-thread) instance is compiled for.  With the SoA accesses as buffer accesses (SoaRef)
+// the laws without Euler-angle feedback fit 128 VGPRs without a spill (position: 113; was 148 with 64-bit address pairs): 4 waves.
+constexpr int env_step_single_waves(int M, int CTRL) {
+  return (M <= 6 && (CTRL == AGX_CTRL_NONE || CTRL == AGX_CTRL_POSITION || CTRL == AGX_CTRL_FULLY_ACTUATED || CTRL == AGX_CTRL_WRENCH))
+             ? AGX_DYN_WAVES_LEAN_LAWS
+             : (CTRL == AGX_CTRL_ACCELERATION ? 2 : AGX_DYN_WAVES);  // (the acceleration law: 168-181 VGPRs, spills at 3 waves)
+}
 template <int M, int CTRL, bool SINGLE, bool WIDE>
-__global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? AGX_DYN_WAVES : AGX_DYN_WAVES_LOOP))
+__global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step_single_waves(M, CTRL) : AGX_DYN_WAVES_LOOP))
     k_env_step(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ actions_in, int k_arg, AgxTaskArgs T) {
   const int k = SINGLE ? 1 : k_arg;
   extern __shared__ float traj[];  // [k][3][blockDim] sub-step positions (only with obstacles)

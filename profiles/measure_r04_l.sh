@@ -3,7 +3,7 @@
 # top): the GPU suite, then the default bench line twice (driver form and 5 x 2000 steps).
 #   gpurun --timeout 900 -- 'bash profiles/measure_r04_l.sh'
 set -u
-O=gpurun_out/r04m2
+O=gpurun_out/r04p
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1
@@ -15,7 +15,7 @@ python - <<'P'
 import json
 for f in ("bench_default", "bench_driver_style", "bench_lidar_nav"):
     try:
-        d = json.loads(open("gpurun_out/r04m2/%s.json" % f).read().strip().splitlines()[-1])
+        d = json.loads(open("gpurun_out/r04p/%s.json" % f).read().strip().splitlines()[-1])
     except Exception as e:
         print(f, "unreadable", e); continue
     print(f, d["value"], d["ms_per_step"], d.get("launch_us_detail"))

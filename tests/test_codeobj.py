@@ -47,7 +47,9 @@ def test_env_step_instances_and_spills(meta):
             # live in scalar register pairs -- and did not need: test_wide_env_step_kernels_issue_no_scratch_instruction checks
             # these instances instruction by instruction)
             assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= 64, (M, C, r)
-            assert r["vgpr_count"] <= 168  # 3 waves per SIMD
+            # round 4 (SoA accesses as buffer accesses: no 64-bit address pairs): the laws without Euler-angle feedback -- none,
+            # position, fully actuated, external wrench -- fit 4 waves per SIMD, the acceleration law takes 2, the rest 3
+            assert r["vgpr_count"] <= (128 if C in (0, 1, 7, 8) else (256 if C == 5 else 168)), (M, C, r["vgpr_count"])
         elif not single:
             assert r["vgpr_count"] <= 256  # 2 waves per SIMD
             assert r["vgpr_spill_count"] <= 40, (M, C, r)  # M = 8 only; n > 65536 envs with k > 1: not a BASELINE config
@@ -94,7 +96,8 @@ def test_wide_env_step_kernels_issue_no_scratch_instruction():
         if m:
             cur = m.group(1)
             continue
-        if cur and "k_env_step" in cur and ("scratch_" in line or re.search(r"\bbuffer_(load|store).*\boffen\b", line)):
+        # (gfx950 spills through scratch_* instructions; buffer_load / buffer_store ... offen are the kernels' own SoA accesses)
+        if cur and "k_env_step" in cur and "scratch_" in line:
             scratch[cur] = scratch.get(cur, 0) + 1
         if cur and "k_env_step" in cur and "s_endpgm" in line:
             seen += 1
