@@ -2023,6 +2023,8 @@ using namespace agx;
 static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) {
   AGX_REQUIRE(B != nullptr, "null buffers");
   AGX_REQUIRE(n > 0, "num_envs must be > 0 (got %d)", n);
+  // (SoaRef: a tensor's [<= 16][N] floats are addressed with 32-bit byte offsets from its base)
+  AGX_REQUIRE(n <= (1 << 26), "num_envs %d above 2^26 = 67 108 864 per GPU: shard the job (the SoA accesses use 32-bit byte offsets)", n);
   AGX_REQUIRE(B->flag_parity == 0 || B->flag_parity == 1, "flag_parity must be 0 or 1");
   AGX_REQUIRE((!B->step_rows[0] && !B->step_rows[1]) ||
                   (B->step_rows[0] && B->step_rows[1] && B->step_reward && B->crashes && B->truncations),

@@ -157,6 +157,18 @@ def test_exchange_entry_points_reject_bad_arguments_without_a_gpu():
         StepGather(4, 13, "cpu", backend="rccl_thread")
 
 
+def test_env_count_above_the_32_bit_offset_range_is_refused_without_a_gpu():
+    """The one-lane kernels address a tensor's [<= 16][N] floats with 32-bit byte offsets (buffer accesses): an env count above
+    2^26 per GPU is refused by the argument check of every entry point, before anything is launched."""
+    from aerial_gym_simulator_amd import _lib
+
+    lib = _lib.load()
+    B = _lib.AgxEnvBuffers()
+    assert lib.agx_update_states(B, (1 << 26) + 1, None) != 0
+    assert "2^26" in lib.agx_last_error().decode()
+    assert lib.agx_update_states(B, 0, None) != 0 and "num_envs must be > 0" in lib.agx_last_error().decode()
+
+
 def test_scene_manager_semantics():
     from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
 
