@@ -1,6 +1,7 @@
 #!/bin/bash
-# Round 4: the LiDAR-navigation epilogue of the ray-cast kernel (agx_raycast_lidar_nav + agx_lidar_image_obs_from_range) -- its
-# tests, and the task's step with and without it (bench line + rocprofv3 kernel statistics of each).
+# Round 4 EXPERIMENT (not in the product: apply profiles/src/lidar_nav_raycast_epilogue_experiment_r04.patch first; results in
+# profiles/r04_lidar_nav_epilogue_experiment.txt): the LiDAR-navigation epilogue of the ray-cast kernel (agx_raycast_lidar_nav +
+# agx_lidar_image_obs_from_range) -- its tests, and the task's step with and without it (bench line + rocprofv3 kernel statistics).
 #   gpurun --timeout 900 -- 'bash profiles/measure_r04_m.sh'
 set -u
 O=gpurun_out/r04n
