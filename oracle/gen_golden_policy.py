@@ -27,20 +27,32 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 OUT = gg.OUT
 
 
+# checkpoint -> fixture.  The two lmf2 networks are the ones the reference deploys on the real vehicle
+# (examples/rl_games_example/rl_games_ros_node.py:17-27), trained in position_setpoint_task_acceleration_sim2real /
+# position_setpoint_task_sim2real (lmf2 + lmf2_acceleration_control / lmf2_velocity_control, 17-D observation = position error,
+# quaternion, body-frame velocities, previous action): tests/test_gpu_policy_transfer.py flies them too.
+POLICIES = {
+    "attitude_policy.pth": "policy_attitude_actor.npz",
+    "acc_command_2_multiplier_disturbance.pth": "policy_lmf2_acceleration_actor.npz",
+    "vel_control_lmf2_direct.pth": "policy_lmf2_velocity_actor.npz",
+}
+
+
 def main(ref="/root/reference"):
-    path = os.path.join(ref, "aerial_gym/examples/rl_games_example/networks/attitude_policy.pth")
-    ck = torch.load(path, map_location="cpu", weights_only=False)
-    m = ck["model"]
-    out = {}
-    for i, layer in enumerate(("actor_mlp.0", "actor_mlp.2", "actor_mlp.4", "mu")):
-        out[f"w{i}"] = m[f"a2c_network.{layer}.weight"].numpy().astype(np.float32)
-        out[f"b{i}"] = m[f"a2c_network.{layer}.bias"].numpy().astype(np.float32)
-    out["logstd"] = m["a2c_network.sigma"].numpy().astype(np.float32)
-    out["last_mean_rewards"] = np.float64(float(ck["last_mean_rewards"]))
-    out["epoch"], out["frame"] = np.int64(ck["epoch"]), np.int64(ck["frame"])
-    dst = os.path.join(OUT, "policy_attitude_actor.npz")
-    np.savez_compressed(dst, **out)
-    print(dst, {k: getattr(v, "shape", v) for k, v in out.items()})
+    for src, name in POLICIES.items():
+        path = os.path.join(ref, "aerial_gym/examples/rl_games_example/networks", src)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        m = ck["model"]
+        out = {}
+        for i, layer in enumerate(("actor_mlp.0", "actor_mlp.2", "actor_mlp.4", "mu")):
+            out[f"w{i}"] = m[f"a2c_network.{layer}.weight"].numpy().astype(np.float32)
+            out[f"b{i}"] = m[f"a2c_network.{layer}.bias"].numpy().astype(np.float32)
+        out["logstd"] = m["a2c_network.sigma"].numpy().astype(np.float32)
+        out["last_mean_rewards"] = np.float64(float(ck["last_mean_rewards"]))
+        out["epoch"], out["frame"] = np.int64(ck["epoch"]), np.int64(ck["frame"])
+        dst = os.path.join(OUT, name)
+        np.savez_compressed(dst, **out)
+        print(dst, {k: getattr(v, "shape", v) for k, v in out.items()})
 
 
 if __name__ == "__main__":
