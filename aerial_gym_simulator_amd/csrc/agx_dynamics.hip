@@ -2182,7 +2182,9 @@ extern "C" int agx_update_states(const AgxEnvBuffers *B, int n, void *stream) {
 }
 
 extern "C" int agx_collide_spheres_boxes(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, void *stream) {
-  AGX_REQUIRE(P && B && B->state && B->crashes && n > 0, "bad arguments");
+  AGX_REQUIRE(P && B, "bad arguments");
+  if (int e = check_common(P, B, n)) return e;  // the n <= 2^26 bound the 32-bit SoaRef offsets of the kernel depend on
+  AGX_REQUIRE(B->state && B->crashes, "null env buffer");
   if (!B->boxes || B->num_boxes <= 0) return AGX_OK;  // no obstacles: nothing can be hit
   hipLaunchKernelGGL(k_collide_spheres_boxes, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *B, n, P->collision_radius);
   return check_launch("agx_collide_spheres_boxes");

@@ -20,7 +20,7 @@ from ..registry.env_registry import env_config_registry
 from ..registry.robot_registry import robot_registry
 from ..registry.sim_registry import sim_config_registry
 from ..robots.robot_manager import RobotManagerHIP
-from ..tensors import aos_view, soa, TensorDict
+from ..tensors import aos_view, soa, LeanStepRefused, TensorDict
 from ..utils import roctx
 from ..utils.logging import CustomLogger
 from ..utils.random_source import TorchRandomSource
@@ -335,6 +335,9 @@ class EnvManager(BaseManager):
         g = self.global_tensor_dict
         self._lean = True
         self._buffers.launch_flags = 4
+        logger.warning("lean step enabled (args={'lean_step': True}, %d envs): robot_euler_angles / robot_vehicle_orientation / "
+                       "robot_vehicle_linvel are recomputed from the CURRENT state when read through the dict (tensor references held "
+                       "across steps show NaN until then); robot_actions / robot_prev_actions are not maintained." % self.num_envs)
 
         def refresh(_key):
             if self._derived_stale and self._lean:
@@ -343,7 +346,7 @@ class EnvManager(BaseManager):
 
         def refuse(key):
             if self._lean:
-                raise RuntimeError(f"'{key}' is not maintained by the lean step (args={{'lean_step': True}}); the task keeps the action "
+                raise LeanStepRefused(f"'{key}' is not maintained by the lean step (args={{'lean_step': True}}); the task keeps the action "
                                    "tensors it was handed (task.actions / task.prev_actions)")
 
         for key in ("robot_euler_angles", "robot_vehicle_orientation", "robot_vehicle_linvel", "robot_body_linvel", "robot_body_angvel"):

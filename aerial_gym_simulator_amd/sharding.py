@@ -30,12 +30,9 @@ import torch.distributed as dist
 
 
 def rccl_library_path():
-    """The librccl.so this process already uses (torch bundles its own); None = loader default.
-    AGX_RCCL_PATH overrides it (the world-size-2 tests on a one-GPU box bind a test double: RCCL refuses two ranks
-    on one device)."""
-    override = os.environ.get("AGX_RCCL_PATH")
-    if override:
-        return override
+    """The librccl.so this process already uses (torch bundles its own); None = loader default.  (Another library is bound
+    only through the explicit `StepGather(rccl_library=...)` argument: the world-size-2 tests on a one-GPU box hand in a test
+    double, because RCCL refuses two ranks on one device.  No environment variable reaches this choice.)"""
     cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     return cand if os.path.exists(cand) else None
 
@@ -51,6 +48,9 @@ def semantic_id_offset(rank, envs_per_rank, assets_per_env):
     """Start of this rank's slice of the reference's global segmentation counter
     (env_manager.py:147: 100 + one id per asset, counted across all envs)."""
     return rank * envs_per_rank * assets_per_env
+
+
+_PARKED = []  # exchanges abandoned without a collective close(): kept mapped for the life of the process (StepGather.close)
 
 
 class StepGather:
@@ -71,7 +71,7 @@ class StepGather:
     KERNEL_PUSH_MAX_ROW = 16  # floats: rows up to this size are stored at every destination by the observation kernel itself
 
     def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None, backend="auto", ready="signal",
-                 kernel_push=None):
+                 kernel_push=None, rccl_library=None):
         """backend: "process_group" (torch.distributed collective), "rccl_thread" (the library's worker
         thread on its own RCCL communicator; HIP devices only) or "auto" (rccl_thread when the group runs
         on RCCL and every rank could set it up, else process_group).
@@ -85,6 +85,7 @@ class StepGather:
         launching kernels; the wide rows of the sensor tasks (84 / 340 floats) are produced element by element -- 4-byte
         stores across xGMI -- so they go through the copy kernel, whose launch is nothing next to a millisecond step."""
         self.group = group
+        self._rccl_library = rccl_library  # tests only: path of the collective library `rccl_thread` binds (default: torch's RCCL)
         self.collective = dist.is_initialized()  # a world of one still goes through RCCL (bench debugging aid)
         self.world = dist.get_world_size(group) if self.collective else 1
         self.n, self.obs_dim = num_envs_local, obs_dim
@@ -156,7 +157,7 @@ class StepGather:
         from . import _lib
 
         lib = _lib.load()
-        path = rccl_library_path()
+        path = self._rccl_library or rccl_library_path()
         cpath = path.encode() if path else None
         uid = (C.c_char * 128)()
         # every rank binds RCCL and draws an id (only rank 0's is used): a rank that cannot must be known
@@ -264,12 +265,23 @@ class StepGather:
         return 0, 1
 
     def close(self, collective=True):
-        """Drains and frees the library-side exchange.  COLLECTIVE with the kernel-push path (call it on every rank: a barrier
-        keeps any rank from unmapping a buffer a peer's kernels may still be storing into); `collective=False` -- what the
-        finalizer uses -- skips the barrier: a rank that is torn down alone (garbage collection, an exception path) must
-        never enter a collective its peers will not join.  After close() the gathered buffer is gone (`self.gathered` is None:
-        every slice exchange() handed out aliased the library's allocation, which is freed here -- copy what you keep)."""
+        """Drains and frees the library-side exchange.  With peer push an explicit close() is REQUIRED ON EVERY RANK and is
+        collective (a barrier keeps any rank from unmapping a buffer a peer's kernels may still be storing into).
+        `collective=False` -- what the finalizer uses -- skips the barrier: a rank that is torn down alone (garbage collection,
+        an exception path) must never enter a collective its peers will not join; with no barrier nobody knows whether a peer
+        is still storing into this rank's receive buffer, so that path only stops THIS rank's kernels from pushing and parks
+        the library handle (receive buffer and mappings stay alive until the process exits) instead of freeing it.  After
+        close() the gathered buffer is gone (`self.gathered` is None: every slice exchange() handed out aliased the library's
+        allocation -- copy what you keep)."""
         h, self._native = self._native, None
+        if h is not None and self._push and not collective:
+            if self._kernel_push:
+                torch.cuda.synchronize(self.device)
+                self._env.unbind_peer_push()
+                self._kernel_push = False
+            self.gathered, self._push_mem = None, None
+            _PARKED.append((self._lib, h))  # a peer's store_peer / store_peer4 may still be in flight: never unmapped from here
+            return
         if h is not None and self._kernel_push:
             torch.cuda.synchronize(self.device)
             if collective and dist.is_initialized():

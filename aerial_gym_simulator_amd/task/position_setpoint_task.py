@@ -24,13 +24,10 @@ class PositionSetpointTask(BaseTask):
         super().__init__(task_config)
         cfg = self.task_config
         self.device = cfg.device
-        # Far above 65 536 envs the step is bound by the bytes it moves (4.7 TB/s of the 6.3 TB/s a copy reaches at 2^21 envs): this
-        # task, which reads none of them, lets the fused step stop maintaining the tensors that exist only to be looked at through
-        # the dict (Euler angles, vehicle-frame tensors, robot_actions / robot_prev_actions: 88 of ~330 B per env and step;
-        # `obs_dict[key]` recomputes them on read, references held across steps show NaN).  args={"lean_step": False} keeps them.
+        # args={"lean_step": True} (opt-in, effective above 65 536 envs: EnvManager._enable_lean_step) lets the fused step stop
+        # maintaining the tensors that exist only to be looked at through the dict.  Never implied by num_envs: the dict behaves
+        # the same at every batch size unless the caller asks otherwise.
         args = dict(cfg.args) if isinstance(cfg.args, dict) else cfg.args
-        if isinstance(args, dict) and cfg.num_envs is not None:
-            args.setdefault("lean_step", int(cfg.num_envs) >= 65537)
         self.sim_env = SimBuilder().build_env(
             sim_name=cfg.sim_name, env_name=cfg.env_name, robot_name=cfg.robot_name,
             controller_name=cfg.controller_name, args=args, device=self.device, num_envs=cfg.num_envs,

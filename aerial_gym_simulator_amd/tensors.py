@@ -17,6 +17,10 @@ def aos_view(soa_tensor, start=0, stop=None):
     return soa_tensor[start:stop].t()
 
 
+class LeanStepRefused(RuntimeError):
+    """Raised by a read hook for a key the lean step (args={"lean_step": True}) does not maintain and cannot reconstruct."""
+
+
 class TensorDict(dict):
     """The global tensor dict (the reference's plain dict, env_manager.py:83) with ONE addition: a key can carry a hook that
     runs before its value is handed out.  The lean step (`args={"lean_step": True}`, AGX_LAUNCH_LEAN) uses it to recompute
@@ -54,7 +58,7 @@ class TensorDict(dict):
         stored -- NaN-poisoned by whoever installed the hook -- instead of failing the whole iteration"""
         try:
             return self[key]
-        except RuntimeError:
+        except LeanStepRefused:  # only the refusal: a HIP error raised by a refresh hook propagates
             return dict.__getitem__(self, key)
 
     def values(self):

@@ -6,8 +6,11 @@ EXECUTE THE REFERENCE'S OWN ray-cast kernel bodies and the classes that launch t
     aerial_gym/sensors/warp/warp_kernels/warp_stereo_camera_kernels.py   StereoCameraWarpKernels.*  (4 kernels)
     aerial_gym/sensors/warp/{warp_cam, warp_lidar, warp_stereo_cam, warp_normal_faceID_cam, warp_normal_faceID_lidar}.py
 
-warp-lang is a third-party dependency that is neither vendored under /root/reference nor installable here.  What the
-reference's code is given instead:
+warp-lang is a third-party dependency that is neither vendored under /root/reference nor installable here.  Goldens made with
+this module are therefore "the reference's kernel source executed under an EMULATED Warp" -- NOT outputs of Warp itself:
+`wp.inverse` (mat44, on which hip_sensor.pinhole_kinv's last-ulp behaviour rests), the Woop test and the tie-break rule are
+restatements that have never been cross-checked against a real warp-lang 1.0.0 (where it can be installed, run
+gen_golden_warp_kernels.py against it and diff).  What the reference's code is given instead:
 
   * the scalar / vector / quaternion / matrix BUILT-INS it calls, restated from Warp's published native headers
     (warp/native/vec.h, quat.h, mat.h), every operation a single IEEE binary32 operation (numpy float32 scalars; no FMA

@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_world2_exchange.py::test_{rccl_thread,peer_push}_exchange_world2_*: one of TWO processes sharing the box's
 single GPU (AGX_TEST_EXCHANGE_BACKEND=peer_push: the rows travel through peer-mapped memory, no RCCL and no double involved).  torch.distributed runs on gloo (control traffic only); the library-side exchange (csrc/agx_exchange.hip:
 worker thread, communication stream, device-flag hand-off, done events) binds tests/fakerccl/libfakerccl.so through
-AGX_RCCL_PATH, a stream-ordered shared-memory all-gather, because RCCL refuses two ranks on one device.
+StepGather(rccl_library=...) (path in AGX_TEST_FAKERCCL, read HERE, not by the product), a stream-ordered shared-memory all-gather, because RCCL refuses two ranks on one device.
 
 argv: rank world port mode steps   (mode: signal | event | sync | fail | close_skew)"""
 import os
@@ -37,7 +37,8 @@ d = task.task_obs["observations"].shape[1]
 ready = "event" if mode == "event" else "signal"
 BACKEND = os.environ.get("AGX_TEST_EXCHANGE_BACKEND", "rccl_thread")  # "peer_push": real hipIpcMemHandle mapping between the two processes
 KERNEL_PUSH = {"0": False, "1": True}.get(os.environ.get("AGX_TEST_KERNEL_PUSH", ""), None)  # None: by row size (here: the kernels push)
-sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready, kernel_push=KERNEL_PUSH)
+sg = StepGather(n, d, DEV, env=task.sim_env, reward=task.rewards, backend=BACKEND, ready=ready, kernel_push=KERNEL_PUSH,
+                rccl_library=os.environ.get("AGX_TEST_FAKERCCL") or None)
 assert BACKEND != "peer_push" or sg._kernel_push == (KERNEL_PUSH is not False)
 assert sg.backend == BACKEND
 if BACKEND == "peer_push":  # both processes stored a word and a flag through the other's mapping and saw the other's arrive

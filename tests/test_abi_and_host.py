@@ -271,14 +271,14 @@ def test_sharded_gather_world2_gloo():
 def test_tensor_dict_hooks_cover_every_access_path():
     """values() / items() / copy() / dict(g) / **g of the global tensor dict run the read hooks too (the lean step
     recomputes derived tensors on read); a refusing hook fails a direct read, not a bulk one."""
-    from aerial_gym_simulator_amd.tensors import TensorDict
+    from aerial_gym_simulator_amd.tensors import LeanStepRefused, TensorDict
 
     g = TensorDict(a=1, b=2, c=3)
     seen = []
     g.on_read("a", lambda k: seen.append(k))
 
     def refuse(k):
-        raise RuntimeError("refused " + k)
+        raise LeanStepRefused("refused " + k)
 
     g.on_read("c", refuse)
     assert g["a"] == 1 and g.get("a") == 1 and seen == ["a", "a"]
@@ -295,3 +295,14 @@ def test_tensor_dict_hooks_cover_every_access_path():
     g2 = TensorDict(a=1)
     g2.on_read("a", lambda k: seen.append("g2"))
     assert dict(g2) == {"a": 1} and (lambda **kw: kw)(**g2) == {"a": 1} and seen[-2:] == ["g2", "g2"]
+    # only the lean step's refusal is tolerated by the bulk paths; any other failure of a hook (a HIP error raised by
+    # the refresh) propagates instead of handing out a stale tensor
+    g3 = TensorDict(a=1)
+
+    def broken(k):
+        raise RuntimeError("hipErrorIllegalAddress")
+
+    g3.on_read("a", broken)
+    for bulk in (g3.values, g3.items, g3.copy):
+        with pytest.raises(RuntimeError, match="hipErrorIllegalAddress"):
+            bulk()

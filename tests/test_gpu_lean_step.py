@@ -75,9 +75,10 @@ def test_lean_step_is_refused_where_it_cannot_hold():
         cfg.args, cfg.device = old
 
 
-def test_lean_step_is_the_position_tasks_default_above_65536_envs():
-    """round 4: at-scale default (the step is bound by the bytes it moves there); args={"lean_step": False} opts out.  The dict
-    recomputes a derived tensor on read, into the tensor a cached reference points at."""
+def test_lean_step_is_opt_in_at_every_batch_size():
+    """round 5: the dict behaves the same at every num_envs unless the caller asks for the lean
+    step.  A tensor reference cached BEFORE stepping stays finite and maintained above 65 536 envs; args={"lean_step": True} turns
+    the lean step on there (and logs it), where a dict read recomputes into the tensor a cached reference points at."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -85,17 +86,21 @@ def test_lean_step_is_the_position_tasks_default_above_65536_envs():
     old = (cfg.args, cfg.device, cfg.controller_name)
     try:
         cfg.device, cfg.args, cfg.controller_name = DEV, {}, "lee_position_control"
-        small = task_registry.make_task("position_setpoint_task", seed=2, num_envs=8192, headless=True)
-        assert not small.sim_env._lean
         big = task_registry.make_task("position_setpoint_task", seed=2, num_envs=70000, headless=True)
-        assert big.sim_env._lean and big.sim_env._buffers.launch_flags == 4
-        raw = dict.__getitem__(big.obs_dict, "robot_euler_angles")  # a reference taken behind the dict's back
+        assert not big.sim_env._lean and big.sim_env._buffers.launch_flags == 0
+        cached = big.obs_dict["robot_euler_angles"]
         big.reset()
-        big.step(torch.zeros(70000, 4, device=DEV))
-        fresh = big.obs_dict["robot_euler_angles"]  # a dict read recomputes from the current state, into the same tensor
+        for _ in range(3):
+            big.step(torch.rand(70000, 4, device=DEV) * 2 - 1)
+        assert torch.isfinite(cached).all() and cached.abs().sum() > 0
+        assert big.obs_dict["robot_prev_actions"].shape == (70000, 4)
+        cfg.args = {"lean_step": True}
+        lean = task_registry.make_task("position_setpoint_task", seed=2, num_envs=70000, headless=True)
+        assert lean.sim_env._lean and lean.sim_env._buffers.launch_flags == 4
+        raw = dict.__getitem__(lean.obs_dict, "robot_euler_angles")  # a reference taken behind the dict's back
+        lean.reset()
+        lean.step(torch.zeros(70000, 4, device=DEV))
+        fresh = lean.obs_dict["robot_euler_angles"]  # a dict read recomputes from the current state, into the same tensor
         assert fresh.data_ptr() == raw.data_ptr() and torch.isfinite(fresh).all()
-        cfg.args = {"lean_step": False}
-        full = task_registry.make_task("position_setpoint_task", seed=2, num_envs=70000, headless=True)
-        assert not full.sim_env._lean
     finally:
         cfg.args, cfg.device, cfg.controller_name = old

@@ -56,7 +56,7 @@ def _run_world2_once(mode, steps, extra_env, timeout):
     port = _rendezvous_port()
     # (the double's rendezvous bound is generous here: on a loaded box one rank's set-up can trail the other's by tens of
     #  seconds; the failure-path test sets its own, short one)
-    env = dict(os.environ, AGX_RCCL_PATH=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", AGX_FAKERCCL_TIMEOUT_S="150")
+    env = dict(os.environ, AGX_TEST_FAKERCCL=lib, HSA_ENABLE_IPC_MODE_LEGACY="0", AGX_FAKERCCL_TIMEOUT_S="150")
     env.update(extra_env or {})
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exchange_world2_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), mode, str(steps)], env=env, stdout=subprocess.PIPE,
