@@ -11,10 +11,17 @@ from dataclasses import dataclass
 
 import numpy as np
 
-CYLINDER_SECTIONS = 9  # 2 * 9 side + 2 * 9 cap triangles = 36 = 3 x 12: the scene works in chunks of 12 triangles
-
-
-SPHERE_SEGMENTS, SPHERE_BANDS = 8, 7  # 2 * 8 cap + 5 * 16 band triangles = 96 = 8 x 12
+# Curved primitives are tessellated as the reference's loader tessellates them (assets/warp_asset.py:19-24: urdfpy's
+# `URDF.load(...).visual_trimesh_fk()`, i.e. urdfpy 0.0.22 `Cylinder.meshes` = trimesh.creation.cylinder(radius, height),
+# `Sphere.meshes` = trimesh.creation.icosphere(radius=radius), `Box.meshes` = trimesh.creation.box(extents)), with trimesh's
+# published defaults: a cylinder is the revolution of the profile (0,-h/2) (r,-h/2) (r,h/2) (0,h/2) in 32 sections about z
+# (128 triangles: per section bottom-cap, two side, top-cap), a sphere is the icosahedron subdivided 3 times with every new
+# vertex pushed out to the radius (1280 triangles).  Neither library is installed here nor vendored under /root/reference
+# (setup.py / requirements.txt name them, trimesh unpinned): PARITY UNPINNED -- restated from the libraries' published
+# sources, triangle ORDER included (it decides face ids and exact-tie breaks).  Round 4 used a 9-gon prism and a 96-triangle
+# lat/long sphere sized to the scene's 12-triangle chunks; now the chunks are filled by padding with duplicates instead.
+CYLINDER_SECTIONS = 32
+SPHERE_SUBDIVISIONS = 3
 
 
 @dataclass
@@ -179,37 +186,64 @@ def _pad12(tris):
     return np.concatenate([tris, np.repeat(tris[-1:], pad, axis=0)], axis=0) if pad else tris
 
 
+def _revolve(profile, sections):
+    """trimesh.creation.revolve(linestring, sections) for a closed revolution: vertices [sections x len(profile)] =
+    (x cos t, x sin t, y) at t = 2 pi k / sections, per section one quad (two triangles (i, i+per, i+1), (i+1, i+per, i+per+1))
+    for every profile segment AND the wrap-around one; the triangles of ONE section that have no area (those touching the axis
+    twice) are dropped from every section.  Returns [T, 3, 3] float64 in trimesh's face order."""
+    profile = np.asarray(profile, np.float64)
+    per = len(profile)
+    theta = np.linspace(0.0, 2.0 * math.pi, sections + 1)
+    pts = np.column_stack((np.cos(theta), np.sin(theta)))
+    radius, height = profile[:, 0], profile[:, 1]
+    verts = np.column_stack((np.tile(pts, (1, per)).reshape((-1, 2)) * np.tile(radius, len(pts)).reshape((-1, 1)),
+                             np.tile(height, len(pts))))
+    verts = verts[:-per]  # the closing slice duplicates the first
+    quad = np.array([0, per, 1, 1, per, per + 1])
+    single = np.tile(quad, per).reshape((-1, 3)) + np.tile(np.arange(per), (2, 1)).T.reshape((-1, 1))
+    tri = verts[single % len(verts)]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    single = single[area > 1e-8]  # trimesh.constants.tol.merge
+    faces = (np.tile(single.ravel(), sections).reshape((-1, 3))
+             + np.tile(np.arange(sections) * per, (len(single), 1)).T.reshape((-1, 1))) % len(verts)
+    return verts[faces]
+
+
+_ICO_T = (1.0 + 5.0 ** 0.5) / 2.0
+_ICO_VERTS = np.array([-1, _ICO_T, 0, 1, _ICO_T, 0, -1, -_ICO_T, 0, 1, -_ICO_T, 0, 0, -1, _ICO_T, 0, 1, _ICO_T, 0, -1, -_ICO_T, 0, 1, -_ICO_T,
+                       _ICO_T, 0, -1, _ICO_T, 0, 1, -_ICO_T, 0, -1, -_ICO_T, 0, 1], np.float64).reshape(-1, 3) / math.sqrt(2.0 + _ICO_T)
+_ICO_FACES = np.array([0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11, 1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8, 3, 9, 4, 3, 4, 2, 3, 2,
+                       6, 3, 6, 8, 3, 8, 9, 4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1]).reshape(-1, 3)
+
+
+def _icosphere(radius, subdivisions):
+    """trimesh.creation.icosphere(subdivisions, radius): the unit icosahedron (trimesh.creation.icosahedron's vertex and face
+    tables), `subdivisions` times { every face (a, b, c) -> (a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca) in that order,
+    ab = the mean of a and b; then every vertex moved along its direction to `radius` }.  Triangles carry their vertices, so
+    the vertex numbering trimesh derives from its unique-edge table does not enter.  [T, 3, 3] float64."""
+    tris = _ICO_VERTS[_ICO_FACES]
+    for _ in range(int(subdivisions)):
+        a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+        ab, bc, ca = 0.5 * (a + b), 0.5 * (b + c), 0.5 * (c + a)
+        tris = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], 1).reshape(-1, 3, 3)
+        scalar = np.sqrt((tris ** 2).sum(-1, keepdims=True))
+        tris = tris + (tris / scalar) * (radius - scalar)
+    return tris
+
+
 def tessellate(prim):
-    """[T,3,3] float32 triangles in the primitive's own frame, outward normals (T = 12 box, 36 cylinder, 96 sphere,
-    the file's triangle count rounded up to a multiple of 12 for a mesh)."""
+    """[T,3,3] float32 triangles in the primitive's own frame, outward normals, in the reference loader's triangle order
+    (T = 12 box; 128 -> 132 cylinder; 1280 -> 1284 sphere; a mesh file's count: all rounded up to the scene's chunks of 12
+    with duplicates of the last triangle, which never change a closest hit)."""
     if prim.kind == "box":
         return (_BOX_VERTS[_BOX_FACES] * np.asarray(prim.dims)).astype(np.float32)
     if prim.kind == "mesh":
         return _pad12(np.asarray(prim.tris, np.float32))
     if prim.kind == "sphere":
-        r, nl, nb = prim.dims[0], SPHERE_SEGMENTS, SPHERE_BANDS
-        lat = np.linspace(-0.5 * math.pi, 0.5 * math.pi, nb + 1)
-        lon = 2 * math.pi * np.arange(nl) / nl
-        P = lambda i, j: np.array([r * math.cos(lat[i]) * math.cos(lon[j % nl]), r * math.cos(lat[i]) * math.sin(lon[j % nl]), r * math.sin(lat[i])])  # noqa: E731
-        tris = []
-        for j in range(nl):
-            tris.append([P(0, 0), P(1, j + 1), P(1, j)])            # south cap
-            tris.append([P(nb, 0), P(nb - 1, j), P(nb - 1, j + 1)])  # north cap
-            for i in range(1, nb - 1):
-                a, b, c, d = P(i, j), P(i, j + 1), P(i + 1, j + 1), P(i + 1, j)
-                tris += [[a, b, c], [a, c, d]]
-        return np.asarray(tris, np.float32)
+        return _pad12(_icosphere(float(prim.dims[0]), SPHERE_SUBDIVISIONS).astype(np.float32))
     r, L = prim.dims
-    n = CYLINDER_SECTIONS
-    ang = 2 * math.pi * np.arange(n) / n
-    ring = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)
-    tris = []
-    top, bot = np.array([0, 0, L / 2]), np.array([0, 0, -L / 2])
-    for i in range(n):
-        a, b = ring[i], ring[(i + 1) % n]
-        a0, b0, a1, b1 = np.r_[a, -L / 2], np.r_[b, -L / 2], np.r_[a, L / 2], np.r_[b, L / 2]
-        tris += [[a0, b0, b1], [a0, b1, a1], [top, a1, b1], [bot, b0, a0]]
-    return np.asarray(tris, np.float32)
+    half = abs(float(L)) / 2.0
+    return _pad12(_revolve([[0.0, -half], [r, -half], [r, half], [0.0, half]], CYLINDER_SECTIONS).astype(np.float32))
 
 
 def half_extents(prim):
@@ -227,4 +261,5 @@ def num_triangles(prim):
     kind = prim if isinstance(prim, str) else prim.kind
     if kind == "mesh":
         return len(_pad12(prim.tris))
-    return {"box": 12, "cylinder": 4 * CYLINDER_SECTIONS, "sphere": 2 * SPHERE_SEGMENTS * (SPHERE_BANDS - 1)}[kind]
+    pad = lambda t: t + (-t) % 12  # noqa: E731
+    return {"box": 12, "cylinder": pad(4 * CYLINDER_SECTIONS), "sphere": pad(20 * 4 ** SPHERE_SUBDIVISIONS)}[kind]

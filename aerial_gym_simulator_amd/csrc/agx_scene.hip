@@ -16,7 +16,7 @@ namespace agx {
 
 constexpr float kBoxEps = 1.0e-3f;
 constexpr int kBvhThreads = 512;
-constexpr int kBvhMaxTris = 2048;
+constexpr int kBvhMaxTris = 2944;  // 160 KiB of LDS: 8 B x 4096 padded keys + 44 B per triangle (bvh_lds_bytes); forest_env = 2148
 
 // triangle f of env: local frame -> world frame through its asset's pose
 AGX_DEV void transform_triangle(int env, int f, int nt, int na, const float *__restrict__ tri_local, const int32_t *__restrict__ tri_asset,

@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--num-envs", type=int, default=None, help="envs per GPU (default: 8192; 4096 for the LiDAR workloads, BASELINE configs[3])")
     ap.add_argument("--workload", default="dynamics", choices=["dynamics", "depth", "lidar", "lidar_velocity", "lidar_nav"])
     ap.add_argument("--no-depth", action="store_true", help="skip the +depth config (BASELINE configs[2]) extra keys")
+    ap.add_argument("--no-lidar", action="store_true", help="skip the LiDAR config (BASELINE configs[3]) extra keys")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict_rng (reference torch RNG stream) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for each step's all-gather before the next step")
     ap.add_argument("--exchange", default="auto", choices=["auto", "process_group", "rccl_thread", "peer_push"],
@@ -127,6 +129,7 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=Tr
     t0 = time.perf_counter()
     for i in range(steps):
         one(i)
+    timed_steps.last_host_s = time.perf_counter() - t0  # the host's share: all launches of the region enqueued (rank-local clock)
     if gather_buf is not None:
         gather_buf.flush()  # the last collective is inside the timed region
     torch.cuda.synchronize()
@@ -138,6 +141,27 @@ def timed_steps(task, actions, steps, warmup, world, gather_buf=None, overlap=Tr
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def desynchronise_episodes(task, seed=4321):
+    """Episodes start together at reset(): all envs would truncate in the same step and, until then, in none -- a short timed
+    region right after reset() never sees a reset.  The steady state of a long-running job is episodes
+    spread uniformly over their length: sim_steps <- U{0 .. episode_len - 1}, written through the public tensor the reference
+    exposes too (env_manager.py: `self.sim_steps`); from the next step on, num_envs / episode_len envs truncate in EVERY step."""
+    env = task.sim_env
+    L = int(task.task_config.episode_len_steps)
+    steps = env.global_tensor_dict["sim_steps"]
+    g = torch.Generator(device=steps.device).manual_seed(seed + int(getattr(env, "env_offset", 0)))
+    steps[:] = torch.randint(0, L, (env.num_envs,), device=steps.device, generator=g, dtype=torch.int32)
+    torch.cuda.synchronize()
+    return {"episode_len_steps": L, "expected_truncations_per_step": env.num_envs / L,
+            "how": "sim_steps <- U{0..episode_len-1} after reset(), before the warm-up"}
+
+
+def resets_per_step(task, before, steps):
+    """episodes that ended inside a region, per step (episode_count is bumped by the reset kernels): what the timed steps contained"""
+    now = int(task.sim_env.global_tensor_dict["episode_count"].sum().item())
+    return (now - before) / max(steps, 1), now
 
 
 def hbm_copy_gbs(device, nbytes=1 << 30, reps=10):
@@ -759,6 +783,60 @@ def cpu_baseline_raycast(task, budget_s=8.0, sample_envs=512):
                                       "included in every frame (OpenMP over envs), scenes and poses of the GPU run"}
 
 
+def sensor_leg(args, workload, num_envs, device, rank, world, use_dist, primary_backend, copy_gbs, label, cpu_baseline=True):
+    """One sensor configuration of BASELINE.json (configs[2] camera, configs[3] LiDAR) timed like `value`: a short region with
+    the episodes as reset() leaves them, then de-synchronised episodes (`value`), median of up to 3 regions; on one GPU also
+    the ray-cast launch on its own with its roofline object."""
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    n_gpus = max(world, 1)
+    t2 = make_task(workload, num_envs, device, args.strict_rng, rank)
+    t2.reset()
+    N, A = t2.num_envs, t2.task_config.action_space_dim
+    g = torch.Generator(device=device).manual_seed(4321 + rank)
+    a2 = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(4)]
+    s2 = min(max(args.steps // 10, 20), 300)
+    gb2 = None
+    if use_dist:
+        gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards, backend=primary_backend)
+    w2 = max(args.warmup // 10, 5)
+    ep = int(t2.sim_env.global_tensor_dict["episode_count"].sum().item())
+    dt_sync = timed_steps(t2, a2, s2, w2, world, gb2, overlap=not args.sync_gather)
+    sync_resets, ep = resets_per_step(t2, ep, w2 + s2)
+    desync = desynchronise_episodes(t2)
+    regions = max(1, min(args.regions, 3))
+    dts2 = sorted(timed_steps(t2, a2, s2, w2 if r == 0 else 0, world, gb2, overlap=not args.sync_gather) for r in range(regions))
+    desync["measured_resets_per_step"], ep = resets_per_step(t2, ep, w2 + regions * s2)
+    dt2 = dts2[len(dts2) // 2]
+    leg = None
+    if rank == 0:
+        cfgs = t2.sim_env.robot_manager.warp_sensor.cfg
+        rays = N * cfgs.num_sensors * cfgs.height * cfgs.width
+        leg = {"value": n_gpus * N * s2 / dt2, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": s2, "num_envs_per_gpu": N,
+               "ms_per_step": 1e3 * dt2 / s2, "timed_regions_ms_per_step": [1e3 * x / s2 for x in dts2],
+               "episodes": dict(desync, state="de-synchronised (steady state)"),
+               "value_synchronised_episodes": n_gpus * N * s2 / dt_sync,
+               "synchronised_episodes": {"ms_per_step": 1e3 * dt_sync / s2, "measured_resets_per_step": sync_resets,
+                                         "note": "episodes as reset() leaves them (crashes under random actions still reset envs)"},
+               "workload": label}
+    if rank == 0 and world == 1:
+        kt2 = kernel_time_raycast(t2)
+        per_env = raycast_bytes_per_env(t2)
+        leg.update({
+            "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": rays / kt2,
+            "raycast_roofline": roofline_block("k_raycast (one frame, all envs)", kt2, per_env * N, raycast_key(t2), copy_gbs, bound="valu",
+                                               note="packet traversal: bound by vector-instruction issue and by the latency of its dependent "
+                                                    "node fetches (profiles/r04_raycast_variants.txt), not by HBM bytes")})
+        if cpu_baseline and not args.no_cpu_baseline:
+            leg["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
+            leg["gpu_frames_per_s_kernel"] = N / kt2
+    if gb2 is not None:
+        gb2.close()
+    del t2, gb2
+    torch.cuda.empty_cache()
+    return leg
+
+
 def ensure_ranks(args):
     """`--gpus N` is a request for N ranks, one per GPU, and it is honoured or refused -- never silently reduced:
 
@@ -873,11 +951,24 @@ def main():
               file=sys.stderr, flush=True)
         if comm_ranks != max(world, 1) or comm_rank != rank:
             raise SystemExit(f"the step exchange's communicator reports rank {comm_rank} of {comm_ranks}; the job is rank {rank} of {world}")
+    # Right after reset() every episode is at step 0: a region shorter than episode_len contains no reset at all.  That number is
+    # measured first and kept as `value_synchronised_episodes` (rounds 1-4 reported it as `value` on short runs); then the episodes
+    # are spread uniformly over their length -- the steady state of a long-running job -- and THAT is what `value` times.
+    sync_steps = max(1, min(args.steps, 100))
+    sync_warm = min(args.warmup, 50)
+    ep0 = int(task.sim_env.global_tensor_dict["episode_count"].sum().item())
+    dts_sync = sorted(timed_steps(task, actions, sync_steps, sync_warm if r == 0 else 0, world, gather_buf, overlap=not args.sync_gather)
+                      for r in range(3))
+    sync_resets, ep0 = resets_per_step(task, ep0, sync_warm + 3 * sync_steps)
+    desync = desynchronise_episodes(task)
     # `value` = the MEDIAN of `--regions` timed regions of exactly `--steps` steps each (each bracketed by barrier + device
     # synchronize, maximum over ranks); minimum and maximum are reported next to it.  One region of the driver's 20 steps lasts
     # 0.25 ms: a single scheduler hiccup is +-30 % of it.
-    dts = [timed_steps(task, actions, args.steps, args.warmup if r == 0 else 0, world, gather_buf, overlap=not args.sync_gather)
-           for r in range(max(1, args.regions))]
+    dts, hosts = [], []
+    for r in range(max(1, args.regions)):
+        dts.append(timed_steps(task, actions, args.steps, args.warmup if r == 0 else 0, world, gather_buf, overlap=not args.sync_gather))
+        hosts.append(timed_steps.last_host_s)
+    desync["measured_resets_per_step"], ep0 = resets_per_step(task, ep0, args.warmup + len(dts) * args.steps)
     dts_sorted = sorted(dts)
     dt = dts_sorted[len(dts_sorted) // 2]
     value = n_gpus * N * args.steps / dt
@@ -893,6 +984,16 @@ def main():
         "timed_regions": {"count": len(dts), "steps_each": args.steps, "value_is": "median",
                           "ms_per_step": [1e3 * x / args.steps for x in dts],
                           "value_min": n_gpus * N * args.steps / dts_sorted[-1], "value_max": n_gpus * N * args.steps / dts_sorted[0]},
+        "episodes": dict(desync, state="de-synchronised (steady state: resets in every step)"),
+        "value_synchronised_episodes": n_gpus * N * sync_steps / dts_sync[1],
+        "synchronised_episodes": {"ms_per_step": [1e3 * x / sync_steps for x in dts_sync], "steps_each": sync_steps, "regions": 3,
+                                  "measured_resets_per_step": sync_resets,
+                                  "note": "every episode at the same step (right after reset()): no env truncates inside these regions -- "
+                                          "the reset branch of the step's second launch does no work; what rounds 1-4 reported for short runs"},
+        "host": {"enqueue_us_per_step": sorted(1e6 * h / args.steps for h in hosts)[len(hosts) // 2],
+                 "share_of_step": sorted(h / d for h, d in zip(hosts, dts))[len(hosts) // 2],
+                 "note": "wall time of the Python loop that enqueues a region's launches (before the closing synchronize) over the region's "
+                         "wall time: 1.0 = the host is the bound, the device idles between steps"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -1013,38 +1114,45 @@ def main():
         out["source_hash"] = _b.source_hash()
         out["build_id"] = _l.build_id()  # what the loaded libaerialgym_hip.so says it was built from
         out["binary_matches_sources"] = _l.binary_matches_sources()
-    if not args.no_depth and args.workload == "dynamics":
-        # the "+depth sensor" half of the metric: BASELINE configs[2] on every GPU (= configs[4] when N > 1:
-        # 8192 envs per rank + the per-step all-gather); fewer steps: ~2.5 ms each
+    if args.workload == "dynamics":
         del task, gather_buf
         torch.cuda.empty_cache()
-        t2 = make_task("depth", args.num_envs, device, args.strict_rng, rank)
-        t2.reset()
-        a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
-        s2 = min(max(args.steps // 10, 20), 300)
-        gb2 = None
-        if use_dist:
-            gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards,
-                             backend=primary_backend)
-        dts2 = sorted(timed_steps(t2, a2, s2, max(args.warmup // 10, 5) if r == 0 else 0, world, gb2, overlap=not args.sync_gather)
-                      for r in range(max(1, min(args.regions, 3))))
-        dt2 = dts2[len(dts2) // 2]
+    if not args.no_depth and args.workload == "dynamics":
+        # the "+depth sensor" half of the metric: BASELINE configs[2] on every GPU (= configs[4] when N > 1:
+        # 8192 envs per rank + the per-step all-gather); fewer steps: ~2 ms each
+        leg = sensor_leg(args, "depth", args.num_envs, device, rank, world, use_dist, primary_backend, copy_gbs,
+                         "navigation_task, 8192 envs per GPU, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step"
+                         + (" (BASELINE configs[4] sharding, 1 all_gather/step)" if world > 1 else " (BASELINE configs[2])"))
         if rank == 0:
-            out["plus_depth"] = {"value": n_gpus * N * s2 / dt2, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": s2,
-                                 "ms_per_step": 1e3 * dt2 / s2, "timed_regions_ms_per_step": [1e3 * x / s2 for x in dts2],
-                                 "workload": "navigation_task, 8192 envs per GPU, 64x48 depth+seg camera, 100 boxes + 6 walls, 10 sub-steps/step"
-                                             + (" (BASELINE configs[4] sharding, 1 all_gather/step)" if world > 1 else "")}
-        if rank == 0 and world == 1:
-            kt2 = kernel_time_raycast(t2)
-            per_env = raycast_bytes_per_env(t2)
-            out["plus_depth"].update({
-                "raycast_launch_us": kt2 * 1e6, "rays_per_s_kernel": N * 64 * 48 / kt2,
-                "raycast_roofline": roofline_block("k_raycast (one frame, all envs)", kt2, per_env * N, raycast_key(t2), copy_gbs, bound="valu",
-                                                   note="packet traversal: bound by vector-instruction issue and by the latency of its dependent "
-                                                        "node fetches (profiles/r04_raycast_variants.txt), not by HBM bytes")})
-            if not args.no_cpu_baseline:
-                out["plus_depth"]["cpu_baseline_raycast"] = cpu_baseline_raycast(t2)
-                out["plus_depth"]["gpu_frames_per_s_kernel"] = N / kt2
+            out["plus_depth"] = leg
+    if not args.no_lidar and args.workload == "dynamics" and world == 1:
+        # BASELINE configs[3]: fully-actuated octarotor + 32 x 512 LiDAR range + segmentation, 4096 envs, one GPU
+        leg = sensor_leg(args, "lidar", 4096, device, rank, world, False, primary_backend, copy_gbs,
+                         "navigation_task_fully_actuated_lidar, 4096 envs, base_octarotor + rov_fully_actuated_control (7-D command), 32x512 LiDAR "
+                         "range+seg, 100 boxes + 6 walls, 10 sub-steps/step (BASELINE configs[3])", cpu_baseline=False)
+        if rank == 0:
+            out["plus_lidar"] = leg
+    if not args.no_strict and args.workload == "dynamics" and world == 1 and not args.strict_rng:
+        # the configuration whose parity with the reference's SEEDS is proven (tests: strict traces): every draw through torch's
+        # generator with the reference's calls, shapes and order, and -- like the reference's nonzero() -- one host read of the
+        # reset flag per step (env_manager.py:364-375, base_multirotor.py:177-205)
+        try:
+            ts = make_task("dynamics", args.num_envs, device, True, rank)
+            ts.reset()
+            dstrict = desynchronise_episodes(ts)
+            epS = int(ts.sim_env.global_tensor_dict["episode_count"].sum().item())
+            ss = min(args.steps, 500)
+            dS = sorted(timed_steps(ts, actions, ss, min(args.warmup, 50) if r == 0 else 0, world, None) for r in range(3))
+            dstrict["measured_resets_per_step"], _ = resets_per_step(ts, epS, min(args.warmup, 50) + 3 * ss)
+            out["value_strict_rng"] = N * ss / dS[1]
+            out["strict_rng"] = {"value": N * ss / dS[1], "unit": "env-steps/s", "ms_per_step": 1e3 * dS[1] / ss, "steps": ss,
+                                 "timed_regions_ms_per_step": [1e3 * x / ss for x in dS], "episodes": dstrict,
+                                 "rng": "strict (reference torch stream: rand_like for all N envs per draw in the reference's order, one host "
+                                        "synchronisation per step to learn whether any env resets)",
+                                 "workload": "same task / config / sizes as `value`"}
+            del ts
+        except Exception as e:  # noqa: BLE001
+            out["strict_rng"] = {"error": f"{type(e).__name__}: {e}"}
     if use_dist and args.exchange == "auto" and args.workload == "dynamics":
         try:
             del t2, gb2

@@ -139,10 +139,18 @@ def test_urdf_primitives_forward_kinematics_and_tessellation():
                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
         assert np.allclose(R, p.T[:3, :3], atol=1e-12) and w >= 0
         tris = tessellate(p).astype(np.float64)
-        assert tris.shape == (36, 3, 3)
+        # trimesh.creation.cylinder's default: 32 sections, per section (bottom cap, side, side, top cap) = 128 triangles, padded to
+        # the scene's chunks of 12 with duplicates of the last one
+        assert tris.shape == (132, 3, 3) and np.array_equal(tris[128:], np.repeat(tris[127:128], 4, axis=0))
+        tris = tris[:128]
         vol = np.einsum("ij,ij->i", tris[:, 0], np.cross(tris[:, 1], tris[:, 2])).sum() / 6  # closed, outward normals
         r, L = p.dims
-        assert abs(vol - 0.5 * 9 * r * r * np.sin(2 * np.pi / 9) * L) < 1e-6 * max(vol, 1)
+        assert abs(vol - 0.5 * 32 * r * r * np.sin(2 * np.pi / 32) * L) < 1e-6 * max(vol, 1)
+        # first section, in the order trimesh.creation.revolve emits it (profile (0,-h) (r,-h) (r,h) (0,h), theta 0 -> 2 pi / 32)
+        c, s_ = np.cos(2 * np.pi / 32), np.sin(2 * np.pi / 32)
+        want = np.array([[[r, 0, -L / 2], [0, 0, -L / 2], [r * c, r * s_, -L / 2]], [[r, 0, -L / 2], [r * c, r * s_, -L / 2], [r, 0, L / 2]],
+                         [[r, 0, L / 2], [r * c, r * s_, -L / 2], [r * c, r * s_, L / 2]], [[r, 0, L / 2], [r * c, r * s_, L / 2], [0, 0, L / 2]]])
+        assert np.allclose(tris[:4], want, atol=1e-6)
         assert np.abs(tris[..., 2]).max() <= L / 2 + 1e-6 and np.abs(np.linalg.norm(tris[..., :2], axis=-1)).max() <= r + 1e-6
         assert half_extents(p) == (r, r, L / 2)
     mixed = load_urdf_primitives(os.path.join(FIX, "trees", "tree_b.urdf"))
@@ -170,7 +178,7 @@ def test_multi_primitive_scene_layout():
     random.seed(0)
     sc = SceneManager(Cfg, 6, "cpu", None)
     assert sc.has_prims and sc.num_assets == 38 and sc.keep_in_env_num == 3
-    assert sc.num_prims == 1 + 2 * 3 + 35 and sc.num_tris == 12 + 2 * 3 * 36 + 35 * 12
+    assert sc.num_prims == 1 + 2 * 3 + 35 and sc.num_tris == 12 + 2 * 3 * 132 + 35 * 12
     d = sc._np
     pa = d["prim_asset"]
     assert all(sorted(set(pa[i])) == list(range(38)) for i in range(6))        # every asset owns at least one primitive
@@ -181,8 +189,8 @@ def test_multi_primitive_scene_layout():
     assert two_link, "tree_b.urdf (box stump + pole) was never drawn"
     i, s = two_link[0]
     assert np.array_equal(d["prim_half"][i, s + 2], d["prim_half"][i, s]) and d["prim_sem"][i, s + 2] == d["prim_sem"][i, s]
-    t0 = d["tri_local"][i, 12 + (s - 1) * 36: 12 + s * 36]
-    assert np.array_equal(t0[:12], t0[12:24])  # a box in a 36-triangle slot: its 12 triangles repeated
+    t0 = d["tri_local"][i, 12 + (s - 1) * 132: 12 + s * 132]
+    assert np.array_equal(t0[:12], t0[12:24]) and np.array_equal(t0[:12], t0[120:132])  # a box in a 132-triangle slot: its 12 triangles repeated
     sem = d["prim_sem"]
     assert sem[0, 0] == 13 and sem[0, 1] == 100 and set(np.diff(sem[0, 1:4])) <= {0, 1}  # floor id, then per-link ids from 100
 
@@ -233,10 +241,74 @@ def test_mesh_and_sphere_geometry_ingestion():
         c0 = np.array([0.1, 0, 0.05]) + np.array([[np.cos(0.3), -np.sin(0.3), 0], [np.sin(0.3), np.cos(0.3), 0], [0, 0, 1]]) @ np.array([0.4, 0.32, 0.36])
         assert np.allclose(p.T[:3, 3], c0)
     post, ball = load_urdf_primitives(os.path.join(M, "ball_on_post.urdf"))
-    assert (post.kind, ball.kind) == ("cylinder", "sphere") and num_triangles(ball) == 96
+    # trimesh.creation.icosphere's default: the icosahedron subdivided 3 times = 1280 triangles (642 distinct vertices), padded to 1284
+    assert (post.kind, ball.kind) == ("cylinder", "sphere") and num_triangles(ball) == 1284 and num_triangles(post) == 132
     s = tessellate(ball)
+    assert len(np.unique(np.round(s.reshape(-1, 3).astype(np.float64), 5), axis=0)) == 642
     assert np.allclose(np.linalg.norm(s.reshape(-1, 3), axis=1), 0.35, atol=1e-6) and np.allclose(ball.T[:3, 3], (0, 0, 1.0))
     vol = sum(np.dot(x[0], np.cross(x[1], x[2])) for x in s.astype(np.float64)) / 6.0
-    assert 0.6 * (4 / 3) * np.pi * 0.35 ** 3 < vol < (4 / 3) * np.pi * 0.35 ** 3  # closed, outward, inscribed
+    assert 0.98 * (4 / 3) * np.pi * 0.35 ** 3 < vol < (4 / 3) * np.pi * 0.35 ** 3  # closed, outward, inscribed
     with pytest.raises(NotImplementedError, match="OBJ, STL"):
         load_mesh_triangles(os.path.join(M, "missing.dae"))
+
+
+def _forest_scene(tree_folder, n_envs=4):
+    import random
+
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import asset_config as A
+    from aerial_gym_simulator_amd.config.env_config import ForestEnvCfg
+    from aerial_gym_simulator_amd.env_manager.scene_manager import SceneManager
+
+    class trees(A.tree_asset_params):
+        asset_folder = tree_folder
+
+    class Cfg(ForestEnvCfg):
+        class env_config:
+            include_asset_type = {"trees": True, "objects": True, "bottom_wall": True}
+            asset_type_to_dict_map = {"trees": trees, "objects": A.object_asset_params, "bottom_wall": A.bottom_wall}
+
+    random.seed(1)
+    return SceneManager(Cfg, n_envs, "cpu", None)
+
+
+def _check_forest_scene_arrays(sc, n_envs):
+    """forest_env at the reference's size (forest_env.py + env_object_config.py:225-312): a floor slab, ONE 13-link cylinder tree
+    (keep_in_env, per-link semantic ids), 35 box objects.  Scene arrays only -- what assets/warp_asset.py:19-136 and
+    warp_env_manager.py:74-95 build: triangle counts per link mesh, the per-link ids 0..12 + the env's running counter."""
+    d = sc._np
+    assert sc.has_prims and sc.num_assets == 37 and sc.keep_in_env_num == 2
+    assert sc.num_prims == 1 + 13 + 35
+    # every cylinder = trimesh.creation.cylinder's 128 triangles (+ 4 duplicates filling the last chunk of 12)
+    assert sc.num_tris == 12 + 13 * 132 + 35 * 12 == 2148
+    tp = d["tri_prim"]
+    assert np.array_equal(np.bincount(tp), [12] + [132] * 13 + [12] * 35)
+    sem = d["prim_sem"]
+    ids_per_env = 13 + 35  # the tree's 13 links + one per object (semantic_id < 0); the floor has its own fixed id
+    for i in range(n_envs):
+        base = 100 + i * ids_per_env
+        assert sem[i, 0] == 13                                             # bottom_wall: configured id
+        assert np.array_equal(sem[i, 1:14], base + np.arange(13))          # per_link_semantic: one id per link, in link order
+        assert sorted(sem[i, 14:]) == list(range(base + 13, base + 48))    # then the objects, one each (shuffled per env)
+    tl = d["tri_local"]
+    for q in range(1, 14):  # each tree primitive: all vertices on its cylinder (radius r on the side rings, 0 on the axis)
+        t = tl[0, 12 + (q - 1) * 132: 12 + q * 132].reshape(-1, 3).astype(np.float64)
+        r, hz = d["prim_half"][0, q, 0], d["prim_half"][0, q, 2]
+        rad = np.linalg.norm(t[:, :2], axis=1)
+        assert np.all((np.abs(rad - r) < 1e-5) | (rad < 1e-7)) and np.allclose(np.abs(t[:, 2]), hz, atol=1e-5)
+        assert len(np.unique(np.round(t, 6), axis=0)) == 2 * 32 + 2
+
+
+def test_forest_env_scene_arrays_at_reference_size_from_the_fixture_tree():
+    """runs everywhere (the GPU box has no reference tree): tests/fixtures/assets/trees13/tree_13.urdf is a synthetic tree with
+    the reference set's structure (make_tree13.py)"""
+    sc = _forest_scene(os.path.join(FIX, "trees13"))
+    _check_forest_scene_arrays(sc, 4)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="reference tree not present (GPU box)")
+def test_forest_env_scene_arrays_from_the_reference_resources():
+    """forest_env built from the reference's own resources/models/environment_assets/trees (100 files, one
+    drawn per env) on the CPU box: the same array checks as the fixture tree"""
+    sc = _forest_scene(os.path.join(REF_ASSETS, "trees"), n_envs=6)
+    _check_forest_scene_arrays(sc, 6)

@@ -12,14 +12,14 @@ DEV = "cuda:0"
 FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fixtures", "assets")
 
 
-def _forest_cfg(num_trees=3):
+def _forest_cfg(num_trees=3, folder="trees"):
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config import asset_config as A
     from aerial_gym_simulator_amd.config.env_config import ForestEnvCfg
 
     class trees(A.tree_asset_params):
         num_assets = num_trees
-        asset_folder = os.path.join(FIX, "trees")
+        asset_folder = os.path.join(FIX, folder)
 
     class Cfg(ForestEnvCfg):
         class env_config:
@@ -42,7 +42,7 @@ def test_forest_scene_primitives_images_and_collisions(orc):
     env = SimBuilder().build_env("base_sim", "forest_env_fixture", "base_quadrotor_with_camera_64x48", "lee_velocity_control", DEV, num_envs=n)
     sc = env.scene
     assert sc.has_prims and sc.num_assets == 39 and sc.num_prims == 1 + 3 * 3 + 35  # floor + 3 trees (<= 3 links) + 35 objects
-    assert sc.num_tris == 12 + 3 * 3 * 36 + 35 * 12 and env._buffers.num_boxes == sc.num_prims
+    assert sc.num_tris == 12 + 3 * 3 * 132 + 35 * 12 and env._buffers.num_boxes == sc.num_prims
     env.reset()
     g = env.get_obs()
     a = torch.zeros(n, 4, device=DEV)
@@ -64,7 +64,7 @@ def test_forest_scene_primitives_images_and_collisions(orc):
     assert np.array_equal(npy(g["segmentation_pixels"]), ref_seg) and np.array_equal(npy(g["depth_range_pixels"]), ref)
     # per-link semantic ids of the trees (warp_asset.py:55-93): consecutive ids, one per link, from the global counter
     seg = npy(sc.tri_seg)
-    tree_ids = np.unique(seg[0, 12:12 + 9 * 36])
+    tree_ids = np.unique(seg[0, 12:12 + 9 * 132])
     assert len(tree_ids) >= 2 * 3 and tree_ids.min() >= 100
     # collisions: put each robot on top of a branch of the first tree of its env -> crash; far from everything -> none
     prim = npy(sc.prim_state)
@@ -76,6 +76,47 @@ def test_forest_scene_primitives_images_and_collisions(orc):
     crash_ref = np.zeros(n, np.uint8)
     orc.collide_sphere_boxes(env.robot_manager.robot.params_dict["collision_radius"], npy(state), np.ascontiguousarray(boxes), crash_ref)
     assert crash_ref.all() and npy(g["crashes"]).all()
+
+
+def test_forest_env_at_the_reference_size_renders_like_the_oracle(orc):
+    """forest_env as the reference configures it -- ONE 13-link cylinder tree (tests/fixtures/assets/trees13: a synthetic tree of the
+    reference set's structure), every cylinder trimesh's 32-section mesh, 35 objects, a floor: 2148 triangles per env, above the
+    2048 the LDS-resident tree build took until round 5.  Frames bit-equal to the oracle's brute-force ray-cast of the same
+    triangles, after partial resets through the compacted rebuild."""
+    import random
+
+    from aerial_gym_simulator_amd.registry.env_registry import env_config_registry
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    random.seed(4)
+    torch.manual_seed(4)
+    env_config_registry.register("forest_env_fixture13", _forest_cfg(1, "trees13"))
+    n = 4
+    env = SimBuilder().build_env("base_sim", "forest_env_fixture13", "base_quadrotor_with_camera_64x48", "lee_velocity_control", DEV, num_envs=n)
+    sc = env.scene
+    assert sc.num_prims == 1 + 13 + 35 and sc.num_tris == 12 + 13 * 132 + 35 * 12 == 2148
+    env.reset()
+    g = env.get_obs()
+    a = torch.zeros(n, 4, device=DEV)
+    env.step(actions=a)
+    env.post_reward_calculation_step()
+    env.reset_idx(torch.tensor([1, 3], device=DEV))  # a partial reset: the compacted persistent rebuild
+    env.step(actions=a)
+    env.post_reward_calculation_step()
+    npy = lambda t: np.ascontiguousarray(t.detach().cpu().numpy())  # noqa: E731
+    tris = orc.scene_transform(npy(sc.tri_local), npy(sc.tri_asset), npy(sc.prim_state))
+    assert np.array_equal(npy(sc.tri_world), tris)
+    sen = env.robot_manager.warp_sensor
+    kinv, cx, cy = orc.camera_kinv(64, 48, sen.cfg.horizontal_fov_deg)
+    ref, ref_seg = orc.raycast_camera(64, 48, kinv, sen.cfg.max_range, cx, cy, "depth", npy(sen.sensor_position), npy(sen.sensor_orientation),
+                                      tris, npy(sc.tri_seg))
+    ref = orc.sensor_postprocess(ref, sen.cfg.min_range, sen.cfg.max_range, sen.cfg.far_out_of_range_value, sen.cfg.near_out_of_range_value,
+                                 sen.cfg.normalize_range)
+    seg = npy(g["segmentation_pixels"])
+    assert np.array_equal(seg, ref_seg) and np.array_equal(npy(g["depth_range_pixels"]), ref)
+    tree_ids = set(np.unique(npy(sc.tri_seg)[:, 12:12 + 13 * 132]).tolist())
+    assert len(tree_ids) == 13 * n  # per-link semantic ids (warp_asset.py:55-93), distinct per env
+    assert tree_ids & set(np.unique(seg).tolist()), "no tree pixel in any frame"
 
 
 def test_mesh_and_sphere_obstacles_images_and_collisions(orc):
@@ -90,7 +131,7 @@ def test_mesh_and_sphere_obstacles_images_and_collisions(orc):
     from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
 
     class shapes(A.tree_asset_params):
-        num_assets = 6
+        num_assets = 1  # (one slot = 132 + 1284 triangles since round 5: the LDS-resident tree build takes 2944 per env)
         asset_folder = os.path.join(FIX, "meshes")  # wedge_obj, wedge_stl, ball_on_post: one is drawn per instance
 
     class Cfg(ForestEnvCfg):
@@ -101,11 +142,11 @@ def test_mesh_and_sphere_obstacles_images_and_collisions(orc):
     random.seed(3)
     torch.manual_seed(3)
     env_config_registry.register("mesh_env_fixture", Cfg)
-    n = 6
+    n = 12  # (one shape per env, drawn per env: 12 envs see all three files)
     env = SimBuilder().build_env("base_sim", "mesh_env_fixture", "base_quadrotor_with_camera_64x48", "lee_velocity_control", DEV, num_envs=n)
     sc = env.scene
-    # a slot holds the largest variant: 2 primitives -- (wedge 12 | post 36) and (duplicate | ball 96) -- smaller ones padded with duplicates
-    assert sc.has_prims and sc.num_prims == 1 + 6 * 2 + 35 and sc.num_tris == 12 + 6 * (36 + 96) + 35 * 12
+    # a slot holds the largest variant: 2 primitives -- (wedge 12 | post 132) and (duplicate | ball 1284) -- smaller ones padded with duplicates
+    assert sc.has_prims and sc.num_prims == 1 + 1 * 2 + 35 and sc.num_tris == 12 + 1 * (132 + 1284) + 35 * 12
     env.reset()
     g = env.get_obs()
     a = torch.zeros(n, 4, device=DEV)
