@@ -13,6 +13,8 @@ from . import _build
 MAX_MOTORS = 8
 MAX_ACTIONS = 8
 MAX_SUBSTEPS = 32
+MAX_BODIES = 24
+LAUNCH_LEAN, LAUNCH_BODY_WRENCH = 4, 8  # AgxEnvBuffers.launch_flags bits 2 and 3
 
 CTRL_IDS = {
     "none": 0,
@@ -223,7 +225,16 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
-ABI_VERSION = 10  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+class AgxRobotStepArgs(C.Structure):
+    _fields_ = [("force", C.c_void_p), ("torque", C.c_void_p), ("num_bodies", C.c_int32), ("substep", C.c_int32),
+                ("body_of_motor", C.c_int32 * MAX_MOTORS)]
+
+
+class AgxLinkFrames(C.Structure):
+    _fields_ = [("num_bodies", C.c_int32), ("reserved", C.c_int32), ("rot", (C.c_float * 9) * MAX_BODIES), ("pos", (C.c_float * 3) * MAX_BODIES)]
+
+
+ABI_VERSION = 11  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
@@ -236,6 +247,8 @@ _SIGNATURES = {
     "agx_update_states": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P]),
     "agx_collide_spheres_boxes": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P]),
     "agx_controller_wrench": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, _P]),
+    "agx_robot_step": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.POINTER(AgxRobotStepArgs), _P]),
+    "agx_net_body_wrench": (C.c_int, [C.c_int, C.POINTER(AgxLinkFrames), _P, _P, _P, _P]),
     "agx_reward_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "agx_obs_position": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, _P, _P, _P]),
     "agx_reward_navigation": (

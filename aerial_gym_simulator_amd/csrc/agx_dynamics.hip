@@ -610,10 +610,12 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step
       float a[AGX_MAX_ACTIONS];
 #pragma unroll
       for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a[c] = clamp_minmax(a_in[c], -10.0f, 10.0f);  // clip_actions
+      // EXTERNAL ROBOT (AGX_LAUNCH_BODY_WRENCH, host-evaluated robot.step()): actions_in is the net body wrench itself
+      const bool body_wrench = EXT && (B.launch_flags & AGX_LAUNCH_BODY_WRENCH) != 0;  // wave-uniform
       if (CTRL == AGX_CTRL_NONE) {
 #pragma unroll
         for (int j = 0; j < M; ++j) u[j] = motor_update(P, a[j], u[j], kT[j], tinc[j], tdec[j]);
-      } else {
+      } else if (!body_wrench) {
         if (EXT) wc = Wrench{V3{a_in[0], a_in[1], a_in[2]}, V3{a_in[3], a_in[4], a_in[5]}};  // as handed in, not clipped
       else wc = run_controller<CTRL>(P, s, d, a, g);
         const float w6[6] = {wc.f.x, wc.f.y, wc.f.z, wc.t.x, wc.t.y, wc.t.z};
@@ -631,7 +633,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step
         float acc = 0.0f;
 #pragma unroll
         for (int j = 0; j < M; ++j) acc += (root_link ? P.alloc[M * r + j] : P.wrench_map[M * r + j]) * u[j];
-        bw[r] = acc;
+        bw[r] = body_wrench ? a_in[r] : acc;
       }
       // The ROOT link's entry of robot_force / robot_torque_tensor: the allocator's wrench in root-link mode, else 0.
       // simulate_drag (base_multirotor.py:260-285; pre-physics body velocities) and apply_disturbance (:213-234) accumulate
@@ -639,7 +641,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step
       // with forces at the motor links, drag AND disturbance are summed first and added to the links' sum once (`root`);
       // with one of the two, or in root-link mode, that is the running sum below.  All-zero drag coefficients (base
       // quadrotor) add +-0 to every component: skipped (a scalar test of kernel arguments).
-      const bool any_dist = B.disturb != nullptr || B.disturb_prob > 0.0f;
+      const bool any_dist = !body_wrench && (B.disturb != nullptr || B.disturb_prob > 0.0f);
       const bool split_root = !root_link && has_drag && any_dist;  // wave-uniform
       float dr[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, di[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       if (has_drag) {
@@ -669,7 +671,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step
           di[c] = ((hi - lo) * ud[1 + c] + lo) * occ;
         }
       }
-      if (has_drag || any_dist) {  // an absent term is +0: x + 0 = x
+      if (!body_wrench && (has_drag || any_dist)) {  // an absent term is +0: x + 0 = x
 #pragma unroll
         for (int c = 0; c < 6; ++c) bw[c] = split_root ? bw[c] + (dr[c] + di[c]) : (bw[c] + dr[c]) + di[c];
       }
@@ -1370,6 +1372,143 @@ __global__ void __launch_bounds__(256) k_controller_wrench(AgxRobotParams P, Agx
   }
   AGX_AT(B.wrench_cmd, 0) = wc.f.x; AGX_AT(B.wrench_cmd, 1) = wc.f.y; AGX_AT(B.wrench_cmd, 2) = wc.f.z;
   AGX_AT(B.wrench_cmd, 3) = wc.t.x; AGX_AT(B.wrench_cmd, 4) = wc.t.y; AGX_AT(B.wrench_cmd, 5) = wc.t.z;
+}
+
+// BaseMultirotor.step(action) of the reference as ONE launch (agx_robot_step; the robot plug-in's super().step()):
+// update_states, clip, controller, allocation + motor model, the per-body force / torque tensors, drag, disturbance.
+// One lane per env, runtime motor count and control law: a plug-in path evaluated between host calls, not a hot loop.
+__global__ void __launch_bounds__(256) k_robot_step(AgxRobotParams P, AgxEnvBuffers B, int n, const float *__restrict__ action,
+                                                    AgxRobotStepArgs R) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int M = P.num_motors, A = P.num_actions, NB = R.num_bodies;
+  EnvState s = load_state(B.state, n, i);
+  const Derived d = update_states(s);
+  store_derived(B.derived, n, i, d);
+  float a[AGX_MAX_ACTIONS];
+#pragma unroll
+  for (int c = 0; c < AGX_MAX_ACTIONS; ++c) a[c] = (c < A) ? clamp_minmax(action[(size_t)i * A + c], -10.0f, 10.0f) : 0.0f;  // clip_actions
+  float u[AGX_MAX_MOTORS];
+  Wrench wc{V3{0, 0, 0}, V3{0, 0, 0}};
+  if (P.controller != AGX_CTRL_NONE) {
+    Gains g = B.gains ? load_gains(B.gains, n, i) : uniform_gains(P);
+    switch (P.controller) {
+      case AGX_CTRL_POSITION: wc = run_controller<AGX_CTRL_POSITION>(P, s, d, a, g); break;
+      case AGX_CTRL_VELOCITY: wc = run_controller<AGX_CTRL_VELOCITY>(P, s, d, a, g); break;
+      case AGX_CTRL_ATTITUDE: wc = run_controller<AGX_CTRL_ATTITUDE>(P, s, d, a, g); break;
+      case AGX_CTRL_RATES: wc = run_controller<AGX_CTRL_RATES>(P, s, d, a, g); break;
+      case AGX_CTRL_ACCELERATION: wc = run_controller<AGX_CTRL_ACCELERATION>(P, s, d, a, g); break;
+      case AGX_CTRL_VEL_STEERING: wc = run_controller<AGX_CTRL_VEL_STEERING>(P, s, d, a, g); break;
+      case AGX_CTRL_FULLY_ACTUATED: wc = run_controller<AGX_CTRL_FULLY_ACTUATED>(P, s, d, a, g); break;
+      default: break;
+    }
+  }
+  const float w6[6] = {wc.f.x, wc.f.y, wc.f.z, wc.t.x, wc.t.y, wc.t.z};
+#pragma unroll
+  for (int j = 0; j < AGX_MAX_MOTORS; ++j) {
+    u[j] = 0.0f;
+    if (j < M) {
+      float ref = a[j];  // no_control: the action IS the motor command
+      if (P.controller != AGX_CTRL_NONE) {
+        ref = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ref += P.alloc_pinv[6 * j + c] * w6[c];
+      }
+      const float kT = P.use_rps ? AGX_AT(B.motor_kT, j) : 1.0f;
+      const float tinc = B.motor_tau_inc ? AGX_AT(B.motor_tau_inc, j) : P.tau_inc_uniform;
+      const float tdec = B.motor_tau_dec ? AGX_AT(B.motor_tau_dec, j) : P.tau_dec_uniform;
+      u[j] = motor_update(P, ref, AGX_AT(B.motor_thrust, j), kT, tinc, tdec);
+      AGX_AT(B.motor_thrust, j) = u[j];
+    }
+  }
+  if (B.wrench_cmd) {
+    AGX_AT(B.wrench_cmd, 0) = wc.f.x; AGX_AT(B.wrench_cmd, 1) = wc.f.y; AGX_AT(B.wrench_cmd, 2) = wc.f.z;
+    AGX_AT(B.wrench_cmd, 3) = wc.t.x; AGX_AT(B.wrench_cmd, 4) = wc.t.y; AGX_AT(B.wrench_cmd, 5) = wc.t.z;
+  }
+  // call_controller (base_multirotor.py:246-258): output_forces / output_torques are zero outside the application mask
+  float *F = R.force + (size_t)i * NB * 3, *T = R.torque + (size_t)i * NB * 3;
+  for (int b = 0; b < NB * 3; ++b) { F[b] = 0.0f; T[b] = 0.0f; }
+  if (P.root_link_mode) {  // control_allocation.py:67-79: output wrench = A u at the (single) masked body
+    float w[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float acc = 0.0f;
+      for (int j = 0; j < M; ++j) acc += P.alloc[M * r + j] * u[j];
+      w[r] = acc;
+    }
+    const int b = R.body_of_motor[0];
+    F[3 * b] = w[0]; F[3 * b + 1] = w[1]; F[3 * b + 2] = w[2];
+    T[3 * b] = w[3]; T[3 * b + 1] = w[4]; T[3 * b + 2] = w[5];
+  } else {  // control_allocation.py:103-114: force (0, 0, u), torque cq * force * (-dir) at every motor link, in the LINK's frame
+    for (int j = 0; j < M; ++j) {
+      const int b = R.body_of_motor[j];
+      F[3 * b + 2] = u[j];
+      T[3 * b] = (P.cq * 0.0f) * (-P.motor_dir[j]);
+      T[3 * b + 1] = (P.cq * 0.0f) * (-P.motor_dir[j]);
+      T[3 * b + 2] = (P.cq * u[j]) * (-P.motor_dir[j]);
+    }
+  }
+  // simulate_drag (:260-285), then apply_disturbance (:213-234): both `+=` into body 0
+  {
+    const float vbn = norm(d.vbody);
+    F[0] += (-P.lin_drag_linear[0] * d.vbody.x) + (-P.lin_drag_quadratic[0] * vbn * d.vbody.x);
+    F[1] += (-P.lin_drag_linear[1] * d.vbody.y) + (-P.lin_drag_quadratic[1] * vbn * d.vbody.y);
+    F[2] += (-P.lin_drag_linear[2] * d.vbody.z) + (-P.lin_drag_quadratic[2] * vbn * d.vbody.z);
+    T[0] += (-P.ang_drag_linear[0] * d.wbody.x) + (-P.ang_drag_quadratic[0] * fabsf(d.wbody.x) * d.wbody.x);
+    T[1] += (-P.ang_drag_linear[1] * d.wbody.y) + (-P.ang_drag_quadratic[1] * fabsf(d.wbody.y) * d.wbody.y);
+    T[2] += (-P.ang_drag_linear[2] * d.wbody.z) + (-P.ang_drag_quadratic[2] * fabsf(d.wbody.z) * d.wbody.z);
+  }
+  float di[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  bool any = false;
+  if (B.disturb) {  // draws supplied by the host ([k][7][N] rows of this sub-step)
+    const float *dd = B.disturb + (size_t)R.substep * 7 * n + i;
+    const float occ = dd[0];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float lo = -B.disturb_max[c], hi = B.disturb_max[c];
+      di[c] = ((hi - lo) * dd[(size_t)(1 + c) * n] + lo) * occ;
+    }
+    any = true;
+  } else if (B.disturb_prob > 0.0f) {  // the device stream of the fused step: same (env, step, sub-step) -> same draws
+    float ud[7];
+    rng_fill<7>(B.rng_seed, B.env_index_base + i, agx::step_index(B), RNG_DISTURB + R.substep, ud);
+    const float occ = ud[0] < B.disturb_prob ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float lo = -B.disturb_max[c], hi = B.disturb_max[c];
+      di[c] = ((hi - lo) * ud[1 + c] + lo) * occ;
+    }
+    any = true;
+  }
+  if (any) {
+    F[0] += di[0]; F[1] += di[1]; F[2] += di[2];
+    T[0] += di[3]; T[1] += di[4]; T[2] += di[5];
+  }
+}
+
+// robot_force_tensor / robot_torque_tensor -> the net body-frame wrench on the rigid composite (agx_net_body_wrench)
+__global__ void __launch_bounds__(256) k_net_body_wrench(int n, AgxLinkFrames L, const float *__restrict__ force,
+                                                         const float *__restrict__ torque, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int NB = L.num_bodies;
+  const float *F = force + (size_t)i * NB * 3, *T = torque + (size_t)i * NB * 3;
+  float w[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int b = 0; b < NB; ++b) {
+    const float *Rm = L.rot[b], *r = L.pos[b];
+    const float f[3] = {F[3 * b], F[3 * b + 1], F[3 * b + 2]}, t[3] = {T[3 * b], T[3 * b + 1], T[3 * b + 2]};
+    float fr[3], tr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      fr[c] = (Rm[3 * c] * f[0] + Rm[3 * c + 1] * f[1]) + Rm[3 * c + 2] * f[2];
+      tr[c] = (Rm[3 * c] * t[0] + Rm[3 * c + 1] * t[1]) + Rm[3 * c + 2] * t[2];
+    }
+    const float cx = r[1] * fr[2] - r[2] * fr[1], cy = r[2] * fr[0] - r[0] * fr[2], cz = r[0] * fr[1] - r[1] * fr[0];
+    w[0] += fr[0]; w[1] += fr[1]; w[2] += fr[2];
+    w[3] += cx + tr[0]; w[4] += cy + tr[1]; w[5] += cz + tr[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) out[(size_t)i * 6 + c] = w[c];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2087,7 +2226,9 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   AGX_REQUIRE(k >= 0 && k <= AGX_MAX_SUBSTEPS, "k_substeps out of range: %d", k);
   AGX_REQUIRE(P->controller != AGX_CTRL_WRENCH || k <= 1,
               "external controller (AGX_CTRL_WRENCH): one launch per physics sub-step, the host re-evaluates the controller in between");
-  AGX_REQUIRE((B->launch_flags & ~0xFF07) == 0, "launch_flags: bits 0, 1, 2 and the sub-step index in bits 8-15");
+  AGX_REQUIRE((B->launch_flags & ~0xFF0F) == 0, "launch_flags: bits 0-3 and the sub-step index in bits 8-15");
+  AGX_REQUIRE((B->launch_flags & AGX_LAUNCH_BODY_WRENCH) == 0 || P->controller == AGX_CTRL_WRENCH,
+              "AGX_LAUNCH_BODY_WRENCH (external robot) goes with AGX_CTRL_WRENCH: actions_in is a wrench [N][6]");
   AGX_REQUIRE((B->launch_flags & 4) == 0 || ((B->launch_flags & 3) == 0 && P->controller != AGX_CTRL_WRENCH &&
                                              (!task || task->kind != AGX_TASK_NAVIGATION)),
               "AGX_LAUNCH_LEAN needs the fused step of a built-in controller without the navigation reward (it reads the action history)");
@@ -2198,6 +2339,30 @@ extern "C" int agx_controller_wrench(const AgxRobotParams *P, const AgxEnvBuffer
   const int block = pick_block(n);
   hipLaunchKernelGGL(k_controller_wrench, dim3(blocks_for(n, block)), dim3(block), 0, (hipStream_t)stream, *P, *B, n, action);
   return check_launch("agx_controller_wrench");
+}
+
+extern "C" int agx_robot_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, const float *action, const AgxRobotStepArgs *R,
+                              void *stream) {
+  if (int e = check_common(P, B, n)) return e;
+  AGX_REQUIRE(P && R && action, "null argument");
+  AGX_REQUIRE(P->controller != AGX_CTRL_WRENCH, "agx_robot_step evaluates a BUILT-IN controller (an external controller class is called by the host)");
+  AGX_REQUIRE(B->state && B->derived && B->motor_thrust && R->force && R->torque, "null buffer");
+  AGX_REQUIRE(!P->use_rps || B->motor_kT, "null motor_kT with use_rps");
+  AGX_REQUIRE(R->num_bodies >= 1 && R->num_bodies <= AGX_MAX_BODIES, "num_bodies %d outside [1, %d]", R->num_bodies, AGX_MAX_BODIES);
+  AGX_REQUIRE(R->substep >= 0 && R->substep < AGX_MAX_SUBSTEPS, "substep out of range");
+  AGX_REQUIRE((long long)n * R->num_bodies * 3 < (1ll << 31), "per-body tensors too large for this entry point");
+  for (int j = 0; j < (P->root_link_mode ? 1 : P->num_motors); ++j)
+    AGX_REQUIRE(R->body_of_motor[j] >= 0 && R->body_of_motor[j] < R->num_bodies, "application mask entry %d = %d outside [0, %d)", j,
+                R->body_of_motor[j], R->num_bodies);
+  hipLaunchKernelGGL(k_robot_step, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *P, *B, n, action, *R);
+  return check_launch("agx_robot_step");
+}
+
+extern "C" int agx_net_body_wrench(int n, const AgxLinkFrames *L, const float *force, const float *torque, float *out, void *stream) {
+  AGX_REQUIRE(n > 0 && L && force && torque && out, "bad arguments");
+  AGX_REQUIRE(L->num_bodies >= 1 && L->num_bodies <= AGX_MAX_BODIES, "num_bodies %d outside [1, %d]", L->num_bodies, AGX_MAX_BODIES);
+  hipLaunchKernelGGL(k_net_body_wrench, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, *L, force, torque, out);
+  return check_launch("agx_net_body_wrench");
 }
 
 extern "C" int agx_reward_position(const AgxEnvBuffers *B, int n, const float *target, int episode_len,

@@ -205,7 +205,8 @@ class EnvManager(BaseManager):
         self._make_reset_args()
         self._disturb_buf = None
         self._reward_fresh = self._obs_fresh = self._mask_fresh = False
-        if self.env_args.get("lean_step") and self.num_envs >= self.LEAN_MIN_ENVS and self._params.controller != 8:  # 8: external
+        if (self.env_args.get("lean_step") and self.num_envs >= self.LEAN_MIN_ENVS and self._params.controller != 8  # 8: external controller
+                and not getattr(robot, "external_robot", False)):
             self._enable_lean_step()
 
     def _make_reset_args(self):
@@ -537,7 +538,9 @@ class EnvManager(BaseManager):
         if a.shape != (self.num_envs, self.num_robot_actions):
             raise ValueError("Action tensor does not have the correct number of environments")
         self._draw_disturbance(num_substeps)
-        if getattr(self.robot_manager.robot, "external_controller", False):
+        if getattr(self.robot_manager.robot, "external_robot", False):
+            self._simulate_with_external_robot(a, num_substeps)
+        elif getattr(self.robot_manager.robot, "external_controller", False):
             self._simulate_with_external_controller(a, num_substeps)
         else:
             _lib.check(
@@ -576,6 +579,89 @@ class EnvManager(BaseManager):
                            "agx_env_step")
         finally:
             B.launch_flags = 0
+
+    # ---- robot plug-in (robots/base_robot.py:10-63, robot_manager.py:486-489) -------------------------------------
+    _robot_step_args = None
+    _robot_substep = 0
+
+    def _robot_plugin_state(self):
+        """per-body tensors, application mask and link-frame table of the robot plug-in path (built on first use)"""
+        if self._robot_step_args is None:
+            from ..robots.robot_model import link_frames
+
+            g, robot = self.global_tensor_dict, self.robot_manager.robot
+            R = _lib.AgxRobotStepArgs()
+            F, T = g["robot_force_tensor"], g["robot_torque_tensor"]
+            R.force, R.torque, R.num_bodies = _lib.dptr(F), _lib.dptr(T), int(F.shape[1])
+            mask = [0] if robot.params_dict["root_link_mode"] else [int(b) for b in robot.cfg.control_allocator_config.application_mask]
+            for j, b in enumerate(mask):
+                R.body_of_motor[j] = b
+            self._robot_step_args = R
+            self._link_frames, known = link_frames(robot.cfg, int(F.shape[1]))
+            self._unknown_bodies = [b for b, k in enumerate(known) if not k]
+            self._net_wrench = torch.zeros(self.num_envs, 6, dtype=torch.float32, device=self.device)
+            # the integrating launch takes the wrench as it is: same constants, controller id "wrench"
+            import copy
+
+            self._params_body_wrench = copy.copy(self._params)
+            self._params_body_wrench.controller = _lib.CTRL_IDS["wrench"]
+            self._unknown_checked = False
+        return self._robot_step_args
+
+    def robot_step(self, action):
+        """BaseMultirotor.step(action) of the reference (base_multirotor.py:296-307) as one launch, agx_robot_step: derived
+        tensors, motor thrusts and the per-body force / torque tensors as the reference's robot leaves them."""
+        self._require_device()
+        robot = self.robot_manager.robot
+        if getattr(robot, "external_controller", False):
+            raise RuntimeError("BaseMultirotor.step with an external controller class: call the controller yourself and write "
+                               "robot_force_tensors / robot_torque_tensors in your step()")
+        a = action
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(dtype=torch.float32).contiguous()
+        if a.shape != (self.num_envs, self.num_robot_actions):
+            raise ValueError("Action tensor does not have the correct number of environments")
+        R = self._robot_plugin_state()
+        R.substep = int(self._robot_substep)
+        _lib.check(self._lib.agx_robot_step(self._params, self._buffers, self.num_envs, _lib.dptr(a), _lib.C.byref(R), self._stream()),
+                   "agx_robot_step")
+
+    def _simulate_with_external_robot(self, a, k):
+        """A robot class the user registered (robot_registry.register) that overrides step(): per physics sub-step, the
+        reference's order -- RobotManagerIGE.pre_physics_step copies the action and calls robot.step(actions)
+        (robot_manager.py:486-489), which leaves each body's wrench (in that body's frame) in robot_force_tensors /
+        robot_torque_tensors; Isaac Gym applies them and steps PhysX (IGE_env_manager.py:444-449, 477).  Here: the user's
+        step() on the host (BaseMultirotor.step, reachable through super(), is ONE launch), agx_net_body_wrench reduces the
+        per-body tensors to the net wrench on the rigid composite, and ONE launch integrates it and tests for collisions
+        (AGX_CTRL_WRENCH + AGX_LAUNCH_BODY_WRENCH: no allocation / motor model / drag / disturbance there -- step() did
+        whatever it does about them).  Flags, step counter, truncation and the task's fused reward run with the last launch."""
+        g, B, robot = self.global_tensor_dict, self._buffers, self.robot_manager.robot
+        self._robot_plugin_state()
+        F, T = g["robot_force_tensor"], g["robot_torque_tensor"]
+        try:
+            for sub in range(max(k, 1)):
+                B.launch_flags = (1 if sub > 0 else 0) | (2 if sub < k - 1 else 0) | _lib.LAUNCH_BODY_WRENCH | (sub << 8)
+                if k > 0:
+                    g["robot_prev_actions"][:] = g["robot_actions"]
+                    g["robot_actions"][:] = a
+                    self._robot_substep = sub
+                    robot.step(g["robot_actions"])
+                    if not self._unknown_checked and self._unknown_bodies:
+                        # once: a wrench on a body whose pose the robot_model table does not know cannot be placed
+                        self._unknown_checked = True
+                        if bool((F[:, self._unknown_bodies] != 0).any()) or bool((T[:, self._unknown_bodies] != 0).any()):
+                            raise NotImplementedError(
+                                f"robot.step() wrote a wrench on bodies {self._unknown_bodies}, whose poses the config's robot_model does not "
+                                "give: add them as robot_model.link_xyz / link_rpy = {body index: [x, y, z] / [r, p, y]}")
+                    _lib.check(self._lib.agx_net_body_wrench(self.num_envs, _lib.C.byref(self._link_frames), _lib.dptr(F), _lib.dptr(T),
+                                                             _lib.dptr(self._net_wrench), self._stream()), "agx_net_body_wrench")
+                else:
+                    self._net_wrench.zero_()
+                _lib.check(self._lib.agx_env_step(self._params_body_wrench, B, self.num_envs, _lib.dptr(self._net_wrench), min(k, 1),
+                                                  self.task_args, self._stream()), "agx_env_step")
+        finally:
+            B.launch_flags = 0
+            self._robot_substep = 0
 
     @roctx.ranged("EnvManager.step")
     def step(self, actions, env_actions=None):

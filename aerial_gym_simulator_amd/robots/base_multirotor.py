@@ -68,6 +68,9 @@ class BaseMultirotor(BaseRobot):
             kind = "wrench"
         self.params_dict = robot_params_dict(self.cfg, self.controller_config, kind, g["sim_config"])
         self.params = pack_robot_params(self.params_dict)
+        # A robot CLASS (robot_registry.register) that overrides step(): the reference's plug-in contract (base_robot.py:10-63).
+        # It is called by the host once per physics sub-step; what it leaves in the per-body tensors is integrated.
+        self.external_robot = type(self).step is not BaseMultirotor.step
 
     def reset(self):
         self.reset_idx(torch.arange(self.num_envs, device=self.device))
@@ -83,7 +86,13 @@ class BaseMultirotor(BaseRobot):
         self._env_binding.update_states()
 
     def step(self, action_tensor):
-        raise RuntimeError(
-            "BaseMultirotor.step is fused with the physics step: call EnvManager.step / simulate "
-            "(agx_dynamics_substeps evaluates controller, allocation, motors and integration in one launch)"
-        )
+        """base_multirotor.py:296-307 as ONE launch (agx_robot_step): update_states, clip, controller, allocation + motor model
+        (the motor thrusts advance), `robot_force_tensors` / `robot_torque_tensors` written, drag and disturbance added to the
+        root body.  EnvManager.step does NOT go through here for a robot whose class leaves step() alone (controller ..
+        integration are one fused launch then); a registered subclass that overrides step() is called once per physics
+        sub-step like the reference's (robot_manager.py:486-489) and typically calls this through super().step(action)."""
+        if self._env_binding is None:
+            raise RuntimeError("robot is not bound to an EnvManager yet")
+        if action_tensor.shape[0] != self.num_envs:
+            raise ValueError("Action tensor does not have the correct number of environments")
+        self._env_binding.robot_step(action_tensor)

@@ -24,6 +24,8 @@ class BaseRobot(ABC):
         self.robot_state = g["robot_state_tensor"]
         self.robot_position, self.robot_orientation = g["robot_position"], g["robot_orientation"]
         self.robot_linvel, self.robot_angvel = g["robot_linvel"], g["robot_angvel"]
+        # tensors for robot forces and torques (base_robot.py:46-48): [N, num_bodies, 3], each body's wrench in ITS frame
+        self.robot_force_tensors, self.robot_torque_tensors = g["robot_force_tensor"], g["robot_torque_tensor"]
         self.env_bounds_min, self.env_bounds_max = g["env_bounds_min"], g["env_bounds_max"]
 
     @abstractmethod

@@ -34,6 +34,14 @@ class RobotManagerHIP:
         g["robot_actions"], g["robot_prev_actions"] = aos_view(self.actions_soa), aos_view(self.prev_actions_soa)
         self.actions, self.prev_actions = g["robot_actions"], g["robot_prev_actions"]
         g["dof_control_mode"] = "none"
+        # per-body force / torque tensors (IGE_env_manager.py:293-358; written by robot.step(), each body's wrench in its own
+        # frame).  The fused step never touches them; they carry the robot plug-in path (EnvManager: a robot class that
+        # overrides step()).  Bodies: the root link, then whatever lies below the highest index of the application mask.
+        ca = self.cfg.control_allocator_config
+        self.num_robot_bodies = int(getattr(self.cfg.robot_asset, "num_bodies", 0) or (max(int(b) for b in ca.application_mask) + 1))
+        g["robot_force_tensor"] = torch.zeros(N, self.num_robot_bodies, 3, device=dev)
+        g["robot_torque_tensor"] = torch.zeros(N, self.num_robot_bodies, 3, device=dev)
+        g["num_robot_bodies"] = self.num_robot_bodies
         self.robot.init_tensors(g)
         pd = self.robot.params_dict
         # (allocated by the robot before its controller's init_tensors, which reads them like the reference's controllers do)

@@ -59,6 +59,40 @@ def motor_wrench_map(model, motor_directions, cq, com):
     return W
 
 
+def link_frames(robot_cfg, num_bodies):
+    """(AgxLinkFrames, known[num_bodies]): pose of every rigid body of the robot in the root-link frame, about the composite's
+    centre of mass -- what turns the per-body tensors robot_force_tensor / robot_torque_tensor (each body's wrench in ITS
+    frame, IGE_env_manager.py:444-449 LOCAL_SPACE) into the net wrench on the rigid composite.  Known from the config's
+    robot_model table: the root link (body 0) and the motor links (control_allocator_config.application_mask -> motor_xyz /
+    motor_rpy); optional `robot_model.link_xyz` / `link_rpy` dicts {body index: pose} name further links.  A body without
+    a known pose (base_quadrotor's four massless arm links) must stay at zero wrench: `known` says which."""
+    from .._lib import MAX_BODIES, AgxLinkFrames
+
+    if not 1 <= num_bodies <= MAX_BODIES:
+        raise ValueError(f"robot with {num_bodies} bodies: the link-frame table holds {MAX_BODIES}")
+    model, ca = robot_cfg.robot_model, robot_cfg.control_allocator_config
+    _, com, _ = composite_body(model)
+    L = AgxLinkFrames()
+    L.num_bodies = num_bodies
+    known = [False] * num_bodies
+    poses = {0: ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0])}
+    for j, b in enumerate(ca.application_mask):
+        if j < len(model.motor_xyz):
+            poses[int(b)] = (model.motor_xyz[j], model.motor_rpy[j])
+    for b, xyz in dict(getattr(model, "link_xyz", {}) or {}).items():
+        poses[int(b)] = (xyz, dict(getattr(model, "link_rpy", {}) or {}).get(b, [0.0, 0.0, 0.0]))
+    for b in range(num_bodies):
+        xyz, rpy = poses.get(b, ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0]))
+        R = rpy_to_matrix(*rpy).astype(np.float32).reshape(-1)
+        r = (np.asarray(xyz, np.float64) - com).astype(np.float32)
+        for c in range(9):
+            L.rot[b][c] = float(R[c])
+        for c in range(3):
+            L.pos[b][c] = float(r[c])
+        known[b] = b in poses
+    return L, known
+
+
 def _fill(dst, values):
     values = np.asarray(values, dtype=np.float32).reshape(-1)
     for i, v in enumerate(values):

@@ -76,6 +76,9 @@ class PositionSetpointTask(BaseTask):
         e = env.cfg.env
         simple = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and env.robot_manager.imu_sensor is None
                   and not env.strict_rng
+                  # host-evaluated controller / robot classes run between launches: the general path dispatches them
+                  and not getattr(env.robot_manager.robot, "external_controller", False)
+                  and not getattr(env.robot_manager.robot, "external_robot", False)
                   and not env.robot_manager.robot.cfg.disturbance.enable_disturbance
                   and e.num_physics_steps_per_env_step_std == 0 and not self.task_config.return_state_before_reset)
         if simple:

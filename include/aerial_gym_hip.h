@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 10
+#define AGX_ABI_VERSION 11
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
+#define AGX_MAX_BODIES 24   /* rigid bodies (links) of one robot: base_quadrotor 9, base_octarotor 17 */
 
 enum {
   AGX_OK = 0,
@@ -194,8 +195,15 @@ typedef struct AgxEnvBuffers {
                             (Euler angles, vehicle quaternion, vehicle-frame velocity), actions, prev_actions -- 88 of the
                             ~330 bytes an env moves per step; agx_update_states recomputes the derived tensors from the
                             current state on demand (the host mirror does that when a dict key is read).  The one-lane
-                            kernels implement it (it is meant for batches far above 65 536 envs, where bytes matter).      */
+                            kernels implement it (it is meant for batches far above 65 536 envs, where bytes matter).
+                            bit 3 (AGX_LAUNCH_BODY_WRENCH, with AGX_CTRL_WRENCH only) = EXTERNAL ROBOT: `actions_in` [N][6] is
+                            the NET body-frame wrench on the rigid composite about its centre of mass -- what the robot
+                            object's step() left in robot_force_tensor / robot_torque_tensor, reduced by
+                            agx_net_body_wrench -- and goes straight to the integrator: no allocation, motor model, drag or
+                            disturbance in this launch (the robot's step() did whatever it does about them).             */
 } AgxEnvBuffers;
+#define AGX_LAUNCH_LEAN 4
+#define AGX_LAUNCH_BODY_WRENCH 8
 
 const char *agx_last_error(void);
 int agx_abi_version(void);
@@ -269,6 +277,42 @@ int agx_copy_f4(const void *src, void *dst, size_t bytes, void *stream);
  * action: [N][A] row-major (clipped to +-10 like BaseMultirotor.clip_actions).          */
 int agx_controller_wrench(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs,
                           const float *action, void *stream);
+
+/* ---- robot plug-in (robots/base_robot.py:10-63, robot_manager.py:486-489) ------------------------------
+ * A robot CLASS registered through robot_registry.register that overrides step(action) is called by the host once per
+ * physics sub-step, like the reference's RobotManagerIGE.pre_physics_step does; what it leaves in robot_force_tensor /
+ * robot_torque_tensor ([N][num_bodies][3], each body's wrench in that BODY's own frame: IGE_env_manager.py:444-449 applies
+ * them with LOCAL_SPACE) is reduced to the net wrench on the rigid composite (agx_net_body_wrench) and integrated by
+ * agx_env_step with AGX_CTRL_WRENCH + AGX_LAUNCH_BODY_WRENCH.
+ *
+ * agx_robot_step = the reference's BaseMultirotor.step(action) (base_multirotor.py:296-307) as ONE launch, for such a class
+ * to call through super().step(action): update_states (derived tensors stored), clip_actions, the built-in controller,
+ * ControlAllocator.allocate_output + MotorModel (motor thrusts stored; control_allocation.py:52-114), the per-body tensors
+ * written like call_controller does (:246-258: every body zero, then motor link j <- force (0, 0, u_j), torque
+ * (0, 0, -cq dir_j u_j); root-link mode: body_of_motor[0] <- the allocator's wrench), simulate_drag and apply_disturbance
+ * accumulated into body 0 (:213-234, :260-285; buf->disturb rows of sub-step `substep`, or the device stream).          */
+typedef struct AgxRobotStepArgs {
+  float *force;                          /* [N][num_bodies][3] robot_force_tensor  (row-major, the reference's layout) */
+  float *torque;                         /* [N][num_bodies][3] robot_torque_tensor                                      */
+  int32_t num_bodies;                    /* 1 .. AGX_MAX_BODIES                                                         */
+  int32_t substep;                       /* physics sub-step inside the env step (disturbance draws)                    */
+  int32_t body_of_motor[AGX_MAX_MOTORS]; /* control_allocator_config.application_mask                                   */
+} AgxRobotStepArgs;
+int agx_robot_step(const AgxRobotParams *params, const AgxEnvBuffers *buf, int num_envs, const float *action /*[N][A]*/,
+                   const AgxRobotStepArgs *args, void *stream);
+
+/* Net body-frame wrench about the centre of mass of per-body wrenches given in each body's own frame:
+ *   F = sum_b R_b f_b,   T = sum_b (r_b x (R_b f_b) + R_b t_b)     (b ascending, fp32, one IEEE operation per + - *)
+ * rot / pos: pose of body b in the root-link frame (URDF joint origins), about the composite's centre of mass.
+ * wrench_out: [N][6] row-major -- the `actions_in` of agx_env_step under AGX_LAUNCH_BODY_WRENCH.                        */
+typedef struct AgxLinkFrames {
+  int32_t num_bodies;
+  int32_t reserved;
+  float rot[AGX_MAX_BODIES][9];          /* row-major 3 x 3 */
+  float pos[AGX_MAX_BODIES][3];
+} AgxLinkFrames;
+int agx_net_body_wrench(int num_envs, const AgxLinkFrames *frames, const float *force, const float *torque,
+                        float *wrench_out, void *stream);
 
 /* ---- tasks ----------------------------------------------------------------------
  * Position-setpoint task: compute_rewards_and_crashes + truncation test

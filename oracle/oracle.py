@@ -177,6 +177,35 @@ def substep(P, state, action, thrust, kT, tau_inc, tau_dec, Kp, Kv, KR, Kw, dist
     return out
 
 
+def robot_step(P, state, action, thrust, kT, tau_inc, tau_dec, Kp, Kv, KR, Kw, num_bodies, body_of_motor, disturb=None, disturb_max=None):
+    """BaseMultirotor.step(action) with its per-body outputs (orc_robot_step): returns (SubstepOut, force [N,B,3], torque [N,B,3]);
+    ``thrust`` [N,M] is updated in place, ``state`` is not integrated."""
+    n = state.shape[0]
+    M, A = P.num_motors, P.num_actions
+    out = SubstepOut()
+    out.euler, out.qveh = np.zeros((n, 3), np.float32), np.zeros((n, 4), np.float32)
+    out.vveh, out.vbody, out.wbody = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    out.wrench_cmd, out.body_wrench = np.zeros((n, 6), np.float32), None
+    out.action_clipped = np.zeros((n, A), np.float32)
+    force, torque = np.zeros((n, num_bodies, 3), np.float32), np.zeros((n, num_bodies, 3), np.float32)
+    mask = np.ascontiguousarray(np.asarray(list(body_of_motor) + [0] * 8, np.int32)[:8])
+    dm = _f(disturb_max) if disturb_max is not None else None
+    ds = _f(disturb) if disturb is not None else None
+    lib().orc_robot_step(
+        C.byref(P), n, _p(_f(state)), _p(_f(action).reshape(n, A)), _p(out.action_clipped), _p(thrust), _p(_f(kT)), _p(_f(tau_inc)),
+        _p(_f(tau_dec)), _p(_f(Kp)), _p(_f(Kv)), _p(_f(KR)), _p(_f(Kw)), _p(ds), _p(dm), _p(out.euler), _p(out.qveh), _p(out.vveh),
+        _p(out.vbody), _p(out.wbody), _p(out.wrench_cmd), int(num_bodies), _p(mask), _p(force), _p(torque))
+    return out, force, torque
+
+
+def net_body_wrench(rot, pos, force, torque):
+    """[N,6] net body-frame wrench about the COM of per-body wrenches given in each body's frame (orc_net_body_wrench)"""
+    n, nb = force.shape[0], force.shape[1]
+    out = np.zeros((n, 6), np.float32)
+    lib().orc_net_body_wrench(n, nb, _p(_f(rot).reshape(nb, 9)), _p(_f(pos).reshape(nb, 3)), _p(_f(force)), _p(_f(torque)), _p(out))
+    return out
+
+
 def update_states(state):
     n = state.shape[0]
     euler = np.zeros((n, 3), np.float32)

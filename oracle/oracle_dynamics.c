@@ -591,6 +591,87 @@ void orc_substep(const OrcRobotParams *P, int n, float *state, const float *acti
   }
 }
 
+/* ------------------------------------------------------------------ */
+/* Robot plug-in path.  BaseMultirotor.step(action) with    */
+/* its OUTPUT as the reference leaves it: the per-body tensors           */
+/* robot_force_tensor / robot_torque_tensor [N, num_bodies, 3], each     */
+/* body's wrench in that body's own frame (base_multirotor.py:246-258   */
+/* call_controller, :260-285 simulate_drag, :213-234 apply_disturbance;  */
+/* control_allocation.py:52-114).  No integration.                       */
+/* ------------------------------------------------------------------ */
+void orc_robot_step(const OrcRobotParams *P, int n, const float *state, const float *action,
+                    float *action_clipped, float *thrust, const float *kT, const float *tau_inc,
+                    const float *tau_dec, const float *Kp, const float *Kv, const float *KR,
+                    const float *Kw, const float *disturb, const float *disturb_max, float *euler,
+                    float *qveh, float *vveh, float *vbody, float *wbody, float *wrench_cmd,
+                    int num_bodies, const int *body_of_motor, float *force, float *torque) {
+  const int M = P->num_motors;
+  float *bw = (float *)malloc(sizeof(float) * 6 * (size_t)n);
+  /* controller, allocation, motor model: orc_substep without its integration (state is not written) */
+  orc_substep(P, n, (float *)state, action, action_clipped, thrust, kT, tau_inc, tau_dec, Kp, Kv, KR, Kw,
+              NULL, NULL, euler, qveh, vveh, vbody, wbody, wrench_cmd, bw, 0);
+  free(bw);
+  for (int i = 0; i < n; ++i) {
+    float *F = force + (size_t)i * num_bodies * 3, *T = torque + (size_t)i * num_bodies * 3;
+    const float *u = thrust + M * i;
+    for (int b = 0; b < num_bodies * 3; ++b) { F[b] = 0.0f; T[b] = 0.0f; }
+    if (P->root_link_mode) { /* control_allocation.py:67-79: output_wrench = A u at the masked (root) body */
+      const int b = body_of_motor[0];
+      for (int r = 0; r < 6; ++r) {
+        float acc = 0.0f;
+        for (int j = 0; j < M; ++j) acc += P->alloc[M * r + j] * u[j];
+        if (r < 3) F[3 * b + r] = acc; else T[3 * b + r - 3] = acc;
+      }
+    } else { /* :103-114: motor_forces = (0, 0, u); motor_torques = cq * motor_forces * (-dir) */
+      for (int j = 0; j < M; ++j) {
+        const int b = body_of_motor[j];
+        F[3 * b + 2] = u[j];
+        T[3 * b] = (P->cq * 0.0f) * (-P->motor_dir[j]);
+        T[3 * b + 1] = (P->cq * 0.0f) * (-P->motor_dir[j]);
+        T[3 * b + 2] = (P->cq * u[j]) * (-P->motor_dir[j]);
+      }
+    }
+    const float *vb = vbody + 3 * i, *wb = wbody + 3 * i;
+    const float vbn = norm3(vb);
+    for (int k = 0; k < 3; ++k) {
+      F[k] += (-P->lin_drag_linear[k] * vb[k]) + (-P->lin_drag_quadratic[k] * vbn * vb[k]);
+      T[k] += (-P->ang_drag_linear[k] * wb[k]) + (-P->ang_drag_quadratic[k] * fabsf(wb[k]) * wb[k]);
+    }
+    if (disturb) {
+      const float *d = disturb + 7 * i;
+      for (int k = 0; k < 6; ++k) {
+        const float lo = -disturb_max[k], hi = disturb_max[k];
+        const float v = ((hi - lo) * d[1 + k] + lo) * d[0];
+        if (k < 3) F[k] += v; else T[k - 3] += v;
+      }
+    }
+  }
+}
+
+/* What PhysX does with per-body wrenches given in each body's own frame (gym.apply_rigid_body_force_tensors(...,   */
+/* LOCAL_SPACE), IGE_env_manager.py:444-449) on a composite of rigidly connected bodies: the net wrench about the    */
+/* centre of mass, F = sum R_b f_b, T = sum (r_b x R_b f_b + R_b t_b).  rot [B,9] row-major, pos [B,3]: body poses   */
+/* in the root-link frame (URDF joint origins).                                                                      */
+void orc_net_body_wrench(int n, int num_bodies, const float *rot, const float *pos, const float *force,
+                         const float *torque, float *out) {
+  for (int i = 0; i < n; ++i) {
+    const float *F = force + (size_t)i * num_bodies * 3, *T = torque + (size_t)i * num_bodies * 3;
+    float w[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < num_bodies; ++b) {
+      const float *R = rot + 9 * b, *r = pos + 3 * b;
+      float fr[3], tr[3];
+      for (int c = 0; c < 3; ++c) {
+        fr[c] = (R[3 * c] * F[3 * b] + R[3 * c + 1] * F[3 * b + 1]) + R[3 * c + 2] * F[3 * b + 2];
+        tr[c] = (R[3 * c] * T[3 * b] + R[3 * c + 1] * T[3 * b + 1]) + R[3 * c + 2] * T[3 * b + 2];
+      }
+      const float cx = r[1] * fr[2] - r[2] * fr[1], cy = r[2] * fr[0] - r[0] * fr[2], cz = r[0] * fr[1] - r[1] * fr[0];
+      w[0] += fr[0]; w[1] += fr[1]; w[2] += fr[2];
+      w[3] += cx + tr[0]; w[4] += cy + tr[1]; w[5] += cz + tr[2];
+    }
+    for (int c = 0; c < 6; ++c) out[6 * i + c] = w[c];
+  }
+}
+
 /* integrator alone (used to build hybrid "reference control + our physics" traces) */
 void orc_integrate(const OrcRobotParams *P, int n, float *state, const float *body_wrench) {
   for (int i = 0; i < n; ++i) integrate_one(P, state + 13 * i, body_wrench + 6 * i, body_wrench + 6 * i + 3);

@@ -1,0 +1,169 @@
+"""GPU: the robot plug-in surface of SURVEY 8(b) (robots/base_robot.py:10-63, robot_manager.py:486-489, base_multirotor.py:296-307).
+
+A robot CLASS registered with robot_registry.register that overrides step(action) is called by the host once per physics
+sub-step; what it leaves in robot_force_tensors / robot_torque_tensors (each body's wrench in that body's frame) is reduced to
+the net wrench on the rigid composite and integrated (AGX_CTRL_WRENCH + AGX_LAUNCH_BODY_WRENCH).  BaseMultirotor.step itself --
+what such a class reaches through super().step(action) -- is ONE launch (agx_robot_step).  Checked bit for bit against the
+oracle's restatement of the same path (orc.robot_step -> orc.net_body_wrench -> orc.integrate), and against the fused step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EXTRA_F = np.array([0.3, -0.2, 0.5], np.float32)  # constant extra force on the root body, in its frame [N]
+EXTRA_TZ = np.float32(0.01)                       # and a torque about the z axis of the third motor link [N m]
+
+
+def npy(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _register(name, cfg_name, with_extra):
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.registry.robot_registry import robot_registry
+    from aerial_gym_simulator_amd.robots.base_multirotor import BaseMultirotor
+
+    class ToyRobot(BaseMultirotor):
+        """the reference's contract: step(action) leaves the per-body tensors Isaac Gym would apply"""
+
+        calls = 0
+
+        def step(self, action_tensor):
+            super().step(action_tensor)  # update_states, controller, allocation, motors, drag, disturbance: one launch
+            type(self).calls += 1
+            if with_extra:
+                third = int(self.cfg.control_allocator_config.application_mask[2])
+                self.robot_force_tensors[:, 0, :] += torch.from_numpy(EXTRA_F).to(self.robot_force_tensors.device)
+                self.robot_torque_tensors[:, third, 2] += float(EXTRA_TZ)
+
+    robot_registry.register(name, ToyRobot, robot_registry.get_robot_config(cfg_name))
+    return ToyRobot
+
+
+@pytest.mark.parametrize("robot,controller,env_name,substeps", [
+    ("base_quadrotor", "lee_position_control", "empty_env", 1),
+    ("base_quadrotor", "lee_velocity_control", "env_with_random_boxes", 10),
+    ("base_octarotor", "octarotor_velocity_control", "empty_env", 1),     # tilted motor links, non-zero drag
+])
+def test_toy_robot_subclass_is_stepped_like_the_reference_and_matches_the_oracle(orc, robot, controller, env_name, substeps):
+    from aerial_gym_simulator_amd.robots.robot_model import link_frames
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    name = f"toy_{robot}_{controller}"
+    cls = _register(name, robot, with_extra=True)
+    n = 160
+    env = SimBuilder().build_env(sim_name="base_sim", env_name=env_name, robot_name=name, controller_name=controller, device=DEV,
+                                 args={"rng_seed": 5}, num_envs=n, headless=True, use_warp=False)
+    rob = env.robot_manager.robot
+    assert rob.external_robot and not rob.external_controller and isinstance(rob, cls)
+    assert env.cfg.env.num_physics_steps_per_env_step_mean == substeps
+    env.reset()
+    g = env.get_obs()
+    pd = rob.params_dict
+    P = orc.make_params(pd)
+    ctrl, mm = rob.controller, rob.control_allocator.motor_model
+    gains = [np.tile(((np.array(ctrl.gains_max, np.float32) + np.array(ctrl.gains_min, np.float32)) / np.float32(2))[3 * k:3 * k + 3], (n, 1))
+             for k in range(4)]
+    NB = int(g["robot_force_tensor"].shape[1])
+    mask = [int(b) for b in rob.cfg.control_allocator_config.application_mask]
+    assert NB == max(mask) + 1 == {"base_quadrotor": 9, "base_octarotor": 17}[robot]
+    L, known = link_frames(rob.cfg, NB)
+    rot = np.array([[L.rot[b][c] for c in range(9)] for b in range(NB)], np.float32)
+    pos = np.array([[L.pos[b][c] for c in range(3)] for b in range(NB)], np.float32)
+    assert [b for b, k in enumerate(known) if k] == [0] + mask
+    dcfg = rob.cfg.disturbance
+    dmax = np.array(dcfg.max_force_and_torque_disturbance, np.float32)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    calls0 = cls.calls
+    for t in range(6):
+        st, th = npy(g["robot_state_tensor"]), npy(mm.current_motor_thrust)
+        kT, ti, td = npy(mm.motor_thrust_constant), npy(mm.motor_time_constants_increasing), npy(mm.motor_time_constants_decreasing)
+        a = torch.rand(n, env.num_robot_actions, device=DEV, generator=gen) * 2 - 1
+        env.step(a)
+        for sub in range(substeps):
+            dist = None
+            if dcfg.enable_disturbance:  # apply_disturbance drawn in the kernel (device stream RNG_DISTURB + sub-step), as in the fused step
+                dist = orc.rng_fill(env.rng_seed, np.full(n, env.step_counter - 1, np.int32), (1 << 20) + sub, 7)
+                dist[:, 0] = (dist[:, 0] < np.float32(dcfg.prob_apply_disturbance)).astype(np.float32)
+            o, F, T = orc.robot_step(P, st, npy(a), th, kT, ti, td, *gains, NB, mask, disturb=dist, disturb_max=dmax)
+            F[:, 0, :] += EXTRA_F
+            T[:, mask[2], 2] += EXTRA_TZ
+            net = orc.net_body_wrench(rot, pos, F, T)
+            orc.integrate(P, st, net)
+        # the per-body tensors as the LAST sub-step's step() left them, the motor thrusts, the state: bit for bit
+        assert np.array_equal(npy(g["robot_force_tensor"]), F) and np.array_equal(npy(g["robot_torque_tensor"]), T), t
+        assert np.array_equal(npy(mm.current_motor_thrust), th), t
+        assert np.array_equal(npy(g["robot_state_tensor"]), st), t
+        assert np.array_equal(npy(g["robot_actions"]), npy(a)) and int(env.sim_steps[0]) == t + 1
+        assert np.array_equal(npy(g["robot_euler_angles"]), o.euler)  # update_states ran inside step(), pre-physics
+    assert cls.calls - calls0 == 6 * substeps  # once per physics sub-step, like robot_manager.py:486-489
+    # the extra force did something: +0.5 N upward on a 0.25 kg (quad) airframe
+    assert np.isfinite(npy(g["robot_state_tensor"])).all()
+
+
+def test_subclass_that_only_calls_super_flies_like_the_fused_step():
+    """step() = super().step(): the split path (one launch per part, per-body tensors reduced with the link-frame table) against the
+    ONE fused launch of the same robot -- same initial state, same actions; the motor thrusts are bit-identical (same controller,
+    allocation and motor model on the same numbers) as long as the states are, the states agree to fp32 rounding of the wrench
+    reduction (wrench_map folded ahead of time vs per-body sum)."""
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    _register("toy_passthrough_octarotor", "base_octarotor", with_extra=False)
+    n = 128
+    envs = [SimBuilder().build_env(sim_name="base_sim", env_name="env_with_random_boxes", robot_name=r, controller_name="octarotor_velocity_control",
+                                   device=DEV, args={"rng_seed": 9}, num_envs=n, headless=True, use_warp=False)
+            for r in ("base_octarotor", "toy_passthrough_octarotor")]
+    assert envs[1].robot_manager.robot.external_robot and not envs[0].robot_manager.robot.external_robot
+    for e in envs:
+        e.reset()
+    assert torch.equal(envs[0].global_tensor_dict["robot_state_tensor"], envs[1].global_tensor_dict["robot_state_tensor"])
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    worst = 0.0
+    for t in range(8):
+        a = torch.rand(n, 4, device=DEV, generator=gen) * 2 - 1
+        for e in envs:
+            e.step(a)
+        s0, s1 = (e.global_tensor_dict["robot_state_tensor"] for e in envs)
+        worst = max(worst, float((s0 - s1).abs().max()))
+        if t == 0:
+            assert worst < 2e-5, worst  # 10 sub-steps from identical states
+        assert torch.equal(envs[0].global_tensor_dict["crashes"], envs[1].global_tensor_dict["crashes"])
+        assert torch.equal(envs[0].sim_steps, envs[1].sim_steps)
+    assert worst < 2e-3, worst
+
+
+def test_builtin_robot_step_on_its_own_and_through_a_task(orc):
+    """BaseMultirotor.step(action) called by hand on the default robot writes the tensors (it raised until round 5); a
+    position_setpoint_task over a plug-in robot takes the general path (no one-call fast plan), reward and flags included."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+    from aerial_gym_simulator_amd.sim.sim_builder import SimBuilder
+
+    env = SimBuilder().build_env(sim_name="base_sim", env_name="empty_env", robot_name="base_quadrotor", controller_name="lee_position_control",
+                                 device=DEV, num_envs=32, headless=True, use_warp=False)
+    env.reset()
+    g = env.get_obs()
+    rob = env.robot_manager.robot
+    before = g["robot_state_tensor"].clone()
+    rob.step(torch.zeros(32, 4, device=DEV))
+    F, T = g["robot_force_tensor"], g["robot_torque_tensor"]
+    u = rob.control_allocator.motor_model.current_motor_thrust
+    assert torch.equal(F[:, 5:9, 2], u) and float(F[:, :5].abs().max()) == 0.0 and float(F[:, 5:9, :2].abs().max()) == 0.0
+    assert torch.equal(T[:, 5:9, 2], (0.01 * u) * (-torch.tensor([1.0, -1.0, 1.0, -1.0], device=DEV)))
+    assert torch.equal(g["robot_state_tensor"], before)  # nothing integrated
+    with pytest.raises(ValueError, match="correct number of environments"):
+        rob.step(torch.zeros(31, 4, device=DEV))
+    _register("toy_task_quadrotor", "base_quadrotor", with_extra=True)
+    old = (cfg.robot_name, cfg.device, cfg.controller_name, cfg.args)
+    try:
+        cfg.robot_name, cfg.device, cfg.controller_name, cfg.args = "toy_task_quadrotor", DEV, "lee_position_control", {}
+        task = task_registry.make_task("position_setpoint_task", seed=3, num_envs=64, headless=True)
+        assert task._plan is None and task.sim_env.robot_manager.robot.external_robot
+        task.reset()
+        for _ in range(5):
+            obs, rew, term, trunc, _ = task.step(torch.zeros(64, 4, device=DEV))
+        assert torch.isfinite(rew).all() and obs["observations"].shape == (64, 13) and int(task.sim_env.sim_steps[0]) == 5
+    finally:
+        cfg.robot_name, cfg.device, cfg.controller_name, cfg.args = old
