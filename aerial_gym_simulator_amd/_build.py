@@ -21,6 +21,10 @@ SOURCES = ["agx_api.cpp", "agx_math_eval.hip", "agx_dynamics.hip", "agx_scene.hi
 # DESIGN.md "numerics"); correctly rounded fp32 divide / sqrt is hipcc's default.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-Wno-comment"]
+# agx_raycast.hip: no SLP vectorisation.  The vectoriser packs the object node's dot products into v_pk_mul / v_pk_add_f32 on
+# SCALAR operands, which need aligned register pairs: six s_mov per node visit hoisted in front of the node-kind branch, 20 more
+# scalars spilled to lanes, and vector spills to scratch -- the frame is 6 % faster without it (profiles/r05_raycast_variants.txt).
+PER_SOURCE_FLAGS = {"agx_raycast.hip": ["-fno-slp-vectorize"]}
 
 
 def source_hash():
@@ -30,7 +34,7 @@ def source_hash():
     directly instead of trusting file times."""
     import hashlib
 
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_SOURCE_FLAGS.items()))).encode())
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
     for path in files + [os.path.join(INCLUDE, "aerial_gym_hip.h")]:
         h.update(os.path.basename(path).encode())
@@ -113,7 +117,7 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=None):
         is_api = src == "agx_api.cpp"  # carries the build id: recompiled (1 s) with every relink
         if force or _stale(obj, [path] + headers) or (is_api and relink):
             extra = ['-DAGX_BUILD_ID="%s"' % build_id] if is_api else []
-            cmds.append([hipcc] + FLAGS + extra + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj])
+            cmds.append([hipcc] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + extra + ["-I", INCLUDE, "-x", "hip", "-c", path, "-o", obj])
     _run_parallel(cmds, verbose)
     if relink or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
@@ -131,7 +135,7 @@ def _build_variant(extra_flags, lib_path, verbose):
         obj = os.path.join(LIB_DIR, f"{tag}_{os.path.splitext(src)[0]}.o")
         objs.append(obj)
         ident = ['-DAGX_BUILD_ID="%s+%s"' % (source_hash(), tag)] if src == "agx_api.cpp" else []
-        cmds.append([hipcc] + FLAGS + list(extra_flags) + ident + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
+        cmds.append([hipcc] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + list(extra_flags) + ident + ["-I", INCLUDE, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj])
     _run_parallel(cmds, verbose)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs, check=True)
     for o in objs:

@@ -207,6 +207,103 @@ AGX_DEV void test_leaf_pair(Ray &r, const float *__restrict__ tris, int f1, int 
   }
 }
 
+AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
+
+// The ray's origin in world order, from the copy ray_setup keeps in the triangle test's axis order
+template <int UPID>
+AGX_DEV V3 ray_origin(const Ray &r) {
+  // (values first, then selects on VALUES: a select between loads of r.op's members becomes a load through a selected address,
+  //  and the Ray then lives in scratch instead of registers)
+  const float p0 = r.op.x, p1 = r.op.y, p2 = r.op.z;
+  int kx, ky;
+  if (UPID >= 0) {
+    constexpr int kz = UPID >> 1;
+    constexpr int kx0 = kz == 2 ? 0 : kz + 1;
+    constexpr int ky0 = kx0 == 2 ? 0 : kx0 + 1;
+    kx = (UPID & 1) ? ky0 : kx0;
+    ky = (UPID & 1) ? kx0 : ky0;
+  } else {
+    const int kz = r.kz;
+    kx = kz == 2 ? 0 : kz + 1;
+    ky = kx == 2 ? 0 : kx + 1;
+    if (r.swap) { const int t = kx; kx = ky; ky = t; }
+  }
+  V3 o;
+  o.x = kx == 0 ? p0 : (ky == 0 ? p1 : p2);
+  o.y = kx == 1 ? p0 : (ky == 1 ? p1 : p2);
+  o.z = kx == 2 ? p0 : (ky == 2 ? p1 : p2);
+  return o;
+}
+
+// OBJECT NODE (AGX_BVH_BOX_OBJECTS): the tree ends at a box whose frame the 64-byte record holds (axes nx, ny, nz, half extents,
+// centre, first triangle).  The result stays what it is defined to be -- the smallest (t, face) over the triangles the EXACT test
+// accepts -- because only triangles that test cannot accept are skipped:
+//   * a = R^T (o - c), b = R^T d: the ray in the box's frame; plane +-k is met at t = (+-h_k - a_k) / b_k.  Every quantity carries an
+//     error bound far below the tolerance it is compared with: |delta t| <= 1e-6 s / |b_k| with s = |a|_1 + |h|_1 + 1 (the rounding of
+//     the nine-term products is < 3e-7 s); eps_k = 1e-3 + 1e-6 s |1 / b_k| is used for plane k, in metres and in units of t alike
+//     (|d| = 1).  1 / b_k is clamped to +-1e30: a ray parallel to a plane has eps ~ 1e24 and keeps every face (the exact test decides).
+//   * a box is convex: the FIRST crossing of a ray with it is at t_first = the slab entry max_k(near_k) if that is >= 0 (origin
+//     outside), else the slab exit min_k(far_k) (origin inside); the exact test can accept a triangle of face F only where the ray
+//     really crosses F (up to ~1e-6 m), i.e. at plane-crossing time t_F inside the face's rectangle.  A crossing later than t_first + eps
+//     loses the (t, face) minimum to the first one, unless the exact test rejects the first one -- which it can only where the first
+//     crossing sits within rounding of the face's rim, and then another face is crossed within eps of t_first, too (the surface is
+//     closed; the exact test is watertight).  So the candidates are the faces with |t_F - t_first| <= 2 eps (the slab overlap says the
+//     crossing point lies inside the face's rectangle, up to eps); t_first itself must lie in [-eps, best + eps].  An origin within the tolerance of the surface keeps
+//     the faces around the EXIT as well (t_alt).  Occlusion rays (ANY) ask whether SOME triangle is hit in [0, best): the first
+//     crossing answers that as well.
+//   * then the face's two triangles go through the same exact test as a two-triangle leaf (test_leaf_pair), masked by the lane's
+//     candidate flag.
+//     Faces of trimesh's box by triangle: -x (0, 2)  +x (10, 11)  -y (1, 5)  +y (7, 9)  -z (3, 8)  +z (4, 6).
+template <int UPID>
+AGX_DEV uint32_t box_face_candidates(const Ray &r, float4 n0, float4 n1, float4 n2, float4 n3) {
+  const V3 o = ray_origin<UPID>(r);
+  const V3 oc = V3{o.x - n3.x, o.y - n3.y, o.z - n3.z};
+  const float a0 = n0.x * oc.x + n0.y * oc.y + n0.z * oc.z, a1 = n1.x * oc.x + n1.y * oc.y + n1.z * oc.z,
+              a2 = n2.x * oc.x + n2.y * oc.y + n2.z * oc.z;
+  const float b0 = n0.x * r.d.x + n0.y * r.d.y + n0.z * r.d.z, b1 = n1.x * r.d.x + n1.y * r.d.y + n1.z * r.d.z,
+              b2 = n2.x * r.d.x + n2.y * r.d.y + n2.z * r.d.z;
+  const float h0 = n0.w, h1 = n1.w, h2 = n2.w;
+  const float kMax = 1.0e30f;
+  // (v_rcp_f32, 1 ulp: the tolerance below absorbs it; a correctly rounded 1 / b is ten instructions each)
+#ifndef AGX_RAY_EXACT_RCP
+  const float rb0 = fminf(fmaxf(__builtin_amdgcn_rcpf(b0), -kMax), kMax), rb1 = fminf(fmaxf(__builtin_amdgcn_rcpf(b1), -kMax), kMax),
+              rb2 = fminf(fmaxf(__builtin_amdgcn_rcpf(b2), -kMax), kMax);
+#else
+  const float rb0 = fminf(fmaxf(1.0f / b0, -kMax), kMax), rb1 = fminf(fmaxf(1.0f / b1, -kMax), kMax), rb2 = fminf(fmaxf(1.0f / b2, -kMax), kMax);
+#endif
+  const float s = 1.0e-6f * (((fabsf(a0) + fabsf(a1)) + (fabsf(a2) + h0)) + ((h1 + h2) + 1.0f));
+  const float e0 = fmaf(s, fabsf(rb0), 1.0e-3f), e1 = fmaf(s, fabsf(rb1), 1.0e-3f), e2 = fmaf(s, fabsf(rb2), 1.0e-3f);
+  const float eps = fmaxf(fmaxf(e0, e1), e2);
+  // plane-crossing times: minus / plus face of each axis
+  const float tm0 = (-h0 - a0) * rb0, tp0 = (h0 - a0) * rb0;
+  const float tm1 = (-h1 - a1) * rb1, tp1 = (h1 - a1) * rb1;
+  const float tm2 = (-h2 - a2) * rb2, tp2 = (h2 - a2) * rb2;
+  const float t_enter = fmaxf(fmaxf(fminf(tm0, tp0), fminf(tm1, tp1)), fminf(tm2, tp2));
+  const float t_exit = fminf(fminf(fmaxf(tm0, tp0), fmaxf(tm1, tp1)), fmaxf(tm2, tp2));
+  const float t_first = t_enter >= -eps ? t_enter : t_exit;
+  const float two_eps = 2.0f * eps;
+  // an origin within the tolerance of the surface: the exact test may place the entry at t < 0 and reject it -- then the exit is the
+  // first hit it accepts (stereo occlusion rays start 0.1 % of the range in front of a surface: sub-millimetre at close range)
+  const float t_alt = fabsf(t_enter) <= two_eps ? t_exit : t_first;
+  // the box is crossed at all (entry before exit, up to the tolerance), and its first crossing is a possible result
+  const bool live = (t_enter <= t_exit + two_eps) & (t_first >= -eps) & (t_first <= r.best + eps);
+  // Which faces: the one(s) whose plane is crossed AT the first crossing (|t_F - t_first| <= 2 eps: the entry face is the face whose
+  // near plane gives the slab entry; at an edge or a corner two or three tie), plus those at the exit for an origin on the surface.
+  // The crossing point needs no test of its own: `live` says the slabs overlap, i.e. the point at t_first is inside the box's other
+  // two slabs.  The six verdicts are packed into ONE register before the first triangle test: nothing of the box-frame arithmetic
+  // stays live across the exact tests (they take the kernel's whole register budget).
+  uint32_t cbits = 0u;
+#define AGX_BOX_FACE(BIT, TF) cbits |= (live & ((fabsf((TF)-t_first) <= two_eps) | (fabsf((TF)-t_alt) <= two_eps))) ? (1u << (BIT)) : 0u;
+  AGX_BOX_FACE(0, tm0)
+  AGX_BOX_FACE(1, tp0)
+  AGX_BOX_FACE(2, tm1)
+  AGX_BOX_FACE(3, tp1)
+  AGX_BOX_FACE(4, tm2)
+  AGX_BOX_FACE(5, tp2)
+#undef AGX_BOX_FACE
+  return cbits;  // bit k: face k (-x +x -y +y -z +z) may hold this ray's result; its triangles: nibble k of 0x4371A0 / 0x6895B2
+}
+
 // Conservative slab test, one fma per plane: t = b * rcp - o * rcp, with rcp CLAMPED to +-1e30 in ray_setup.
 // Why this never culls a box that holds a hit (boxes are grown by kBoxEps = 1e-3 at build time; |coords| < 10 km):
 //   * |d_c| > 1e-30: the products are finite (|b| |rcp| < 1e34); the only new error vs (b - o) * rcp is the
@@ -236,57 +333,66 @@ AGX_DEV bool ray_box(const Ray &r, float lx, float ly, float lz, float hx, float
   return fmaxf(tmin, 0.0f) <= fminf(tmax, r.best);
 }
 
-AGX_DEV unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }  // the mask itself, no round trip through a VGPR
 
 // Packet traversal: the whole wave follows one path.  The stack is a single VGPR whose lane k holds entry k (depth <= 64 > 30
 // Morton bits + log2(T) tie bits of the LBVH).  Votes of conjunctions are mask arithmetic on the votes of their terms (the
 // ballot of ONE comparison is the comparison's own mask).
 template <bool ANY, int UPID>
-AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
-  if (nt == 1) {
-    test_leaf_pair<ANY, UPID>(r, tris, 0, -1, r.active);
-    return;
-  }
+AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris) {
   int sp = 0;
   int node = 0;
   int stack = 0;
   const int lane = threadIdx.x & 63;
   while (true) {
     // 32-bit byte offsets from the env's node block (< 2^31 bytes): a scalar load with a register offset, no 64-bit address arithmetic
-    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)node << 6));
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + (((uint32_t)node & 0x3FFFFFFFu) << 6));
     float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-    int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
-    const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
-    float tl, tr;
-    bool hl = ray_box<UPID>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
-    bool hr = ray_box<UPID>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
-    unsigned long long ml = vote(hl), mr = vote(hr);
-    if (cl < 0) {
-      if (ml) test_leaf_pair<ANY, UPID>(r, tris, ~cl, cl2, hl);
-      ml = 0;
-    }
-    if (cr < 0) {
-      if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
-        mr &= vote(tr <= r.best);
-        hr = hr && (tr <= r.best);
-      }
-      if (mr) test_leaf_pair<ANY, UPID>(r, tris, ~cr, cr2, hr);
-      mr = 0;
-    }
     int next = -1;
-    if (ml && mr) {
-      // majority vote on which child is nearer among lanes that hit both
-      const unsigned long long both = ml & mr;
-      const unsigned long long lfirst = both & vote(tl <= tr);
-      const bool left_first = both ? (2 * (int)__popcll(lfirst) >= (int)__popcll(both)) : ((int)__popcll(ml) >= (int)__popcll(mr));
-      next = left_first ? cl : cr;
-      int far = left_first ? cr : cl;
-      stack = (lane == (sp & (kStackDepth - 1))) ? far : stack;  // push: entry sp lives in lane sp
-      ++sp;
-    } else if (ml) {
-      next = cl;
-    } else if (mr) {
-      next = cr;
+    // (the ordinary node is the fall-through of the wave-uniform branch, the object node the arm behind it: one taken branch per
+    //  object visit instead of one per node visit)
+    if (__builtin_expect((node & AGX_BVH_OBJECT_REF) == 0, 1)) {
+      int cl = __float_as_int(n0.w), cr = __float_as_int(n1.w);
+      const int cl2 = __float_as_int(n2.w), cr2 = __float_as_int(n3.w);  // second triangle of a two-triangle leaf, or -1
+      float tl, tr;
+      bool hl = ray_box<UPID>(r, n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, tl);
+      bool hr = ray_box<UPID>(r, n2.x, n2.y, n2.z, n3.x, n3.y, n3.z, tr);
+      unsigned long long ml = vote(hl), mr = vote(hr);
+      if (cl < 0) {
+        if (ml) test_leaf_pair<ANY, UPID>(r, tris, ~cl, cl2, hl);
+        ml = 0;
+      }
+      if (cr < 0) {
+        if (cl < 0 && mr) {  // the left leaf may just have shortened the rays: vote again with the new `best`
+          mr &= vote(tr <= r.best);
+          hr = hr && (tr <= r.best);
+        }
+        if (mr) test_leaf_pair<ANY, UPID>(r, tris, ~cr, cr2, hr);
+        mr = 0;
+      }
+      if (ml && mr) {
+        // majority vote on which child is nearer among lanes that hit both
+        const unsigned long long both = ml & mr;
+        const unsigned long long lfirst = both & vote(tl <= tr);
+        const bool left_first = both ? (2 * (int)__popcll(lfirst) >= (int)__popcll(both)) : ((int)__popcll(ml) >= (int)__popcll(mr));
+        next = left_first ? cl : cr;
+        int far = left_first ? cr : cl;
+        stack = (lane == (sp & (kStackDepth - 1))) ? far : stack;  // push: entry sp lives in lane sp
+        ++sp;
+      } else if (ml) {
+        next = cl;
+      } else if (mr) {
+        next = cr;
+      }
+    } else {  // an OBJECT NODE: the box itself, no children
+      const uint32_t cbits = box_face_candidates<UPID>(r, n0, n1, n2, n3);
+      const int f0 = __float_as_int(n3.w);
+      // ONE copy of the exact test, looped over the faces somebody wants (unrolled, the scheduler hoists all twelve triangles' scalar
+      // loads in front of the first test: 108 more live scalars in a kernel that spills scalars to lanes already)
+#pragma nounroll
+      for (int k = 0; k < 6; ++k) {
+        const bool want = (cbits & (1u << k)) != 0u;
+        if (vote(want)) test_leaf_pair<ANY, UPID>(r, tris, f0 + (int)((0x4371A0u >> (4 * k)) & 15u), f0 + (int)((0x6895B2u >> (4 * k)) & 15u), want);
+      }
     }
     if (next < 0) {
       if (sp == 0) break;
@@ -300,6 +406,11 @@ AGX_DEV void traverse_impl(Ray &r, const float *__restrict__ nodes, const float 
 // ANY: occlusion query -- the first accepted hit retires the lane
 template <bool ANY = false>
 AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__restrict__ tris, int nt) {
+  if (!r.active) r.best = -INFINITY;  // (a lane outside the image: nobody reads its `best`)
+  if (nt == 1) {  // a one-triangle scene has no node: the generic instance of the test, once
+    test_leaf_pair<ANY, -1>(r, tris, 0, -1, r.active);
+    return;
+  }
   // do all active rays of the packet share the dominant axis and its orientation?
   int upid = -1;  // 2 * kz + swap, or -1 (mixed)
   {
@@ -310,15 +421,14 @@ AGX_DEV void traverse(Ray &r, const float *__restrict__ nodes, const float *__re
       if (vote(r.active && pid != p0) == 0ull) upid = p0;
     }
   }
-  if (!r.active) r.best = -INFINITY;  // (a lane outside the image: nobody reads its `best`)
   switch (upid) {  // wave-uniform, once per packet: seven copies of the loop (-2 % vs a switch in front of every triangle test)
-    case 0: traverse_impl<ANY, 0>(r, nodes, tris, nt); break;
-    case 1: traverse_impl<ANY, 1>(r, nodes, tris, nt); break;
-    case 2: traverse_impl<ANY, 2>(r, nodes, tris, nt); break;
-    case 3: traverse_impl<ANY, 3>(r, nodes, tris, nt); break;
-    case 4: traverse_impl<ANY, 4>(r, nodes, tris, nt); break;
-    case 5: traverse_impl<ANY, 5>(r, nodes, tris, nt); break;
-    default: traverse_impl<ANY, -1>(r, nodes, tris, nt); break;
+    case 0: traverse_impl<ANY, 0>(r, nodes, tris); break;
+    case 1: traverse_impl<ANY, 1>(r, nodes, tris); break;
+    case 2: traverse_impl<ANY, 2>(r, nodes, tris); break;
+    case 3: traverse_impl<ANY, 3>(r, nodes, tris); break;
+    case 4: traverse_impl<ANY, 4>(r, nodes, tris); break;
+    case 5: traverse_impl<ANY, 5>(r, nodes, tris); break;
+    default: traverse_impl<ANY, -1>(r, nodes, tris); break;
   }
 }
 
@@ -405,26 +515,41 @@ __global__ void __launch_bounds__(kRayThreads, VARIANT == 2 ? AGX_RAY_STEREO_WAV
   constexpr int kTileW = Tile<LIDAR>::W, kTileH = Tile<LIDAR>::H;
   const int tiles_x = (width + kTileW - 1) / kTileW, tiles_y = (height + kTileH - 1) / kTileH;
   for (int tile = (int)part * (kRayThreads / 64) + wave; tile < tiles_x * tiles_y; tile += split * (kRayThreads / 64)) {
-    const int x = (tile % tiles_x) * kTileW + (lane % kTileW), y = (tile / tiles_x) * kTileH + (lane / kTileW);
-    const bool active = x < width && y < height;
-    V3 local = V3{0.0f, 0.0f, 1.0f};
-    if (active) {
-      if (LIDAR) {
-        const float *rv = ray_vectors + ((size_t)y * width + x) * 3;
-        local = wp_normalize(V3{rv[0], rv[1], rv[2]});
-      } else {
-        // wp.transform_vector(K_inv, (x, y, 1)) (warp_camera_kernels.py:199-200)
-        local = V3{CA.k00 * (float)x + CA.k02, CA.k11 * (float)y + CA.k12, 1.0f};
-        if (mode >= AGX_RAY_POINTCLOUD) local = wp_normalize(local);
+    // the pixel's ray in the sensor frame: wp.transform_vector(K_inv, (x, y, 1)) (warp_camera_kernels.py:199-200) / the ray table
+    auto local_ray = [&](int px_x, int px_y, bool on) {
+      V3 l = V3{0.0f, 0.0f, 1.0f};
+      if (on) {
+        if (LIDAR) {
+          const float *rv = ray_vectors + ((size_t)px_y * width + px_x) * 3;
+          l = wp_normalize(V3{rv[0], rv[1], rv[2]});
+        } else {
+          l = V3{CA.k00 * (float)px_x + CA.k02, CA.k11 * (float)px_y + CA.k12, 1.0f};
+          if (mode >= AGX_RAY_POINTCLOUD) l = wp_normalize(l);
+        }
       }
-    }
-    V3 rd = wp_normalize(wp_quat_rotate(sq, local));
-    float mult = 1.0f;
-    if (!LIDAR && mode == AGX_RAY_DEPTH) mult = dot(rd, rdp);
-    float max_t = (!LIDAR && mode <= AGX_RAY_DEPTH) ? far_plane / mult : far_plane;
+      return l;
+    };
     Ray r;
-    ray_setup(r, ro, rd, max_t, active);
+    {
+      const int x0 = (tile % tiles_x) * kTileW + (lane % kTileW), y0 = (tile / tiles_x) * kTileH + (lane / kTileW);
+      const bool on = x0 < width && y0 < height;
+      const V3 rd0 = wp_normalize(wp_quat_rotate(sq, local_ray(x0, y0, on)));
+      const float mult0 = (!LIDAR && mode == AGX_RAY_DEPTH) ? dot(rd0, rdp) : 1.0f;
+      ray_setup(r, ro, rd0, (!LIDAR && mode <= AGX_RAY_DEPTH) ? far_plane / mult0 : far_plane, on);
+    }
     traverse(r, nodes, tris, nt);
+    // Nothing but the ray's own state is carried across the traversal (the loop takes the whole register budget; what a store needs
+    // was spilled to scratch around it): pixel coordinates, the sensor-frame ray and the depth multiplier are evaluated AGAIN here --
+    // the same operations on the same operands, the same bits.  (The lane id goes through an empty asm so that the compiler does not
+    // recognise the expressions and keep their first values alive.)
+    int lane_again = lane;
+    asm volatile("" : "+v"(lane_again));
+    const int x = (tile % tiles_x) * kTileW + (lane_again % kTileW), y = (tile / tiles_x) * kTileH + (lane_again / kTileW);
+    const bool active = x < width && y < height;
+    const V3 rd = r.d;
+    const float mult = (!LIDAR && mode == AGX_RAY_DEPTH) ? dot(rd, rdp) : 1.0f;
+    V3 local = V3{0.0f, 0.0f, 1.0f};
+    if (mode >= AGX_RAY_POINTCLOUD && mode != AGX_RAY_POINTCLOUD_WORLD && VARIANT != RAY_NORMAL) local = local_ray(x, y, active);
     const size_t px = ((sidx * height) + y) * width + x;
     if (VARIANT == RAY_NORMAL) {
       // miss: zero normal, face -1 (the reference's `n`, `f` stay at their initial values)

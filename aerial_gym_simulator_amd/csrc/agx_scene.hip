@@ -200,13 +200,74 @@ AGX_DEV void bitonic_sort_lds(unsigned long long *keys, int m, int tid) {
   }
 }
 
+// AGX_BVH_BOX_OBJECTS: is internal node c the root of exactly ONE object's 12 triangles, and do those make an orthogonal box of
+// trimesh.creation.box's topology?  Then (rec != nullptr) its record is the box's frame (include/aerial_gym_hip.h).  The key range
+// of node c is [min(c, j), max(c, j)], j left in counter[c] >> 2 by the radix-tree pass.  Faces of trimesh's box (corners
+// ({0,1}^3 - 0.5) * extents, index 4 x + 2 y + z): triangle 0 = (1, 3, 0), 1 = (4, 1, 0), 2 = (0, 3, 2), 11 = (7, 5, 6).
+AGX_DEV bool box_object_record(const unsigned long long *keys, const int *counter, const float *__restrict__ tris, int c, float *rec) {
+  const int j = counter[c] >> 2;
+  const int first = min(c, j), last = max(c, j);
+  if (last - first != 11) return false;
+  const int f0 = (int)(uint32_t)(keys[first] & 0xFFFFFFFFull);
+  const int obj = f0 / 12;
+  for (int r = 1; r < 12; ++r)
+    if ((int)(uint32_t)(keys[first + r] & 0xFFFFFFFFull) / 12 != obj) return false;
+  const float *t = tris + (size_t)obj * 12 * 9;
+  const V3 v1 = V3{t[0], t[1], t[2]}, v0 = V3{t[6], t[7], t[8]};          // triangle 0 = (1, 3, 0)
+  const V3 v4 = V3{t[9], t[10], t[11]};                                     // triangle 1 = (4, 1, 0)
+  const V3 v2 = V3{t[18 + 6], t[18 + 7], t[18 + 8]};                        // triangle 2 = (0, 3, 2)
+  const V3 v7 = V3{t[99], t[100], t[101]};                                  // triangle 11 = (7, 5, 6)
+  const V3 ex = v4 - v0, ey = v2 - v0, ez = v1 - v0;
+  const float lx = sqrtf(dot(ex, ex)), ly = sqrtf(dot(ey, ey)), lz = sqrtf(dot(ez, ez));
+  if (!(lx > 1.0e-5f && ly > 1.0e-5f && lz > 1.0e-5f) || !(lx < 1.0e4f && ly < 1.0e4f && lz < 1.0e4f)) return false;
+  const V3 nx = ex * (1.0f / lx), ny = ey * (1.0f / ly), nz = ez * (1.0f / lz);
+  if (fabsf(dot(nx, ny)) > 1.0e-4f || fabsf(dot(ny, nz)) > 1.0e-4f || fabsf(dot(nz, nx)) > 1.0e-4f) return false;
+  const V3 far = v0 + ex + ey + ez - v7;  // the opposite corner is where a box has it
+  if (!(sqrtf(dot(far, far)) <= 1.0e-4f * (lx + ly + lz))) return false;
+  // ... and every one of the 12 triangles is where the ray-cast's face table expects it: its three vertices are corners of the box,
+  // in the plane of its face, and the two triangles of a face have four distinct corners between them (they tile the rectangle).
+  // Faces by triangle: -x (0, 2)  +x (10, 11)  -y (1, 5)  +y (7, 9)  -z (3, 8)  +z (4, 6)  (trimesh.creation.box's face order).
+  {
+    const V3 cen = v0 + (ex + ey + ez) * 0.5f;
+    const float hx = 0.5f * lx, hy = 0.5f * ly, hz = 0.5f * lz, tol = 1.0e-4f * (lx + ly + lz) + 1.0e-5f;
+    constexpr int kFaceOf[12] = {0, 2, 0, 4, 5, 2, 5, 3, 4, 3, 1, 1};  // 2 * axis + (plus side)
+    uint32_t seen[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    for (int q = 0; q < 12; ++q) {
+      const int face = kFaceOf[q], axis = face >> 1;
+      const float want = (face & 1) ? 1.0f : -1.0f;
+      uint32_t ids = 0u;
+      for (int v = 0; v < 3; ++v) {
+        const V3 p = V3{t[9 * q + 3 * v] - cen.x, t[9 * q + 3 * v + 1] - cen.y, t[9 * q + 3 * v + 2] - cen.z};
+        const float l0 = dot(nx, p), l1 = dot(ny, p), l2 = dot(nz, p);
+        if (fabsf(fabsf(l0) - hx) > tol || fabsf(fabsf(l1) - hy) > tol || fabsf(fabsf(l2) - hz) > tol) return false;
+        const float la = axis == 0 ? l0 : (axis == 1 ? l1 : l2);
+        if (!(la * want > 0.0f)) return false;
+        ids |= 1u << ((l0 > 0.0f ? 4 : 0) | (l1 > 0.0f ? 2 : 0) | (l2 > 0.0f ? 1 : 0));
+      }
+      if (__popc(ids) != 3) return false;
+      seen[face] |= ids;
+    }
+    for (int f = 0; f < 6; ++f)
+      if (__popc(seen[f]) != 4) return false;
+  }
+  if (rec) {
+    const V3 cen = v0 + (ex + ey + ez) * 0.5f;
+    rec[0] = nx.x; rec[1] = nx.y; rec[2] = nx.z; rec[3] = 0.5f * lx;
+    rec[4] = ny.x; rec[5] = ny.y; rec[6] = ny.z; rec[7] = 0.5f * ly;
+    rec[8] = nz.x; rec[9] = nz.y; rec[10] = nz.z; rec[11] = 0.5f * lz;
+    rec[12] = cen.x; rec[13] = cen.y; rec[14] = cen.z; rec[15] = __int_as_float(obj * 12);
+  }
+  return true;
+}
+
 // Node record written to HBM (16 floats):
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
 // child >= 0: internal node index, child < 0: leaf holding triangle ~child and, if second >= 0, that triangle too.
 AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
   const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
-  ppo &= ~AGX_BVH_FULL_SORT;
+  const bool box_objects = (ppo & AGX_BVH_BOX_OBJECTS) != 0;
+  ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
@@ -468,7 +529,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     child[2 * i + 1] = right;
     parent[left] = i;
     parent[right] = i;
-    counter[i] = 0;
+    counter[i] = j << 2;  // arrival count in the two low bits; the other end of the node's key range above them (emit stage)
   }
   if (tid == 0) parent[0] = -1;
   __syncthreads();
@@ -477,7 +538,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     int node = parent[n_int + i];
     while (node >= 0) {
       __threadfence_block();  // release: this thread's box is written before the arrival
-      if (atomicAdd(&counter[node], 1) == 0) break;
+      if ((atomicAdd(&counter[node], 1) & 3) == 0) break;
       __threadfence_block();  // acquire: the sibling's box is read after the arrival
       float a[6], b[6];
       node_box(box, keys, tris, n_int, child[2 * node], a);
@@ -505,6 +566,8 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       second[side] = -1;
       if (c >= n_int) {
         ref[side] = ~(int)(uint32_t)(keys[c - n_int] & 0xFFFFFFFFull);
+      } else if (box_objects && box_object_record(keys, counter, tris, c, nullptr)) {
+        ref[side] = c | AGX_BVH_OBJECT_REF;  // the child is an OBJECT NODE: the tree ends at the box
       } else if (child[2 * c] >= n_int && child[2 * c + 1] >= n_int) {
         ref[side] = ~(int)(uint32_t)(keys[child[2 * c] - n_int] & 0xFFFFFFFFull);
         second[side] = (int)(uint32_t)(keys[child[2 * c + 1] - n_int] & 0xFFFFFFFFull);
@@ -512,8 +575,9 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
         ref[side] = c;
       }
     }
-    const float *a = bx[0], *b = bx[1];
     float *o = out + (size_t)i * 16;
+    if (box_objects && i > 0 && box_object_record(keys, counter, tris, i, o)) continue;  // this node IS an object node (the same test its parent made)
+    const float *a = bx[0], *b = bx[1];
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(ref[0]);
     o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(ref[1]);
     o[8] = b[0]; o[9] = b[1]; o[10] = b[2]; o[11] = __int_as_float(second[0]);
@@ -645,7 +709,8 @@ extern "C" int agx_assets_integrate(int n, int num_assets, float *asset_state, c
 // argument checks and launch shape shared by the two LBVH builders; `kernel`'s dynamic LDS limit is raised once (*attr_set)
 static int bvh_launch_shape(int nt, int prims_per_object, int *npad_out, size_t *lds_out, const void *kernel, bool *attr_set) {
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
-  const int ppo = prims_per_object & ~AGX_BVH_FULL_SORT;  // (AGX_BVH_FULL_SORT: test hook, include/aerial_gym_hip.h)
+  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);  // (flags: include/aerial_gym_hip.h)
+  AGX_REQUIRE(!(prims_per_object & AGX_BVH_BOX_OBJECTS) || ppo == 12, "AGX_BVH_BOX_OBJECTS goes with objects of 12 triangles");
   AGX_REQUIRE(ppo == 0 || (ppo >= 9 && nt % ppo == 0),
               "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;

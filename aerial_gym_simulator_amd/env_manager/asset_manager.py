@@ -103,5 +103,5 @@ class AssetManager:
             st = sc.prim_state
         # triangles -> world frame, collision boxes, LBVH: one call (masked: one persistent launch over the dirty envs)
         _lib.check(lib.agx_scene_refresh(N, sc.num_tris, KP, p(sc.tri_local), p(sc.tri_asset), p(st), p(sc.half_extents),
-                                         int(getattr(env, 'bvh_prims_per_object', 12)), mk, p(sc.tri_world), p(sc.boxes_soa),
+                                         int(getattr(env, 'bvh_prims_per_object', None) or sc.bvh_prims_per_object), mk, p(sc.tri_world), p(sc.boxes_soa),
                                          p(sc.bvh_nodes), p(sc.bvh_work), stream), "agx_scene_refresh")

@@ -48,6 +48,11 @@ class SceneManager:
         K = self.num_assets = len(keep_slots) + len(free_slots)
         self.num_tris = 12 * K
         self.num_prims, self.has_prims = K, False  # collision / scene pieces: one per asset unless a URDF has several links
+        # objects of 12 consecutive triangles (agx_bvh_build) + AGX_BVH_BOX_OBJECTS: where an object's 12 triangles ARE a box of
+        # trimesh's topology -- the builder checks every vertex -- the tree ends at the object and the ray-cast kernels intersect
+        # the box's frame, running the exact triangle test on the entered face only (same frames, bit for bit); chunks of a
+        # cylinder / sphere / mesh keep their triangle subtrees.  AGX_BVH_BOX_OBJECTS=0: triangle subtrees everywhere (A/B runs).
+        self.bvh_prims_per_object = 12 | (0x20000000 if os.environ.get("AGX_BVH_BOX_OBJECTS", "1") != "0" else 0)
         # sharding: start of this rank's slice of the global asset counter
         semantic_offset = self.semantic_offset = env_offset * K  # this shard's slice of the global id counter
         if K == 0:

@@ -53,6 +53,10 @@ def parse():
                     help="N > 1: who enqueues the per-step all-gather. auto = time both (torch's process group first, then the "
                          "library's RCCL worker thread under a watchdog) and report the faster one as `value`")
     ap.add_argument("--strict-rng", action="store_true", help="reference-faithful RNG consumption (host sync per step)")
+    ap.add_argument("--exchange-selftest-only", action="store_true",
+                    help="no timing: build every exchange backend (process_group, peer_push, rccl_thread) on the N ranks, run "
+                         "--selftest-steps checksum-verified exchange steps on each and print ONE JSON verdict line per backend")
+    ap.add_argument("--selftest-steps", type=int, default=1000)
     args = ap.parse_args()
     if args.num_envs is None:
         args.num_envs = 4096 if args.workload in ("lidar", "lidar_velocity") else 8192
@@ -837,6 +841,96 @@ def sensor_leg(args, workload, num_envs, device, rank, world, use_dist, primary_
     return leg
 
 
+def exchange_selftest(args, world, rank, device, limit_s=60.0):
+    """`--exchange-selftest-only`: first contact with an N-GPU node made cheap.  Per backend: the communicator / IPC mappings are
+    built, `--selftest-steps` real env steps run with the per-step exchange, every rank checksums the rows it SENT and every
+    slice it RECEIVED (bit patterns summed as integers: exact, order-independent), the sent checksums travel over the process
+    group and are compared step by step -- the checks of tests/exchange_world2_worker.py.  One JSON line per backend on rank 0's
+    stdout: which leg failed, in which stage, and which (receiver, sender) pair first disagreed at which step.  Nothing is timed
+    for the record; a leg that does not come back within `limit_s` prints what it has and ends the process."""
+    import threading
+
+    import torch.distributed as dist
+    from aerial_gym_simulator_amd.sharding import StepGather
+
+    steps, N = int(args.selftest_steps), args.num_envs
+    for backend in ("process_group", "peer_push", "rccl_thread"):
+        res = {"selftest": "exchange", "backend": backend, "world": world, "steps": steps, "num_envs_per_rank": N, "ok": False}
+        stage = ["build"]
+
+        def give_up(res=res, stage=stage):
+            res["error"] = f"no completion within {limit_s:.0f} s (rank {rank} was in stage '{stage[0]}')"
+            if rank == 0:
+                emit_line(res)
+            os._exit(3)
+
+        dog = threading.Timer(limit_s, give_up)
+        dog.daemon = True
+        dog.start()
+        t0 = time.perf_counter()
+        mine_bad = {}
+        try:
+            task = make_task("dynamics", N, device, False, rank)
+            task.reset()
+            desynchronise_episodes(task)  # resets (and the rows they rewrite) are part of every step
+            d = task.task_obs["observations"].shape[1]
+            g = torch.Generator(device=device).manual_seed(99 + rank)
+            actions = [torch.rand(N, task.task_config.action_space_dim, device=device, generator=g) * 2 - 1 for _ in range(8)]
+            stage[0] = "setup"
+            sg = StepGather(N, d, device, env=task.sim_env, reward=task.rewards, backend=backend)
+            stage[0] = "run"
+            res["communicator"] = dict(zip(("rank", "ranks"), sg.comm_info()))
+            if backend == "peer_push":
+                res["connection_selftest"], res["kernel_push"] = sg.push_selftest, bool(sg._kernel_push)
+            if res["communicator"]["ranks"] != world:
+                raise RuntimeError(f"the communicator spans {res['communicator']['ranks']} ranks, the job has {world}")
+            W, lag = d + 3, sg.lag
+            own = torch.zeros(steps, dtype=torch.int64, device=device)
+            got = torch.zeros(steps, world, dtype=torch.int64, device=device)
+            own_ok = torch.ones((), dtype=torch.bool, device=device)
+            history = []
+            for t in range(steps):
+                obs, rew, term, trunc, _ = task.step(actions[t % 8])
+                out = sg.exchange(task.sim_env._parity, overlap=True)
+                rows = torch.cat([obs["observations"], rew[:, None], term[:, None].float(), trunc[:, None].float()], dim=1)
+                own[t] = rows.view(torch.int32).long().sum()
+                history.append(rows)
+                if out is not None:
+                    got[t - lag] = out.view(torch.int32).view(world, N, W).long().sum(dim=(1, 2))
+                    own_ok &= torch.equal(out.view(world, N, W)[rank], history[-lag - 1])
+                history = history[-3:]
+            sg.flush()
+            torch.cuda.synchronize()
+            stage[0] = "compare"
+            sent = torch.zeros(world * steps, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(sent, own)
+            last = steps - lag
+            wrong = got[:last] != sent.view(world, steps).t()[:last]
+            for sender in range(world):
+                idx = wrong[:, sender].nonzero()
+                if idx.numel():
+                    mine_bad[sender] = int(idx[0])
+            res_rank = {"rank": rank, "ok": not mine_bad and bool(own_ok), "own_slice_ok": bool(own_ok),
+                        "first_bad_step_by_sender": mine_bad, "resets": int(task.sim_env.global_tensor_dict["episode_count"].sum()) - N}
+            stage[0] = "close"
+            sg.close()
+            del task, sg
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            res_rank = {"rank": rank, "ok": False, "error": f"{type(e).__name__}: {e}", "failed_in": stage[0]}
+        stage[0] = "verdict"
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, res_rank)
+        dog.cancel()
+        res.update(ok=all(r["ok"] for r in per_rank), per_rank=per_rank, seconds=time.perf_counter() - t0)
+        if rank == 0:
+            emit_line(res)
+        if any("error" in r and r.get("failed_in") not in ("setup",) for r in per_rank):
+            # something half-built may be left behind (a communicator some rank never joined): no further legs, no teardown
+            sys.stdout.flush()
+            os._exit(0 if rank != 0 else 4)
+
+
 def ensure_ranks(args):
     """`--gpus N` is a request for N ranks, one per GPU, and it is honoured or refused -- never silently reduced:
 
@@ -916,7 +1010,7 @@ def main():
     torch.cuda.set_device(local_rank)
     diag = rank_diagnostics(rank, world, local_rank)
     device = f"cuda:{local_rank}"
-    use_dist = world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or os.environ.get("AGX_BENCH_FORCE_DIST") == "1" or args.exchange_selftest_only
     json_fd = None
     if use_dist:
         # RCCL prints a version banner on stdout when a communicator goes away: keep stdout for the ONE JSON line
@@ -933,6 +1027,13 @@ def main():
         else:
             dist.init_process_group("nccl")  # RCCL over xGMI; rank / world size / master from the env
     n_gpus = max(world, 1)
+    if args.exchange_selftest_only:
+        import torch.distributed as dist
+
+        exchange_selftest(args, world, rank, device)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     task = make_task(args.workload, args.num_envs, device, args.strict_rng, rank)
     task.reset()
     N, A = task.num_envs, task.task_config.action_space_dim

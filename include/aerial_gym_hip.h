@@ -563,6 +563,19 @@ int agx_assets_integrate(int num_envs, int num_assets, float *asset_state, const
  * object (the full key sort runs only when two objects that are in the env share a code); AGX_BVH_FULL_SORT ORed into
  * prims_per_object forces the full sort -- a test hook: both must give the same tree.   */
 #define AGX_BVH_FULL_SORT 0x40000000
+/* AGX_BVH_BOX_OBJECTS ORed into prims_per_object (= 12): every object is a box of trimesh.creation.box's topology (the
+ * reference's box URDFs through urdfpy: 8 corners, the 12 faces in trimesh's order).  The builder then ends the tree at the
+ * OBJECT: the subtree root whose leaves are exactly one object's 12 triangles becomes an OBJECT NODE -- its 64-byte record
+ * holds the box's frame instead of two child boxes,
+ *     [0..2] axis x (unit, world)  [3] half extent x     [4..6] axis y  [7] half extent y
+ *     [8..10] axis z               [11] half extent z    [12..14] centre  [15] index of the object's first triangle (int bits)
+ * (derived from the object's world-frame triangles: corners 0, 1, 2, 4 of the box), and the parent's child reference carries
+ * AGX_BVH_OBJECT_REF.  The ray-cast kernels intersect the box's slabs in its own frame, conservatively (tolerance >> rounding),
+ * and run the exact triangle test only on the face(s) a ray can enter through: the closest hit over the triangles the exact test
+ * accepts -- the result's definition -- is unchanged, the five in-object nodes and most face tests are gone.  An object whose
+ * triangles do not make an orthogonal box (or whose keys interleave with another object's) keeps its triangle subtree.     */
+#define AGX_BVH_BOX_OBJECTS 0x20000000
+#define AGX_BVH_OBJECT_REF 0x40000000   /* bit 30 of a non-negative child reference: the child is an object node */
 size_t agx_bvh_nodes_bytes(int num_envs, int num_tris);
 int agx_bvh_build(int num_envs, int num_tris, int prims_per_object, const float *tri_world,
                   const uint8_t *mask, float *nodes, int32_t *work, void *stream);

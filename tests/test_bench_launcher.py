@@ -57,7 +57,7 @@ def test_world_size_mismatch_is_refused_loudly():
 def test_self_spawn_path_prints_the_same_line():
     """AGX_BENCH_SPAWN=1 sends --gpus 1 through the launcher (torch.distributed.run, one rank): ONE JSON line on stdout with the
     keys of the direct run, n_gpus 1, and the rank's device diagnostics on stderr"""
-    argv = ["--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-depth"]
+    argv = ["--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-depth", "--no-lidar", "--no-strict"]
     direct = run_bench(argv)
     assert direct.returncode == 0, direct.stderr[-3000:]
     spawned = run_bench(argv, {"AGX_BENCH_SPAWN": "1"})
@@ -69,3 +69,18 @@ def test_self_spawn_path_prints_the_same_line():
     assert set(a) == set(b)
     assert "torch.distributed.run" in spawned.stderr and "[bench rank 0/1]" in spawned.stderr and '"can_access_peer"' in spawned.stderr
     assert 0.2 < b["value"] / a["value"] < 5.0
+
+
+@pytest.mark.gpu
+def test_exchange_selftest_only_prints_one_verdict_per_backend():
+    """`bench.py --gpus N --exchange-selftest-only` builds every exchange backend, runs checksum-verified exchange
+    steps and prints ONE JSON verdict per backend, no timing.  Here: a world of one through the real code path (RCCL communicator of
+    one rank, the rank's own IPC-free receive buffer), resets inside the steps."""
+    r = run_bench(["--gpus", "1", "--exchange-selftest-only", "--selftest-steps", "300", "--num-envs", "2048"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = json_lines(r.stdout)
+    assert [v["backend"] for v in lines] == ["process_group", "peer_push", "rccl_thread"], r.stdout[-2000:]
+    for v in lines:
+        assert v["selftest"] == "exchange" and v["ok"] is True and v["world"] == 1 and v["steps"] == 300, v
+        (pr,) = v["per_rank"]
+        assert pr["own_slice_ok"] and pr["first_bad_step_by_sender"] == {} and pr["resets"] > 300 * 2  # ~4 truncations per step at 2048 envs

