@@ -553,6 +553,14 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     }
   }
   __syncthreads();
+  // --- AGX_BVH_BOX_OBJECTS: which internal nodes are the root of ONE box object?  Decided once per node, before the emit stage reads
+  // the verdict from both sides (the node itself and its parent): bit 0 of counter[] (its arrival count is no longer needed; the
+  // other end of the node's key range stays above bit 1).
+  for (int i = tid; i < n_int; i += kBvhThreads) {
+    const int j = counter[i] >> 2;
+    counter[i] = (j << 2) | ((box_objects && i > 0 && box_object_record(keys, counter, tris, i, nullptr)) ? 1 : 0);
+  }
+  __syncthreads();
   // --- emit nodes with both child boxes inline.  A child whose own two children are both leaves is folded into a
   // two-triangle leaf (first triangle in the child slot, second in the pad slot); the folded node is never visited.
   float *out = nodes + (size_t)env * (nt - 1) * 16;
@@ -566,7 +574,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       second[side] = -1;
       if (c >= n_int) {
         ref[side] = ~(int)(uint32_t)(keys[c - n_int] & 0xFFFFFFFFull);
-      } else if (box_objects && box_object_record(keys, counter, tris, c, nullptr)) {
+      } else if (counter[c] & 1) {
         ref[side] = c | AGX_BVH_OBJECT_REF;  // the child is an OBJECT NODE: the tree ends at the box
       } else if (child[2 * c] >= n_int && child[2 * c + 1] >= n_int) {
         ref[side] = ~(int)(uint32_t)(keys[child[2 * c] - n_int] & 0xFFFFFFFFull);
@@ -576,7 +584,10 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
       }
     }
     float *o = out + (size_t)i * 16;
-    if (box_objects && i > 0 && box_object_record(keys, counter, tris, i, o)) continue;  // this node IS an object node (the same test its parent made)
+    if (counter[i] & 1) {  // this node IS an object node (the verdict its parent reads, too): the box's frame is its record
+      box_object_record(keys, counter, tris, i, o);
+      continue;
+    }
     const float *a = bx[0], *b = bx[1];
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(ref[0]);
     o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(ref[1]);
@@ -603,7 +614,7 @@ __global__ void __launch_bounds__(1024) k_compact_mask(int n, const uint8_t *__r
   }
 }
 
-__global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int npad, int ppo, const float *__restrict__ tri_world,
+__global__ void __launch_bounds__(kBvhThreads, 4) k_bvh_build(int n, int nt, int npad, int ppo, const float *__restrict__ tri_world,
                                                             int32_t *__restrict__ work, float *__restrict__ nodes) {
   if (!work) {  // every env
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
@@ -628,7 +639,7 @@ __global__ void __launch_bounds__(kBvhThreads) k_bvh_build(int n, int nt, int np
 // writes that env's world-frame triangles and collision boxes itself, then builds its tree.  As three launches the two small
 // ones cost a dispatch over ALL envs each (40 960 and 3 392 workgroups at 8192 envs x 106 obstacles that look at the mask and
 // leave: 22 + 9 us per step for a few dozen dirty envs).  Same device functions, same arithmetic.
-__global__ void __launch_bounds__(kBvhThreads) k_scene_refresh(int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
+__global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
                                                                 const int32_t *__restrict__ tri_asset,
                                                                 const float *__restrict__ asset_state,
                                                                 const float *__restrict__ half_extents, float *tri_world,
