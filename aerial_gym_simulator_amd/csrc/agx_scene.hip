@@ -200,19 +200,22 @@ AGX_DEV void bitonic_sort_lds(unsigned long long *keys, int m, int tid) {
   }
 }
 
-// AGX_BVH_BOX_OBJECTS: is internal node c the root of exactly ONE object's 12 triangles, and do those make an orthogonal box of
-// trimesh.creation.box's topology?  Then (rec != nullptr) its record is the box's frame (include/aerial_gym_hip.h).  The key range
-// of node c is [min(c, j), max(c, j)], j left in counter[c] >> 2 by the radix-tree pass.  Faces of trimesh's box (corners
-// ({0,1}^3 - 0.5) * extents, index 4 x + 2 y + z): triangle 0 = (1, 3, 0), 1 = (4, 1, 0), 2 = (0, 3, 2), 11 = (7, 5, 6).
-AGX_DEV bool box_object_record(const unsigned long long *keys, const int *counter, const float *__restrict__ tris, int c, float *rec) {
-  const int j = counter[c] >> 2;
-  const int first = min(c, j), last = max(c, j);
-  if (last - first != 11) return false;
-  const int f0 = (int)(uint32_t)(keys[first] & 0xFFFFFFFFull);
-  const int obj = f0 / 12;
-  for (int r = 1; r < 12; ++r)
-    if ((int)(uint32_t)(keys[first + r] & 0xFFFFFFFFull) / 12 != obj) return false;
-  const float *t = tris + (size_t)obj * 12 * 9;
+// AGX_BVH_BOX_OBJECTS.  An internal node whose leaves are exactly ONE object's 12 triangles becomes an OBJECT NODE if those triangles
+// make an orthogonal box of trimesh.creation.box's topology -- decided from the world-frame triangles alone, every vertex checked,
+// in three parallel steps (a thread that validated an object alone was a chain of ~120 dependent loads: +20 us on a 60 us build):
+//   1. per internal node: is its key range one object's twelve keys?  (LDS only)              -> objroot[object] = node
+//   2. per triangle: are its three vertices corners of its object's box, in the plane of the face the ray-cast's table expects it
+//      in; per face pair: do the two triangles have four distinct corners between them (they tile the rectangle)?  -> objroot[o] = -1
+//   3. per object: the verdict into bit 0 of counter[node] (read by the node itself and by its parent in the emit stage).
+// Faces of trimesh's box (corners ({0,1}^3 - 0.5) * extents, index 4 x + 2 y + z) by triangle:
+//   0 = (1, 3, 0), 1 = (4, 1, 0), 2 = (0, 3, 2), 11 = (7, 5, 6);  -x (0, 2)  +x (10, 11)  -y (1, 5)  +y (7, 9)  -z (3, 8)  +z (4, 6).
+struct BoxFrame {
+  V3 nx, ny, nz, cen;
+  float hx, hy, hz, tol;
+};
+
+// the box four corners of an object's first triangles span (corners 0, 1, 2, 4; the opposite corner 7 must close it)
+AGX_DEV bool box_frame(const float *__restrict__ t, BoxFrame &F) {
   const V3 v1 = V3{t[0], t[1], t[2]}, v0 = V3{t[6], t[7], t[8]};          // triangle 0 = (1, 3, 0)
   const V3 v4 = V3{t[9], t[10], t[11]};                                     // triangle 1 = (4, 1, 0)
   const V3 v2 = V3{t[18 + 6], t[18 + 7], t[18 + 8]};                        // triangle 2 = (0, 3, 2)
@@ -220,44 +223,43 @@ AGX_DEV bool box_object_record(const unsigned long long *keys, const int *counte
   const V3 ex = v4 - v0, ey = v2 - v0, ez = v1 - v0;
   const float lx = sqrtf(dot(ex, ex)), ly = sqrtf(dot(ey, ey)), lz = sqrtf(dot(ez, ez));
   if (!(lx > 1.0e-5f && ly > 1.0e-5f && lz > 1.0e-5f) || !(lx < 1.0e4f && ly < 1.0e4f && lz < 1.0e4f)) return false;
-  const V3 nx = ex * (1.0f / lx), ny = ey * (1.0f / ly), nz = ez * (1.0f / lz);
-  if (fabsf(dot(nx, ny)) > 1.0e-4f || fabsf(dot(ny, nz)) > 1.0e-4f || fabsf(dot(nz, nx)) > 1.0e-4f) return false;
+  F.nx = ex * (1.0f / lx); F.ny = ey * (1.0f / ly); F.nz = ez * (1.0f / lz);
+  if (fabsf(dot(F.nx, F.ny)) > 1.0e-4f || fabsf(dot(F.ny, F.nz)) > 1.0e-4f || fabsf(dot(F.nz, F.nx)) > 1.0e-4f) return false;
   const V3 far = v0 + ex + ey + ez - v7;  // the opposite corner is where a box has it
   if (!(sqrtf(dot(far, far)) <= 1.0e-4f * (lx + ly + lz))) return false;
-  // ... and every one of the 12 triangles is where the ray-cast's face table expects it: its three vertices are corners of the box,
-  // in the plane of its face, and the two triangles of a face have four distinct corners between them (they tile the rectangle).
-  // Faces by triangle: -x (0, 2)  +x (10, 11)  -y (1, 5)  +y (7, 9)  -z (3, 8)  +z (4, 6)  (trimesh.creation.box's face order).
-  {
-    const V3 cen = v0 + (ex + ey + ez) * 0.5f;
-    const float hx = 0.5f * lx, hy = 0.5f * ly, hz = 0.5f * lz, tol = 1.0e-4f * (lx + ly + lz) + 1.0e-5f;
-    constexpr int kFaceOf[12] = {0, 2, 0, 4, 5, 2, 5, 3, 4, 3, 1, 1};  // 2 * axis + (plus side)
-    uint32_t seen[6] = {0u, 0u, 0u, 0u, 0u, 0u};
-    for (int q = 0; q < 12; ++q) {
-      const int face = kFaceOf[q], axis = face >> 1;
-      const float want = (face & 1) ? 1.0f : -1.0f;
-      uint32_t ids = 0u;
-      for (int v = 0; v < 3; ++v) {
-        const V3 p = V3{t[9 * q + 3 * v] - cen.x, t[9 * q + 3 * v + 1] - cen.y, t[9 * q + 3 * v + 2] - cen.z};
-        const float l0 = dot(nx, p), l1 = dot(ny, p), l2 = dot(nz, p);
-        if (fabsf(fabsf(l0) - hx) > tol || fabsf(fabsf(l1) - hy) > tol || fabsf(fabsf(l2) - hz) > tol) return false;
-        const float la = axis == 0 ? l0 : (axis == 1 ? l1 : l2);
-        if (!(la * want > 0.0f)) return false;
-        ids |= 1u << ((l0 > 0.0f ? 4 : 0) | (l1 > 0.0f ? 2 : 0) | (l2 > 0.0f ? 1 : 0));
-      }
-      if (__popc(ids) != 3) return false;
-      seen[face] |= ids;
-    }
-    for (int f = 0; f < 6; ++f)
-      if (__popc(seen[f]) != 4) return false;
-  }
-  if (rec) {
-    const V3 cen = v0 + (ex + ey + ez) * 0.5f;
-    rec[0] = nx.x; rec[1] = nx.y; rec[2] = nx.z; rec[3] = 0.5f * lx;
-    rec[4] = ny.x; rec[5] = ny.y; rec[6] = ny.z; rec[7] = 0.5f * ly;
-    rec[8] = nz.x; rec[9] = nz.y; rec[10] = nz.z; rec[11] = 0.5f * lz;
-    rec[12] = cen.x; rec[13] = cen.y; rec[14] = cen.z; rec[15] = __int_as_float(obj * 12);
-  }
+  F.cen = v0 + (ex + ey + ez) * 0.5f;
+  F.hx = 0.5f * lx; F.hy = 0.5f * ly; F.hz = 0.5f * lz;
+  F.tol = 1.0e-4f * (lx + ly + lz) + 1.0e-5f;
   return true;
+}
+
+// triangle q of the object (9 floats at t): three distinct corners of the box, all in the plane of face `kFaceOf[q]`; -> the corners' ids
+AGX_DEV bool box_triangle_ok(const BoxFrame &F, const float *__restrict__ t, int q, uint32_t &ids) {
+  const int face = (int)((0x113435254020ull >> (4 * q)) & 15ull);  // {0, 2, 0, 4, 5, 2, 5, 3, 4, 3, 1, 1}[q] = 2 * axis + (plus side)
+  const int axis = face >> 1;
+  const float want = (face & 1) ? 1.0f : -1.0f;
+  ids = 0u;
+  bool ok = true;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    const V3 p = V3{t[3 * v] - F.cen.x, t[3 * v + 1] - F.cen.y, t[3 * v + 2] - F.cen.z};
+    const float l0 = dot(F.nx, p), l1 = dot(F.ny, p), l2 = dot(F.nz, p);
+    ok = ok && !(fabsf(fabsf(l0) - F.hx) > F.tol || fabsf(fabsf(l1) - F.hy) > F.tol || fabsf(fabsf(l2) - F.hz) > F.tol);
+    const float la = axis == 0 ? l0 : (axis == 1 ? l1 : l2);
+    ok = ok && (la * want > 0.0f);
+    ids |= 1u << ((l0 > 0.0f ? 4 : 0) | (l1 > 0.0f ? 2 : 0) | (l2 > 0.0f ? 1 : 0));
+  }
+  return ok && __popc(ids) == 3;
+}
+
+// the object node's record (include/aerial_gym_hip.h): the frame of object `obj`
+AGX_DEV void box_object_record(const float *__restrict__ tris, int obj, float *rec) {
+  BoxFrame F;
+  box_frame(tris + (size_t)obj * 12 * 9, F);  // (validated before)
+  rec[0] = F.nx.x; rec[1] = F.nx.y; rec[2] = F.nx.z; rec[3] = F.hx;
+  rec[4] = F.ny.x; rec[5] = F.ny.y; rec[6] = F.ny.z; rec[7] = F.hy;
+  rec[8] = F.nz.x; rec[9] = F.nz.y; rec[10] = F.nz.z; rec[11] = F.hz;
+  rec[12] = F.cen.x; rec[13] = F.cen.y; rec[14] = F.cen.z; rec[15] = __int_as_float(obj * 12);
 }
 
 // Node record written to HBM (16 floats):
@@ -553,14 +555,45 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     }
   }
   __syncthreads();
-  // --- AGX_BVH_BOX_OBJECTS: which internal nodes are the root of ONE box object?  Decided once per node, before the emit stage reads
-  // the verdict from both sides (the node itself and its parent): bit 0 of counter[] (its arrival count is no longer needed; the
-  // other end of the node's key range stays above bit 1).
-  for (int i = tid; i < n_int; i += kBvhThreads) {
-    const int j = counter[i] >> 2;
-    counter[i] = (j << 2) | ((box_objects && i > 0 && box_object_record(keys, counter, tris, i, nullptr)) ? 1 : 0);
+  // --- AGX_BVH_BOX_OBJECTS: which internal nodes are the root of ONE box object?  (three parallel steps, see box_frame)
+  // bit 0 of counter[] takes the verdict (the arrival count is no longer needed; the other end of the node's key range stays above
+  // bit 1); objroot[] lives in parent[], dead since the propagation.
+  int *objroot = parent;  // [nt / 12]
+  const int n_obj = nt / 12;
+  if (box_objects) {
+    for (int o = tid; o < n_obj; o += kBvhThreads) objroot[o] = -1;
+    __syncthreads();
+    for (int i = tid + 1; i < n_int; i += kBvhThreads) {  // (never the root: it has no parent to carry the reference)
+      const int j = counter[i] >> 2;
+      const int first = min(i, j), last = max(i, j);
+      if (last - first != 11) continue;
+      const int obj = (int)(uint32_t)(keys[first] & 0xFFFFFFFFull) / 12;
+      bool same = true;
+      for (int r = 1; r < 12; ++r) same = same && ((int)(uint32_t)(keys[first + r] & 0xFFFFFFFFull) / 12 == obj);
+      if (same) objroot[obj] = i;  // (one node at most has exactly this range)
+    }
+    __syncthreads();
+    for (int f = tid; f < n_obj * 12; f += kBvhThreads) {
+      const int obj = f / 12, q = f - obj * 12;
+      if (objroot[obj] < 0) continue;
+      const float *t = tris + (size_t)obj * 12 * 9;
+      BoxFrame F;
+      uint32_t ids = 0u, ids2 = 0u;
+      bool ok = box_frame(t, F) && box_triangle_ok(F, t + 9 * q, q, ids);
+      // the first triangle of each face also looks at its partner: four distinct corners between them
+      const int mate = q == 0 ? 2 : (q == 10 ? 11 : (q == 1 ? 5 : (q == 7 ? 9 : (q == 3 ? 8 : (q == 4 ? 6 : -1)))));
+      if (ok && mate >= 0) ok = box_triangle_ok(F, t + 9 * mate, mate, ids2) && __popc(ids | ids2) == 4;
+      if (!ok) objroot[obj] = -1;  // (every writer stores the same value)
+    }
+    __syncthreads();
   }
+  for (int i = tid; i < n_int; i += kBvhThreads) counter[i] &= ~3;
   __syncthreads();
+  if (box_objects) {
+    for (int o = tid; o < n_obj; o += kBvhThreads)
+      if (objroot[o] >= 0) counter[objroot[o]] |= 1;
+    __syncthreads();
+  }
   // --- emit nodes with both child boxes inline.  A child whose own two children are both leaves is folded into a
   // two-triangle leaf (first triangle in the child slot, second in the pad slot); the folded node is never visited.
   float *out = nodes + (size_t)env * (nt - 1) * 16;
@@ -585,7 +618,8 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     }
     float *o = out + (size_t)i * 16;
     if (counter[i] & 1) {  // this node IS an object node (the verdict its parent reads, too): the box's frame is its record
-      box_object_record(keys, counter, tris, i, o);
+      const int j = counter[i] >> 2;
+      box_object_record(tris, (int)(uint32_t)(keys[min(i, j)] & 0xFFFFFFFFull) / 12, o);
       continue;
     }
     const float *a = bx[0], *b = bx[1];
