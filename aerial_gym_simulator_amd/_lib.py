@@ -148,6 +148,11 @@ class AgxTaskArgs(C.Structure):
         ("pos_err", C.c_void_p),
         ("prev_pos_err", C.c_void_p),
         ("rp", C.c_float * 18),
+        ("successes", C.c_void_p),
+        ("timeouts", C.c_void_p),
+        ("counters", C.c_void_p),
+        ("success_radius", C.c_float),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -292,6 +297,8 @@ _SIGNATURES = {
     "agx_bvh_build": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_boxes_from_assets": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "agx_scene_refresh": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "agx_scene_reset_refresh": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.c_int, C.POINTER(AgxResetArgs), _P, _P, C.c_int, C.c_int, _P,
+                                          _P, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "agx_sensor_pose": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "agx_raycast_camera": (
         C.c_int,

@@ -523,6 +523,26 @@ AGX_DEV float reward_navigation(const float *rp, float cpf, V3 pe, V3 ppe, float
 // The env step: k fused physics sub-steps + (optionally) the task's reward / crash /
 // truncation / reset set as an epilogue on the same registers.
 // ---------------------------------------------------------------------------------------
+// NavigationTask bookkeeping (navigation_task.py:311-326) on the registers of the step's epilogue -- the arithmetic of k_nav_bookkeeping
+// (agx_task_glue.hip): near = norm(target - p) < radius.  `store`: this lane stores the env's flags (one lane per env).  Must be
+// reached by every lane of the wave that runs the epilogue (the counters are bumped once per wave).
+AGX_DEV void nav_bookkeeping_epilogue(const AgxTaskArgs &T, int i, bool store, V3 tgt, V3 p, bool crashed, bool trunc) {
+  const bool near = norm(tgt - p) < T.success_radius;
+  const bool succ = store && trunc && near && !crashed;
+  const bool tout = store && trunc && !succ && !crashed;
+  if (store) {
+    T.successes[i] = succ ? 1 : 0;
+    T.timeouts[i] = tout ? 1 : 0;
+  }
+  const unsigned long long act = __ballot(true);
+  const unsigned long long ms = __ballot(succ), mc = __ballot(store && crashed), mt = __ballot(tout);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+    if (ms) atomicAdd(T.counters + 0, __popcll(ms));
+    if (mc) atomicAdd(T.counters + 1, __popcll(mc));
+    if (mt) atomicAdd(T.counters + 2, __popcll(mt));
+  }
+}
+
 // SINGLE: exactly one sub-step (empty_env, BASELINE config 1/2): straight-line code, no loop-
 // carried copies of the loop invariants.
 // WIDE: the launch uses one-wave workgroups (n <= 65536 envs: at most one wave per SIMD is resident anyway), so the
@@ -733,6 +753,7 @@ __global__ void __launch_bounds__(WIDE ? 64 : 256, WIDE ? 1 : (SINGLE ? env_step
       trunc = steps > T.episode_len;
       reset = (crashed && T.reset_on_collision) || trunc;
       B.reset_mask[i] = reset ? 1 : 0;
+      if (T.successes) nav_bookkeeping_epilogue(T, i, true, tgt, s.p, crashed, trunc);  // (wave-uniform pointer test)
     }
     B.crashes[i] = crashed ? 1 : 0;
     if (!more_launches) B.truncations[i] = trunc ? 1 : 0;
@@ -1306,6 +1327,9 @@ __global__ void __launch_bounds__(64, 1)
       }
       trunc = steps > T.episode_len;
       reset = (crashed && T.reset_on_collision) || trunc;
+      if (T.successes)  // (wave-uniform; lane 0 of the env's quad stores)
+        nav_bookkeeping_epilogue(T, i, l == 0, V3{q4::bc<0>(tgt), q4::bc<1>(tgt), q4::bc<2>(tgt)}, V3{q4::bc<0>(p), q4::bc<1>(p), q4::bc<2>(p)},
+                                 crashed, trunc);
     }
     if (l == 0) {
       B.sim_steps[i] = steps;
@@ -1732,28 +1756,6 @@ __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, 
 // Reset.  Uniform draws come either from tensors (host RNG, reference-faithful stream) or
 // from Philox4x32-10 evaluated in place (sync-free mode).
 // ---------------------------------------------------------------------------------------
-AGX_DEV void bounds_from_draws(const AgxResetArgs &R, const float ub[6], float bmin[3], float bmax[3]) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float ulo = ub[c], uhi = ub[3 + c];
-    bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
-    bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
-  }
-}
-AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int rng_env, int episode, float bmin[3], float bmax[3]) {
-  float ub[6];
-  if (R.u_state) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      ub[c] = R.u_bounds_lo[(size_t)i * 3 + c];
-      ub[3 + c] = R.u_bounds_hi[(size_t)i * 3 + c];
-    }
-  } else {
-    rng_fill<6>(R.seed, rng_env, episode, RNG_BOUNDS, ub);
-  }
-  bounds_from_draws(R, ub, bmin, bmax);
-}
-
 // The uniform draws one env's reset consumes: env bounds (6), robot state (13), controller gains (12), and per motor
 // (tau_inc, tau_dec, thrust, kT).
 template <int M>
@@ -2099,34 +2101,7 @@ __global__ void __launch_bounds__(256) k_reset_assets(AgxEnvBuffers B, int n, in
   const int a = blockIdx.y * blockDim.x + threadIdx.x;
   if (a >= K) return;
   if (B.reset_flag[B.flag_parity] == 0 || B.reset_mask[env] == 0) return;
-  const int ep = B.episode_count ? B.episode_count[env] : 0;
-  const bool host_rng = u1 != nullptr;
-  const int genv = B.env_index_base + env;  // the device generator is keyed by the global env index
-  float usel = host_rng ? u_sel[env] : rng_block(R.seed, genv, ep, RNG_ASSET_SEL, 0).v[0];
-  // strict mode hands over the bernoulli outcome (0/1); the device generator thresholds at 0.15
-  const bool sel = host_rng ? (usel > 0.0f) : (usel < 0.15f);
-  const int n_active = sel ? max(num_obstacles / 2, nk / 2) : max(num_obstacles, nk);
-  float bmin[3], bmax[3];
-  sample_bounds(R, env, genv, ep, bmin, bmax);
-  const size_t base = ((size_t)env * K + a) * 13;
-  float ratio[6], ua[6];
-  if (host_rng) {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) ua[c] = sel ? u2[base + c] : u1[base + c];
-  } else {
-    rng_fill<6>(R.seed, genv, ep, RNG_ASSETS + a, ua);
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * ua[c] + min_ratio[base + c];
-  float *st = asset_state + base;
-  if (a >= n_active) {
-    st[0] = -1000.0f; st[1] = -1000.0f; st[2] = -1000.0f;
-  } else {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) st[c] = bmin[c] + (bmax[c] - bmin[c]) * ratio[c];
-  }
-  Q4 q = quat_from_euler(ratio[3], ratio[4], ratio[5]);
-  st[3] = q.x; st[4] = q.y; st[5] = q.z; st[6] = q.w;
+  reset_asset_one(B, R, env, a, K, u1, u2, u_sel, min_ratio, max_ratio, num_obstacles, nk, asset_state);
 }
 
 }  // namespace agx
@@ -2242,6 +2217,8 @@ extern "C" int agx_env_step(const AgxRobotParams *P, const AgxEnvBuffers *B, int
   if (T.kind != AGX_TASK_NONE) {
     AGX_REQUIRE(T.target && T.reward && B->reset_mask && B->reset_flag, "null task buffer");
     AGX_REQUIRE(T.kind != AGX_TASK_NAVIGATION || (T.pos_err && T.prev_pos_err && P->num_actions >= 4), "null navigation buffer");
+    AGX_REQUIRE((!T.successes && !T.timeouts && !T.counters) || (T.successes && T.timeouts && T.counters && T.kind == AGX_TASK_NAVIGATION),
+                "navigation bookkeeping in the epilogue needs successes, timeouts and counters, and the navigation task kind");
   }
   const int block = pick_block(n);
   const size_t lds = B->boxes ? (size_t)k * 3 * block * sizeof(float) : 0;

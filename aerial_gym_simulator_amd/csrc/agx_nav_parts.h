@@ -12,6 +12,65 @@ struct Ratio3 {
   float lo[3], hi[3];
 };
 
+AGX_DEV void bounds_from_draws(const AgxResetArgs &R, const float ub[6], float bmin[3], float bmax[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float ulo = ub[c], uhi = ub[3 + c];
+    bmin[c] = (R.lower_bound_max[c] - R.lower_bound_min[c]) * ulo + R.lower_bound_min[c];
+    bmax[c] = (R.upper_bound_max[c] - R.upper_bound_min[c]) * uhi + R.upper_bound_min[c];
+  }
+}
+AGX_DEV void sample_bounds(const AgxResetArgs &R, int i, int rng_env, int episode, float bmin[3], float bmax[3]) {
+  float ub[6];
+  if (R.u_state) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ub[c] = R.u_bounds_lo[(size_t)i * 3 + c];
+      ub[3 + c] = R.u_bounds_hi[(size_t)i * 3 + c];
+    }
+  } else {
+    rng_fill<6>(R.seed, rng_env, episode, RNG_BOUNDS, ub);
+  }
+  bounds_from_draws(R, ub, bmin, bmax);
+}
+
+
+// AssetManager.reset_idx (asset_manager.py:51-71) + the half-obstacle resample (env_manager.py:283-295) for asset `a` of env `env`
+// (the caller has checked reset_flag / reset_mask).  u1 / u2 / u_sel: host draws (strict mode) or NULL = the device generator,
+// keyed by the GLOBAL env index and the env's episode count BEFORE the robot reset increments it.
+AGX_DEV void reset_asset_one(const AgxEnvBuffers &B, const AgxResetArgs &R, int env, int a, int K, const float *__restrict__ u1,
+                             const float *__restrict__ u2, const float *__restrict__ u_sel, const float *__restrict__ min_ratio,
+                             const float *__restrict__ max_ratio, int num_obstacles, int nk, float *__restrict__ asset_state) {
+  const int ep = B.episode_count ? B.episode_count[env] : 0;
+  const bool host_rng = u1 != nullptr;
+  const int genv = B.env_index_base + env;  // the device generator is keyed by the global env index
+  float usel = host_rng ? u_sel[env] : rng_block(R.seed, genv, ep, RNG_ASSET_SEL, 0).v[0];
+  // strict mode hands over the bernoulli outcome (0/1); the device generator thresholds at 0.15
+  const bool sel = host_rng ? (usel > 0.0f) : (usel < 0.15f);
+  const int n_active = sel ? max(num_obstacles / 2, nk / 2) : max(num_obstacles, nk);
+  float bmin[3], bmax[3];
+  sample_bounds(R, env, genv, ep, bmin, bmax);
+  const size_t base = ((size_t)env * K + a) * 13;
+  float ratio[6], ua[6];
+  if (host_rng) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ua[c] = sel ? u2[base + c] : u1[base + c];
+  } else {
+    rng_fill<6>(R.seed, genv, ep, RNG_ASSETS + a, ua);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) ratio[c] = (max_ratio[base + c] - min_ratio[base + c]) * ua[c] + min_ratio[base + c];
+  float *st = asset_state + base;
+  if (a >= n_active) {
+    st[0] = -1000.0f; st[1] = -1000.0f; st[2] = -1000.0f;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st[c] = bmin[c] + (bmax[c] - bmin[c]) * ratio[c];
+  }
+  Q4 q = quat_from_euler(ratio[3], ratio[4], ratio[5]);
+  st[3] = q.x; st[4] = q.y; st[5] = q.z; st[6] = q.w;
+}
+
 // reset_idx of the navigation tasks (navigation_task.py:166-175, lidar_navigation_task.py:164-181) for env i (the caller has
 // checked reset_flag / reset_mask): target = bounds_min + (bounds_max - bounds_min) * U(min_ratio, max_ratio); optional
 // target_yaw = U(-pi, pi); optional robot_prev_actions = 0.  u: host draws [N][4] or NULL (device generator, keyed by the

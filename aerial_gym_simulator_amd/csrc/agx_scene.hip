@@ -11,6 +11,7 @@
 // long as node boxes are conservative -- they are grown by kBoxEps like Warp's 1e-3.
 #include "agx_common.h"
 #include "agx_device_math.h"
+#include "agx_nav_parts.h"
 
 namespace agx {
 
@@ -673,12 +674,45 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_bvh_build(int n, int nt, int
 // writes that env's world-frame triangles and collision boxes itself, then builds its tree.  As three launches the two small
 // ones cost a dispatch over ALL envs each (40 960 and 3 392 workgroups at 8192 envs x 106 obstacles that look at the mask and
 // leave: 22 + 9 us per step for a few dozen dirty envs).  Same device functions, same arithmetic.
+// the asset reset of a dirty env in the refresh launch itself (agx_scene_reset_refresh; device generator only)
+struct SceneResetArgs {
+  int enabled, num_obstacles, num_keep;
+  AgxEnvBuffers B;
+  AgxResetArgs R;
+  const float *min_ratio, *max_ratio;
+};
+
+AGX_DEV void scene_refresh_env(int env, int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
+                               const int32_t *__restrict__ tri_asset, float *asset_state, const float *__restrict__ half_extents,
+                               float *tri_world, float *__restrict__ boxes, float *__restrict__ nodes, const SceneResetArgs &S) {
+  if (S.enabled) {  // AssetManager.reset_idx for this env first: the poses the triangles are about to be moved to
+    for (int a = threadIdx.x; a < na; a += kBvhThreads)
+      reset_asset_one(S.B, S.R, env, a, na, nullptr, nullptr, nullptr, S.min_ratio, S.max_ratio, S.num_obstacles, S.num_keep, asset_state);
+    __syncthreads();  // (workgroup scope: the poses are read back by this workgroup only)
+  }
+  for (int f = threadIdx.x; f < nt; f += kBvhThreads) transform_triangle(env, f, nt, na, tri_local, tri_asset, asset_state, tri_world);
+  if (boxes)
+    for (int k = threadIdx.x; k < na; k += kBvhThreads) box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
+  __syncthreads();  // the env's triangles are in memory (workgroup scope) before the build reads them
+  bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
+}
+
 __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
                                                                 const int32_t *__restrict__ tri_asset,
-                                                                const float *__restrict__ asset_state,
+                                                                float *asset_state,
                                                                 const float *__restrict__ half_extents, float *tri_world,
                                                                 float *__restrict__ boxes, int32_t *__restrict__ work,
-                                                                float *__restrict__ nodes) {
+                                                                float *__restrict__ nodes, const uint8_t *__restrict__ mask, SceneResetArgs S) {
+  if (mask) {
+    // DIRECT mode (small batches: one workgroup per env, no work list): a clean env's workgroup leaves at once -- the launch that
+    // compacted the mask (and the one that reset the assets, S.enabled) are gone from the step, and a step without a dirty env
+    // costs one dispatch
+    const int env = blockIdx.x;
+    if (S.enabled && S.B.reset_flag[S.B.flag_parity] == 0) return;
+    if (!mask[env]) return;
+    scene_refresh_env(env, n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
+    return;
+  }
   __shared__ int next;
   const int count = work[0];
   while (true) {
@@ -687,12 +721,7 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt,
     const int idx = next;
     __syncthreads();  // everybody has read `next` before thread 0 overwrites it; also fences LDS reuse
     if (idx >= count) break;
-    const int env = work[2 + idx];
-    for (int f = threadIdx.x; f < nt; f += kBvhThreads) transform_triangle(env, f, nt, na, tri_local, tri_asset, asset_state, tri_world);
-    if (boxes)
-      for (int k = threadIdx.x; k < na; k += kBvhThreads) box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
-    __syncthreads();  // the env's triangles are in memory (workgroup scope) before the build reads them
-    bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
+    scene_refresh_env(work[2 + idx], n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
   }
 }
 
@@ -776,6 +805,34 @@ static int bvh_launch_shape(int nt, int prims_per_object, int *npad_out, size_t 
 // AssetManager's geometry refresh behind a reset (asset_manager.py:51-71 -> warp mesh refit, warp_env ...): world-frame
 // triangles, collision boxes and the tree of the envs flagged in `mask`; mask == nullptr: every env (the three stand-alone
 // launches).  One C call; with a mask, two launches (compaction + the persistent k_scene_refresh).
+extern "C" int agx_reset_assets(const AgxEnvBuffers *B, int n, int K, const AgxResetArgs *R, const float *u1, const float *u2,
+                                const float *u_sel, const float *min_ratio, const float *max_ratio, int num_obstacles,
+                                int num_keep, float *asset_state, void *stream);
+
+constexpr int kDirectRefreshEnvs = 2048;  // up to here a workgroup per env (clean ones leave at once) beats compaction + a persistent grid
+
+// the masked refresh: direct (one workgroup per env, optionally with the asset reset in it) or compaction + persistent grid
+static int scene_refresh_launch(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset, float *asset_state,
+                                const float *half_extents, int prims_per_object, const uint8_t *mask, float *tri_world, float *boxes,
+                                float *nodes, int32_t *work, const SceneResetArgs *reset, void *stream) {
+  static bool attr_set = false;
+  int npad = 0;
+  size_t lds = 0;
+  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_scene_refresh), &attr_set)) return e;
+  SceneResetArgs S{};
+  if (reset) S = *reset;
+  if (n <= kDirectRefreshEnvs) {
+    hipLaunchKernelGGL(k_scene_refresh, dim3(n), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
+                       tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes, mask, S);
+    return check_launch("agx_scene_refresh");
+  }
+  hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
+  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
+  hipLaunchKernelGGL(k_scene_refresh, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
+                     tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes, (const uint8_t *)nullptr, S);
+  return check_launch("agx_scene_refresh");
+}
+
 extern "C" int agx_scene_refresh(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset, const float *asset_state,
                                  const float *half_extents, int prims_per_object, const uint8_t *mask, float *tri_world,
                                  float *boxes, float *nodes, int32_t *work, void *stream) {
@@ -788,15 +845,30 @@ extern "C" int agx_scene_refresh(int n, int nt, int na, const float *tri_local, 
     return boxes ? agx_boxes_from_assets(n, na, asset_state, half_extents, nullptr, boxes, stream) : AGX_OK;
   }
   AGX_REQUIRE(work, "a masked refresh needs the work buffer (int32[num_envs + 2])");
-  static bool attr_set = false;
-  int npad = 0;
-  size_t lds = 0;
-  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_scene_refresh), &attr_set)) return e;
-  hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
-  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
-  hipLaunchKernelGGL(k_scene_refresh, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na,
-                     tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes);
-  return check_launch("agx_scene_refresh");
+  return scene_refresh_launch(n, nt, na, tri_local, tri_asset, const_cast<float *>(asset_state), half_extents, prims_per_object, mask, tri_world, boxes,
+                              nodes, work, nullptr, stream);
+}
+
+// AssetManager.reset_idx + the geometry refresh behind it (agx_reset_assets + agx_scene_refresh) for the envs of buf->reset_mask, device
+// generator only.  Up to kDirectRefreshEnvs envs: ONE launch (a workgroup per env; a clean env's leaves at once); above: the three
+// launches (asset reset, mask compaction, persistent refresh).  Same device functions either way: the same poses, triangles and trees.
+extern "C" int agx_scene_reset_refresh(const AgxEnvBuffers *B, int n, int nt, int na, const AgxResetArgs *R, const float *min_ratio,
+                                       const float *max_ratio, int num_obstacles, int num_keep, float *asset_state, const float *tri_local,
+                                       const int32_t *tri_asset, const float *half_extents, int prims_per_object, float *tri_world,
+                                       float *boxes, float *nodes, int32_t *work, void *stream) {
+  AGX_REQUIRE(B && R && n > 0 && nt > 0 && na > 0, "bad arguments");
+  AGX_REQUIRE(min_ratio && max_ratio && asset_state && tri_local && tri_asset && tri_world && nodes && work, "null buffer");
+  AGX_REQUIRE(B->reset_flag && B->reset_mask && B->episode_count, "the device generator needs reset_flag, reset_mask and episode_count");
+  AGX_REQUIRE(!R->u_state, "agx_scene_reset_refresh draws from the device generator (strict draws: agx_reset_assets + agx_scene_refresh)");
+  AGX_REQUIRE(!boxes || half_extents, "collision boxes need the half extents");
+  SceneResetArgs S{1, num_obstacles, num_keep, *B, *R, min_ratio, max_ratio};
+  if (n > kDirectRefreshEnvs) {
+    if (int e = agx_reset_assets(B, n, na, R, nullptr, nullptr, nullptr, min_ratio, max_ratio, num_obstacles, num_keep, asset_state, stream)) return e;
+    return scene_refresh_launch(n, nt, na, tri_local, tri_asset, asset_state, half_extents, prims_per_object, B->reset_mask, tri_world, boxes, nodes,
+                                work, nullptr, stream);
+  }
+  return scene_refresh_launch(n, nt, na, tri_local, tri_asset, asset_state, half_extents, prims_per_object, B->reset_mask, tri_world, boxes, nodes, work,
+                              &S, stream);
 }
 
 extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *tri_world, const uint8_t *mask, float *nodes,

@@ -1,6 +1,8 @@
 """Obstacle pose randomisation at reset (aerial_gym/env_manager/asset_manager.py:51-71 and the
 half-obstacle resample of env_manager.py:283-295) in agx_reset_assets, followed by the scene
 rebuild of the reset envs (warp_env_manager.py:40-54): triangles, LBVH, collision OBBs."""
+import os
+
 import torch
 
 from .. import _lib
@@ -80,6 +82,18 @@ class AssetManager:
         N, K = sc.num_envs, sc.num_assets
         lib, stream, p = env._lib, env._stream(), _lib.dptr
         st = self.env_asset_state_tensor
+        if not env.strict_rng and not sc.has_prims and os.environ.get("AGX_FUSED_ASSET_RESET", "1") != "0":
+            # obstacle poses, world-frame triangles, collision boxes and tree of the envs that reset: one call -- up to 2048 envs ONE
+            # launch (the asset reset and the mask compaction are gone from the step), above, the three launches below
+            _lib.check(
+                lib.agx_scene_reset_refresh(env._buffers, N, sc.num_tris, K, env._reset_args, p(self.asset_min_state_ratio),
+                                            p(self.asset_max_state_ratio), int(num_obstacles), int(self.num_keep_in_env), p(st),
+                                            p(sc.tri_local), p(sc.tri_asset), p(sc.half_extents),
+                                            int(getattr(env, 'bvh_prims_per_object', None) or sc.bvh_prims_per_object), p(sc.tri_world),
+                                            p(sc.boxes_soa), p(sc.bvh_nodes), p(sc.bvh_work), stream),
+                "agx_scene_reset_refresh",
+            )
+            return
         u1 = p(self._u1) if env.strict_rng else None
         u2 = p(self._u2) if env.strict_rng else None
         us = p(self._sel) if env.strict_rng else None

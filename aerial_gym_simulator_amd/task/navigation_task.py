@@ -106,6 +106,12 @@ class NavigationTask(BaseTask):
         T.pos_err, T.prev_pos_err = _lib.dptr(self.pos_err_soa), _lib.dptr(self.prev_pos_err_soa)
         for i in range(18):
             T.rp[i] = self._rp[i]
+        # sync-free mode: successes / timeouts / curriculum counters of the step come out of the same epilogue (the arithmetic of
+        # agx_nav_bookkeeping on the launch's registers: one dispatch fewer per step).  AGX_FUSED_BOOKKEEPING=0: the launch of its own.
+        self._bookkeeping_fused = not env.strict_rng and os.environ.get("AGX_FUSED_BOOKKEEPING", "1") != "0"
+        if self._bookkeeping_fused:
+            T.successes, T.timeouts, T.counters = _lib.dptr(self._successes), _lib.dptr(self._timeouts), _lib.dptr(self._counters)
+            T.success_radius = 1.0
         env.task_args = T
 
     def _update_progress(self):
@@ -175,8 +181,9 @@ class NavigationTask(BaseTask):
             self.check_and_update_curriculum_level(successes, crashed, timeouts)
             return
         p = _lib.dptr
-        _lib.check(env._lib.agx_nav_bookkeeping(env._buffers, env.num_envs, p(self.target_soa), 1.0, p(self._successes),
-                                                p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
+        if not (getattr(self, "_bookkeeping_fused", False) and env.task_args is not None and env.task_args.successes):
+            _lib.check(env._lib.agx_nav_bookkeeping(env._buffers, env.num_envs, p(self.target_soa), 1.0, p(self._successes),
+                                                    p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
         self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = self._successes, self._timeouts, self.terminations
 
     def _bookkeeping_host(self, in_step=False):

@@ -239,6 +239,14 @@ typedef struct AgxTaskArgs {
   float *pos_err;             /* [3][N] navigation only (in/out)                           */
   float *prev_pos_err;        /* [3][N] navigation only (out)                              */
   float rp[18];               /* navigation reward parameters                              */
+  /* navigation bookkeeping in the same epilogue (navigation_task.py:311-326; what agx_nav_bookkeeping does as a launch of its
+   * own): all three NULL = not done here.  successes = truncated & |target - p| < success_radius & not crashed; timeouts =
+   * truncated & not success & not crashed; counters[0..2] += number of (successes, crashes, timeouts) of this step.          */
+  uint8_t *successes;         /* [N] */
+  uint8_t *timeouts;          /* [N] */
+  int32_t *counters;          /* [3] */
+  float success_radius;
+  int32_t reserved;
 } AgxTaskArgs;
 
 /* agx_env_step = agx_dynamics_substeps + the task's reward / crash / truncation / reset-set
@@ -596,6 +604,17 @@ int agx_scene_refresh(int num_envs, int num_tris, int num_assets, const float *t
                       const int32_t *tri_asset, const float *asset_state, const float *half_extents,
                       int prims_per_object, const uint8_t *mask, float *tri_world, float *boxes,
                       float *nodes, int32_t *work, void *stream);
+
+/* AssetManager.reset_idx AND the geometry refresh behind it for the envs of buf->reset_mask (agx_reset_assets + agx_scene_refresh,
+ * asset_manager.py:51-71 -> warp_env_manager.py:40-54), draws from the device generator (args->u_* NULL).  Up to 2048 envs this is
+ * ONE launch -- a workgroup per env that resets the env's obstacle poses, moves its triangles and collision boxes and rebuilds its
+ * tree; a clean env's workgroup leaves at once, a step without a reset costs one dispatch -- above, the three launches it replaces
+ * at small batches (asset reset, mask compaction, persistent refresh).  num_assets = obstacles per env (one rigid piece each:
+ * multi-primitive scenes keep agx_reset_assets + agx_prims_from_assets + agx_scene_refresh).  Same device functions either way. */
+int agx_scene_reset_refresh(const AgxEnvBuffers *buf, int num_envs, int num_tris, int num_assets, const AgxResetArgs *args,
+                            const float *min_ratio, const float *max_ratio, int num_obstacles, int num_keep, float *asset_state,
+                            const float *tri_local, const int32_t *tri_asset, const float *half_extents, int prims_per_object,
+                            float *tri_world, float *boxes, float *nodes, int32_t *work, void *stream);
 
 /* WarpSensor.update pose composition (warp_sensor.py:177-187).
  * local_pos [N][S][3], local_quat [N][S][4], frame_quat [4] -> pos [N][S][3], quat [N][S][4] */

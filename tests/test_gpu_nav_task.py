@@ -427,6 +427,56 @@ def test_fused_robot_side_launch_equals_the_four_separate_launches(task_name, cf
         cfg.episode_len_steps, cfg.args, cfg.device = old
 
 
+@pytest.mark.parametrize("n", [40, 2304])
+def test_folded_step_launches_equal_the_separate_ones(n, monkeypatch):
+    """round 5: the navigation step without three of its small launches -- the success / timeout / curriculum
+    bookkeeping in the env-step launch's epilogue (AgxTaskArgs.successes ...) and the obstacle reset + mask compaction inside the
+    geometry refresh (agx_scene_reset_refresh: ONE launch up to 2048 envs, the three launches above) -- against the separate
+    launches (AGX_FUSED_BOOKKEEPING=0, AGX_FUSED_ASSET_RESET=0): same seed, same actions -> bit-identical observations, rewards,
+    flags, bookkeeping, obstacle poses, triangles, trees and images, resets on most steps.  n = 2304: the large-batch form."""
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config import task_config as tc
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    cfg = tc.navigation_task_config
+    old = (cfg.episode_len_steps, cfg.args, cfg.device)
+    tasks = []
+    try:
+        for fused in ("0", "1"):
+            monkeypatch.setenv("AGX_FUSED_BOOKKEEPING", fused)
+            monkeypatch.setenv("AGX_FUSED_ASSET_RESET", fused)
+            cfg.device, cfg.episode_len_steps = DEV, 7
+            cfg.args = {"rng_seed": 77}
+            t = task_registry.make_task("navigation_task", seed=3, num_envs=n, headless=True)
+            t.reset()
+            tasks.append(t)
+        separate, fused = tasks
+        assert fused._bookkeeping_fused and not separate._bookkeeping_fused
+        g = torch.Generator(device=DEV).manual_seed(2)
+        steps = 40 if n < 1000 else 12
+        for step in range(steps):
+            a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
+            for t, flag in ((separate, "0"), (fused, "1")):
+                monkeypatch.setenv("AGX_FUSED_BOOKKEEPING", flag)
+                monkeypatch.setenv("AGX_FUSED_ASSET_RESET", flag)
+                t._out = t.step(a)
+            torch.cuda.synchronize()
+            (o0, r0, te0, tr0, i0), (o1, r1, te1, tr1, i1) = separate._out, fused._out
+            assert torch.equal(o0["observations"], o1["observations"]), step
+            assert torch.equal(r0, r1) and torch.equal(te0, te1) and torch.equal(tr0, tr1), step
+            assert torch.equal(separate._successes, fused._successes) and torch.equal(separate._timeouts, fused._timeouts), step
+            assert torch.equal(separate._counters, fused._counters), step
+            for key in ("robot_state_tensor", "depth_range_pixels", "env_asset_state_tensor", "scene_tri_world", "scene_bvh_nodes"):
+                a0, a1 = separate.obs_dict[key], fused.obs_dict[key]
+                assert torch.equal(a0.view(torch.int32) if a0.is_floating_point() else a0, a1.view(torch.int32) if a1.is_floating_point() else a1), (step, key)
+            assert torch.equal(separate.sim_env.scene.boxes_soa, fused.sim_env.scene.boxes_soa), step
+        assert int(fused.sim_env.global_tensor_dict["episode_count"].sum()) >= (steps // 8) * n
+        assert int(fused.success_aggregate + fused.crashes_aggregate + fused.timeouts_aggregate) == int(
+            separate.success_aggregate + separate.crashes_aggregate + separate.timeouts_aggregate)
+    finally:
+        cfg.episode_len_steps, cfg.args, cfg.device = old
+
+
 def test_builtin_action_transformations_as_one_launch():
     """agx_action_transform (what the tasks use when the config carries the built-in function) against the torch functions of
     config/task_config.py evaluated in float64-backed numpy: the linear columns bit for bit, sine / cosine correctly rounded
