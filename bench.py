@@ -377,7 +377,7 @@ def cpu_baseline_reference():
             return dict({k: d[k] for k in keys}, measured_here=True)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] the reference tree is present but could not be timed ({type(e).__name__}: {e})", file=sys.stderr)
-    for name in ("r04_cpu_baseline_reference.json", "r03_cpu_baseline_reference.json", "r02_cpu_baseline_reference.json"):
+    for name in ("r05_cpu_baseline_reference.json", "r04_cpu_baseline_reference.json", "r03_cpu_baseline_reference.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return dict({k: d[k] for k in keys}, measured_here=False, source="profiles/" + name)
