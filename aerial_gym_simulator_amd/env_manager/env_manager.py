@@ -491,7 +491,12 @@ class EnvManager(BaseManager):
                        "agx_reset_set")
             self._mask_fresh = True
         if self.strict_rng and int(g["reset_flag"][self._parity].item()) != 0:  # host sync, like the reference's nonzero()/len()
-            env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1)
+            # the indices themselves (a second synchronisation) only where a draw is shaped by them: per-env controller gains, the
+            # obstacles' half-resample, sensor mounts -- the plain position task draws for all N envs whatever the set is
+            sensor = self.robot_manager.warp_sensor
+            needs_ids = (self._randomize_gains or (self.scene.num_assets > 0 and int(g["num_obstacles_in_env"]) > 0)
+                         or (sensor is not None and sensor.cfg.randomize_placement))
+            env_ids = g["reset_mask"].nonzero(as_tuple=False).squeeze(-1) if needs_ids else None
             self._draw_reset_randoms(env_ids)
         self._launch_reset(with_obs=True, per_step=True)
         return ResetSet(g["reset_mask"])
