@@ -632,6 +632,7 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
         torch.cuda.empty_cache()
         task = make_task("dynamics", args.num_envs, device, args.strict_rng, rank)
         task.reset()
+        desynchronise_episodes(task)  # the same steady state as the first leg's `value`: resets in every timed step
         N, A = task.num_envs, task.task_config.action_space_dim
         g = torch.Generator(device=device).manual_seed(1234 + rank)
         actions = [torch.rand(N, A, device=device, generator=g) * 2 - 1 for _ in range(16)]
@@ -661,6 +662,7 @@ def library_exchange_leg(args, world, rank, device, out, backend, limit_s=240.0)
             torch.cuda.empty_cache()
             t2 = make_task("depth", args.num_envs, device, args.strict_rng, rank)
             t2.reset()
+            desynchronise_episodes(t2)
             a2 = [torch.rand(N, 4, device=device, generator=g) * 2 - 1 for _ in range(4)]
             s2 = min(max(args.steps // 10, 20), 300)
             gb2 = StepGather(N, t2.task_obs["observations"].shape[1], device, env=t2.sim_env, reward=t2.rewards, backend=backend)
