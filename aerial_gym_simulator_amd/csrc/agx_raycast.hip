@@ -238,9 +238,10 @@ AGX_DEV V3 ray_origin(const Ray &r) {
 // OBJECT NODE (AGX_BVH_BOX_OBJECTS): the tree ends at a box whose frame the 64-byte record holds (axes nx, ny, nz, half extents,
 // centre, first triangle).  The result stays what it is defined to be -- the smallest (t, face) over the triangles the EXACT test
 // accepts -- because only triangles that test cannot accept are skipped:
-//   * a = R^T (o - c), b = R^T d: the ray in the box's frame; plane +-k is met at t = (+-h_k - a_k) / b_k.  Every quantity carries an
-//     error bound far below the tolerance it is compared with: |delta t| <= 1e-6 s / |b_k| with s = |a|_1 + |h|_1 + 1 (the rounding of
-//     the nine-term products is < 3e-7 s); eps_k = 1e-3 + 1e-6 s |1 / b_k| is used for plane k, in metres and in units of t alike
+//   * a = R^T (o - c), b = R^T d: the ray in the box's frame; plane +-k is met at t = (+-h_k - a_k) / b_k, evaluated as
+//     fma(+-h_k, 1 / b_k, -a_k / b_k).  Every quantity carries an error bound far below the tolerance it is compared with:
+//     |delta t| <= 1e-6 s / |b_k| with s = |a|_1 + |h|_1 + 1 (the roundings of the dot products, of 1 / b and of the two products
+//     that cancel in the fma are each < 2e-7 s / |b_k|); eps_k = 1e-3 + 1e-6 s |1 / b_k| is used for plane k, in metres and in units of t alike
 //     (|d| = 1).  1 / b_k is clamped to +-1e30: a ray parallel to a plane has eps ~ 1e24 and keeps every face (the exact test decides).
 //   * a box is convex: the FIRST crossing of a ray with it is at t_first = the slab entry max_k(near_k) if that is >= 0 (origin
 //     outside), else the slab exit min_k(far_k) (origin inside); the exact test can accept a triangle of face F only where the ray
@@ -258,10 +259,12 @@ template <int UPID>
 AGX_DEV uint32_t box_face_candidates(const Ray &r, float4 n0, float4 n1, float4 n2, float4 n3) {
   const V3 o = ray_origin<UPID>(r);
   const V3 oc = V3{o.x - n3.x, o.y - n3.y, o.z - n3.z};
-  const float a0 = n0.x * oc.x + n0.y * oc.y + n0.z * oc.z, a1 = n1.x * oc.x + n1.y * oc.y + n1.z * oc.z,
-              a2 = n2.x * oc.x + n2.y * oc.y + n2.z * oc.z;
-  const float b0 = n0.x * r.d.x + n0.y * r.d.y + n0.z * r.d.z, b1 = n1.x * r.d.x + n1.y * r.d.y + n1.z * r.d.z,
-              b2 = n2.x * r.d.x + n2.y * r.d.y + n2.z * r.d.z;
+  // (this arithmetic is the accelerator's own -- conservative, never part of a result -- so it may contract: explicit fma, a third
+  //  fewer instructions than the mul / add chains the library's -ffp-contract=off would make of the plain expressions)
+  const float a0 = fmaf(n0.z, oc.z, fmaf(n0.y, oc.y, n0.x * oc.x)), a1 = fmaf(n1.z, oc.z, fmaf(n1.y, oc.y, n1.x * oc.x)),
+              a2 = fmaf(n2.z, oc.z, fmaf(n2.y, oc.y, n2.x * oc.x));
+  const float b0 = fmaf(n0.z, r.d.z, fmaf(n0.y, r.d.y, n0.x * r.d.x)), b1 = fmaf(n1.z, r.d.z, fmaf(n1.y, r.d.y, n1.x * r.d.x)),
+              b2 = fmaf(n2.z, r.d.z, fmaf(n2.y, r.d.y, n2.x * r.d.x));
   const float h0 = n0.w, h1 = n1.w, h2 = n2.w;
   const float kMax = 1.0e30f;
   // (v_rcp_f32, 1 ulp: the tolerance below absorbs it; a correctly rounded 1 / b is ten instructions each)
@@ -274,10 +277,11 @@ AGX_DEV uint32_t box_face_candidates(const Ray &r, float4 n0, float4 n1, float4 
   const float s = 1.0e-6f * (((fabsf(a0) + fabsf(a1)) + (fabsf(a2) + h0)) + ((h1 + h2) + 1.0f));
   const float e0 = fmaf(s, fabsf(rb0), 1.0e-3f), e1 = fmaf(s, fabsf(rb1), 1.0e-3f), e2 = fmaf(s, fabsf(rb2), 1.0e-3f);
   const float eps = fmaxf(fmaxf(e0, e1), e2);
-  // plane-crossing times: minus / plus face of each axis
-  const float tm0 = (-h0 - a0) * rb0, tp0 = (h0 - a0) * rb0;
-  const float tm1 = (-h1 - a1) * rb1, tp1 = (h1 - a1) * rb1;
-  const float tm2 = (-h2 - a2) * rb2, tp2 = (h2 - a2) * rb2;
+  // plane-crossing times: minus / plus face of each axis, (+-h - a) / b as fma(+-h, 1 / b, -a / b)
+  const float ar0 = -a0 * rb0, ar1 = -a1 * rb1, ar2 = -a2 * rb2;
+  const float tm0 = fmaf(-h0, rb0, ar0), tp0 = fmaf(h0, rb0, ar0);
+  const float tm1 = fmaf(-h1, rb1, ar1), tp1 = fmaf(h1, rb1, ar1);
+  const float tm2 = fmaf(-h2, rb2, ar2), tp2 = fmaf(h2, rb2, ar2);
   const float t_enter = fmaxf(fmaxf(fminf(tm0, tp0), fminf(tm1, tp1)), fminf(tm2, tp2));
   const float t_exit = fminf(fminf(fmaxf(tm0, tp0), fmaxf(tm1, tp1)), fmaxf(tm2, tp2));
   const float t_first = t_enter >= -eps ? t_enter : t_exit;
