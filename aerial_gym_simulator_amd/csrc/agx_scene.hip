@@ -344,31 +344,38 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
     }
   }
   if (ppo > 0) __syncthreads();  // the reduction scratch below shares the region the triangle bounds were read from
+  // bounds of the sort centres over the workgroup: inside a wave by shuffles (min / max are exact: any order gives the same bits),
+  // then the eight waves' results through LDS -- two barriers (the pairwise tree over 512 LDS entries took ten)
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    red[c * kBvhThreads + tid] = lo[c];
-    red[(3 + c) * kBvhThreads + tid] = hi[c];
+    float a = lo[c], b = hi[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a = fminf(a, __shfl_xor(a, off));
+      b = fmaxf(b, __shfl_xor(b, off));
+    }
+    if ((tid & 63) == 0) {
+      red[c * (kBvhThreads / 64) + (tid >> 6)] = a;
+      red[(3 + c) * (kBvhThreads / 64) + (tid >> 6)] = b;
+    }
   }
   __syncthreads();
-  for (int s = kBvhThreads / 2; s > 0; s >>= 1) {
-    if (tid < s) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        red[c * kBvhThreads + tid] = fminf(red[c * kBvhThreads + tid], red[c * kBvhThreads + tid + s]);
-        red[(3 + c) * kBvhThreads + tid] = fmaxf(red[(3 + c) * kBvhThreads + tid], red[(3 + c) * kBvhThreads + tid + s]);
-      }
-    }
-    __syncthreads();
-  }
-  float blo[3], inv[3];
+  float blo[3], bhi[3], inv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    blo[c] = red[c * kBvhThreads];
-    float ext = red[(3 + c) * kBvhThreads] - blo[c];
+    float a = INFINITY, b = -INFINITY;
+#pragma unroll
+    for (int wv = 0; wv < kBvhThreads / 64; ++wv) {
+      a = fminf(a, red[c * (kBvhThreads / 64) + wv]);
+      b = fmaxf(b, red[(3 + c) * (kBvhThreads / 64) + wv]);
+    }
+    blo[c] = a;
+    bhi[c] = b;
+    float ext = b - a;
     inv[c] = (ext > 0.0f && ext < INFINITY) ? 1023.0f / ext : 0.0f;  // ext = -inf - inf when every primitive is parked
   }
+  float max_ext = fmaxf(fmaxf(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]);
   // --- keys: [large flag | 30-bit Morton code of the sort centre] . [triangle index]
-  float max_ext = fmaxf(fmaxf(red[3 * kBvhThreads] - blo[0], red[4 * kBvhThreads] - blo[1]), red[5 * kBvhThreads] - blo[2]);
   // --- objects of ppo triangles each (boxes: 12): the order of the keys is the order of the OBJECTS' codes, and inside an
   // object (face class, index).  So sort the K object keys (128 instead of 2048: the full sort was 35 of the build's 67 us) and
   // RANK every triangle inside its object against the ppo - 1 others.  This is the full sort's order exactly unless two
