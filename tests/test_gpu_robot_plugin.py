@@ -33,6 +33,7 @@ def _register(name, cfg_name, with_extra):
             super().step(action_tensor)  # update_states, controller, allocation, motors, drag, disturbance: one launch
             type(self).calls += 1
             if with_extra:
+                # (a torque on the third motor link; root-link robots apply everything at body 0 but keep their motor links)
                 third = int(self.cfg.control_allocator_config.application_mask[2])
                 self.robot_force_tensors[:, 0, :] += torch.from_numpy(EXTRA_F).to(self.robot_force_tensors.device)
                 self.robot_torque_tensors[:, third, 2] += float(EXTRA_TZ)
@@ -45,6 +46,7 @@ def _register(name, cfg_name, with_extra):
     ("base_quadrotor", "lee_position_control", "empty_env", 1),
     ("base_quadrotor", "lee_velocity_control", "env_with_random_boxes", 10),
     ("base_octarotor", "octarotor_velocity_control", "empty_env", 1),     # tilted motor links, non-zero drag
+    ("base_quad_root_link_control", "lee_position_control", "empty_env", 1),  # the allocator's wrench at the root link (mask [0])
 ])
 def test_toy_robot_subclass_is_stepped_like_the_reference_and_matches_the_oracle(orc, robot, controller, env_name, substeps):
     from aerial_gym_simulator_amd.robots.robot_model import link_frames
@@ -66,12 +68,13 @@ def test_toy_robot_subclass_is_stepped_like_the_reference_and_matches_the_oracle
     gains = [np.tile(((np.array(ctrl.gains_max, np.float32) + np.array(ctrl.gains_min, np.float32)) / np.float32(2))[3 * k:3 * k + 3], (n, 1))
              for k in range(4)]
     NB = int(g["robot_force_tensor"].shape[1])
-    mask = [int(b) for b in rob.cfg.control_allocator_config.application_mask]
-    assert NB == max(mask) + 1 == {"base_quadrotor": 9, "base_octarotor": 17}[robot]
+    links = [int(b) for b in rob.cfg.control_allocator_config.application_mask]  # the motor links' body indices
+    mask = [0] if pd["root_link_mode"] else links                                # where the allocator's output goes (base_multirotor.py:152-159)
+    assert NB == max(links) + 1 == {"base_quadrotor": 9, "base_octarotor": 17, "base_quad_root_link_control": 9}[robot]
     L, known = link_frames(rob.cfg, NB)
     rot = np.array([[L.rot[b][c] for c in range(9)] for b in range(NB)], np.float32)
     pos = np.array([[L.pos[b][c] for c in range(3)] for b in range(NB)], np.float32)
-    assert [b for b, k in enumerate(known) if k] == [0] + mask
+    assert [b for b, k in enumerate(known) if k] == [0] + links
     dcfg = rob.cfg.disturbance
     dmax = np.array(dcfg.max_force_and_torque_disturbance, np.float32)
     gen = torch.Generator(device=DEV).manual_seed(3)
@@ -90,7 +93,7 @@ def test_toy_robot_subclass_is_stepped_like_the_reference_and_matches_the_oracle
                 dist[:, 0] = (dist[:, 0] < np.float32(dcfg.prob_apply_disturbance)).astype(np.float32)
             o, F, T = orc.robot_step(P, st, npy(a), th, kT, ti, td, *gains, NB, mask, disturb=dist, disturb_max=dmax)
             F[:, 0, :] += EXTRA_F
-            T[:, mask[2], 2] += EXTRA_TZ
+            T[:, links[2], 2] += EXTRA_TZ
             net = orc.net_body_wrench(rot, pos, F, T)
             orc.integrate(P, st, net)
         # the per-body tensors as the LAST sub-step's step() left them, the motor thrusts, the state: bit for bit
