@@ -1087,6 +1087,8 @@ def main():
         "timed_regions": {"count": len(dts), "steps_each": args.steps, "value_is": "median",
                           "ms_per_step": [1e3 * x / args.steps for x in dts],
                           "value_min": n_gpus * N * args.steps / dts_sorted[-1], "value_max": n_gpus * N * args.steps / dts_sorted[0]},
+        "value_is": "steady state with de-synchronised episodes: num_envs / episode_len envs reset in EVERY timed step (since round 5; rounds 1-4 "
+                    "timed short regions right after reset(), where no env resets: that figure is `value_synchronised_episodes`)",
         "episodes": dict(desync, state="de-synchronised (steady state: resets in every step)"),
         "value_synchronised_episodes": n_gpus * N * sync_steps / dts_sync[1],
         "synchronised_episodes": {"ms_per_step": [1e3 * x / sync_steps for x in dts_sync], "steps_each": sync_steps, "regions": 3,
