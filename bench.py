@@ -426,7 +426,7 @@ def live_parity(device):
     return {"case": "tests/golden/step_quad_position.npz (reference BaseMultirotor.step outputs, 6 sub-steps x 64 envs)",
             "max_err_vs_reference": out, "bit_exact_vs_reference_with_correctly_rounded_functions": bool(exact), "unit": "|err| / max(1, |x|) per component (thrust: / 2 N full scale)",
             "gates": "tests/ (pytest -m gpu): bit-exact vs the CPU oracle, <= 1e-5 vs the reference (every state component), bit-exact vs the reference with correctly rounded elementary functions; "
-                     "measured maxima of the last full run: profiles/r04_parity_report.json"}
+                     "measured maxima of the last full run: profiles/r05_parity_report.json"}
 
 
 def kernel_time_dynamics(task, actions, reps=400):
@@ -707,10 +707,158 @@ _ABANDONED = []
 _JSON_FD = [None]
 
 
+LINE_LIMIT = 6144  # bytes of the ONE stdout line; the driver keeps ~9 KB of stdout and parses the line from it (r05: a 23 KB line -> "parsed": null)
+DETAIL_NAME = "bench_detail.json"
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the line is a record, not an archive: bench_detail.json keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roofline_brief(blk):
+    """the contract's roofline object and nothing nested: bound / achieved / peak / unit / frac / traffic + the kernel it is
+    about, its live launch time, the algorithmic bytes it is priced with and the traffic ratio"""
+    if not isinstance(blk, dict):
+        return blk
+    if "error" in blk:
+        return {"error": str(blk["error"])[:160]}
+    hbm = blk.get("hbm") or blk  # a kernel labelled bound "valu" keeps its byte view under "hbm": the LINE carries the byte view
+    out = {"bound": "hbm", "achieved": hbm.get("achieved"), "peak": hbm.get("peak"), "unit": hbm.get("unit"), "frac": hbm.get("frac"),
+           "traffic": hbm.get("traffic"), "kernel": str(blk.get("kernel", ""))[:96], "launch_us": blk.get("launch_us"),
+           "algorithmic_bytes_per_launch": hbm.get("algorithmic_bytes_per_launch"),
+           "traffic_over_algorithmic": hbm.get("traffic_over_algorithmic"), "traffic_stale": hbm.get("traffic_stale")}
+    if blk.get("bound") == "valu":
+        out["limited_by"] = "valu issue"
+        out["valu_issue_frac_of_guide_peak"] = blk.get("frac")
+    if "num_envs" in blk:
+        out["num_envs"] = blk["num_envs"]
+    return out
+
+
+def _sensor_brief(leg):
+    if not isinstance(leg, dict):
+        return leg
+    out = _pick(leg, ("value", "unit", "ms_per_step", "steps", "workload", "value_synchronised_episodes", "raycast_launch_us", "exchange"))
+    if "workload" in out:
+        out["workload"] = str(out["workload"])[:200]
+    rr = leg.get("raycast_roofline")
+    if isinstance(rr, dict):
+        hbm = rr.get("hbm") or rr
+        out["raycast_hbm_frac"] = hbm.get("frac")
+        out["raycast_traffic_over_algorithmic"] = hbm.get("traffic_over_algorithmic")
+    cb = leg.get("cpu_baseline_raycast")
+    if isinstance(cb, dict):
+        out["cpu_baseline_raycast"] = _pick(cb, ("value", "unit", "cores", "kind"))
+    return out
+
+
+def compact_line(out, detail_path=None):
+    """What goes on stdout: the contract's keys, the two objects it asks for (`roofline`, `cpu_baseline`), one number per
+    secondary leg, and the path of the file that holds everything else.  Everything measured stays in `out` -> bench_detail.json."""
+    if "metric" not in out:  # self-test verdicts and the like: small by construction
+        return out
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data"))
+    cfg = dict(out.get("config", {}))
+    for k in ("workload", "sharding"):
+        if k in cfg:
+            cfg[k] = str(cfg[k])[:220]
+    line["config"] = cfg
+    if "roofline" in out:
+        line["roofline"] = _roofline_brief(out["roofline"])
+    if "cpu_baseline" in out:
+        cb = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "measured_here"))
+        cb["sample"] = str(cb.get("sample", ""))[:200]
+        line["cpu_baseline"] = cb
+    for k in ("cpu_baseline_reference", "cpu_baseline_port"):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("value", "unit", "cores", "kind", "measured_here", "source"))
+    tr = out.get("timed_regions")
+    if isinstance(tr, dict):
+        line["timed_regions"] = _pick(tr, ("count", "steps_each", "value_is", "value_min", "value_max"))
+    line["value_is"] = "median region; de-synchronised episodes (resets in every timed step)"
+    for k in ("value_synchronised_episodes", "value_strict_rng"):
+        if k in out:
+            line[k] = out[k]
+    if isinstance(out.get("host"), dict):
+        line["host_share_of_step"] = out["host"].get("share_of_step")
+    for k in ("roofline_reset_obs", "roofline_at_scale", "roofline_at_scale_lean"):
+        if k in out:
+            b = _roofline_brief(out[k])
+            line[k] = _pick(b, ("kernel", "launch_us", "frac", "traffic_over_algorithmic", "num_envs", "error")) if isinstance(b, dict) else b
+    if isinstance(out.get("roofline_step"), dict):
+        line["roofline_step"] = _pick(out["roofline_step"], ("launches", "kernel_us_sum", "algorithmic_bytes_per_step", "frac_over_step_time"))
+    for k in ("plus_depth", "plus_lidar"):
+        if k in out:
+            line[k] = _sensor_brief(out[k])
+    ex = out.get("exchange")
+    if isinstance(ex, dict):
+        brief = _pick(ex, ("ms_per_step_with_exchange", "ms_per_step_without_exchange", "all_gather_us_synchronised", "bytes_per_rank",
+                           "communicator_ranks", "backend_of_first_leg"))
+        for b in ("process_group", "peer_push", "rccl_thread"):
+            if isinstance(ex.get(b), dict):
+                brief[b] = _pick(ex[b], ("value", "ms_per_step", "plus_depth_value", "ranks_seen", "failed_in"))
+                if "error" in ex[b]:
+                    brief[b]["error"] = str(ex[b]["error"])[:160]
+        line["exchange"] = brief
+    par = out.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = ({"error": str(par["error"])[:160]} if "error" in par else
+                          {"max_err_vs_reference": par.get("max_err_vs_reference"),
+                           "bit_exact_vs_reference_cr": par.get("bit_exact_vs_reference_with_correctly_rounded_functions")})
+    if isinstance(out.get("strict_rng"), dict) and "error" in out["strict_rng"]:
+        line["strict_rng_error"] = str(out["strict_rng"]["error"])[:160]
+    line.update(_pick(out, ("build_id", "binary_matches_sources")))
+    if detail_path:
+        line["detail"] = detail_path
+    line = _r(line)
+    # the guard: whatever a future key adds, the line that reaches stdout parses from the driver's tail.  Secondary objects go
+    # first (they are all in the detail file), the contract's keys never
+    for k in ("parity", "exchange", "roofline_step", "roofline_reset_obs", "roofline_at_scale_lean", "roofline_at_scale", "cpu_baseline_port",
+              "cpu_baseline_reference", "plus_lidar", "plus_depth", "timed_regions"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        if k in line:
+            line.pop(k)
+            line.setdefault("dropped_for_size", []).append(k)
+    assert len(json.dumps(line)) < LINE_LIMIT, "bench line over the size the driver parses"
+    return line
+
+
+def write_detail(out):
+    """everything measured, at full precision: bench_detail.json next to bench.py (and under gpurun_out/ when that exists, so
+    that a gpurun call brings it back).  Returns the path named in the line (relative to the repo root)."""
+    text = json.dumps(out, indent=1)
+    path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                f.write(text)
+            path = path or os.path.relpath(os.path.join(d, DETAIL_NAME), ROOT)
+        except OSError:
+            continue
+    return path
+
+
 def emit_line(out, fd=None):
-    """the ONE JSON line, on the process's original stdout"""
+    """the ONE JSON line, on the process's original stdout: the compact form (< LINE_LIMIT bytes); the full record goes to
+    bench_detail.json"""
     fd = fd if fd is not None else _JSON_FD[0]
-    line = json.dumps(out) + "\n"
+    detail = write_detail(out) if "metric" in out else None
+    line = json.dumps(compact_line(out, detail)) + "\n"
     if fd is None:
         sys.stdout.write(line)
         sys.stdout.flush()

@@ -84,3 +84,44 @@ def test_exchange_selftest_only_prints_one_verdict_per_backend():
         assert v["selftest"] == "exchange" and v["ok"] is True and v["world"] == 1 and v["steps"] == 300, v
         (pr,) = v["per_rank"]
         assert pr["own_slice_ok"] and pr["first_bad_step_by_sender"] == {} and pr["resets"] > 300 * 2  # ~4 truncations per step at 2048 envs
+
+
+def _bench_module():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench
+
+
+@pytest.mark.parametrize("name", ["r05_bench_driver_style", "r05_bench_default", "r05_bench_forced_dist_world1", "r05_bench_lidar"])
+def test_stdout_line_stays_parseable_from_the_drivers_tail(name):
+    """the driver keeps ~9 KB of stdout and parses the ONE JSON line out of it; round 5's 23 KB line came
+    back as "parsed": null.  The line built from round 5's full records is < 8 KB, parses from its own last 8 KB, and still
+    carries the contract's keys and the two objects the contract adds."""
+    bench = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", name + ".json")))
+    assert len(json.dumps(full)) > 4000  # the canned record is the big one
+    line = json.dumps(bench.compact_line(full, "bench_detail.json")) + "\n"
+    assert len(line) < bench.LINE_LIMIT < 8192
+    d = json.loads(line[-8192:])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert all(not isinstance(v, (dict, list)) for v in r.values())  # nothing nested
+    if "cpu_baseline" in full:
+        assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert d["detail"] == "bench_detail.json"
+
+
+def test_stdout_line_guard_drops_secondary_objects_never_the_contract():
+    bench = _bench_module()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_driver_style.json")))
+    full["config"]["num_envs_per_gpu"] = "x" * 1500  # something a later edit let grow
+    full["plus_depth"]["exchange"] = "y" * 2500
+    full["plus_lidar"]["exchange"] = "z" * 2500
+    line = bench.compact_line(full, "bench_detail.json")
+    assert len(json.dumps(line)) < bench.LINE_LIMIT
+    assert "dropped_for_size" in line and "roofline" in line and "cpu_baseline" in line and "value" in line
