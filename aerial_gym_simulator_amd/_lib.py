@@ -239,12 +239,14 @@ class AgxLinkFrames(C.Structure):
     _fields_ = [("num_bodies", C.c_int32), ("reserved", C.c_int32), ("rot", (C.c_float * 9) * MAX_BODIES), ("pos", (C.c_float * 3) * MAX_BODIES)]
 
 
-ABI_VERSION = 11  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
+ABI_VERSION = 12  # AGX_ABI_VERSION of include/aerial_gym_hip.h these mirrors were written against
 _P = C.c_void_p
 _SIGNATURES = {
     "agx_last_error": (C.c_char_p, []),
     "agx_abi_version": (C.c_int, []),
     "agx_build_id": (C.c_char_p, []),
+    "agx_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "agx_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "agx_math_eval": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P]),
     "agx_copy_f4": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "agx_dynamics_substeps": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, _P, C.c_int, _P]),
@@ -388,6 +390,33 @@ def binary_matches_sources():
     """True when the loaded library was built from the kernel sources lying next to it (counter files under profiles/ are
     stamped with `build_id()`; a stale library shipped with newer sources shows up here, not in file times)"""
     return build_id() == _build.source_hash()
+
+
+def set_option(name, value):
+    """agx_set_option: process-wide tuning / A-B switches of the library ("env_step_quad", "ray_split"; include/aerial_gym_hip.h)"""
+    check(load().agx_set_option(name.encode(), int(value)), "agx_set_option")
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(load().agx_get_option(name.encode(), C.byref(v)), "agx_get_option")
+    return v.value
+
+
+class option:
+    """`with _lib.option("env_step_quad", 0): ...` -- the previous value comes back on exit"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def check(code, what=""):

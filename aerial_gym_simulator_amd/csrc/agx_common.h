@@ -19,6 +19,10 @@ inline int check_launch(const char *what) {
   return AGX_OK;
 }
 
+// process-wide options (agx_set_option, agx_api.cpp); read per launch
+int option_env_step_quad();
+int option_ray_split();
+
 inline int blocks_for(int n, int block) { return (n + block - 1) / block; }
 
 // Small batches are latency bound: spread them over as many CUs as possible

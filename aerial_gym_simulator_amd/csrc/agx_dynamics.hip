@@ -2156,10 +2156,9 @@ static int check_common(const AgxRobotParams *P, const AgxEnvBuffers *B, int n) 
   return AGX_OK;
 }
 
-// The four-lanes-per-env kernel covers the plain quadrotor position step; AGX_ENV_STEP_QUAD=0 keeps k_env_step (A/B runs).
+// The four-lanes-per-env kernel covers the plain quadrotor position step; agx_set_option("env_step_quad", 0) keeps k_env_step (A/B runs).
 static bool quad_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, const AgxTaskArgs *T) {
-  const char *e = getenv("AGX_ENV_STEP_QUAD");  // looked up per launch: tests flip it inside one process
-  if ((e && e[0] == '0') || B->boxes || B->launch_flags != 0 || B->disturb || B->disturb_prob > 0.0f || P->num_actions != 4) return false;
+  if (!option_env_step_quad() || B->boxes || B->launch_flags != 0 || B->disturb || B->disturb_prob > 0.0f || P->num_actions != 4) return false;
   if (T->kind != AGX_TASK_NONE && T->kind != AGX_TASK_POSITION) return false;
   for (int c = 0; c < 3; ++c)
     if (P->lin_drag_linear[c] != 0.0f || P->lin_drag_quadratic[c] != 0.0f || P->ang_drag_linear[c] != 0.0f ||
@@ -2170,8 +2169,7 @@ static bool quad_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, 
 
 // ... and the sub-step loop of the velocity / acceleration controlled quadrotors (navigation tasks)
 static bool quad_loop_kernel_usable(const AgxRobotParams *P, const AgxEnvBuffers *B, int n, int k) {
-  const char *e = getenv("AGX_ENV_STEP_QUAD");
-  if ((e && e[0] == '0') || pick_block(n) != 64 || k < 1 || B->launch_flags != 0) return false;
+  if (!option_env_step_quad() || pick_block(n) != 64 || k < 1 || B->launch_flags != 0) return false;
   const bool lee_quad = P->num_motors == 4 && P->num_actions == 4 && P->controller >= AGX_CTRL_POSITION &&
                         P->controller <= AGX_CTRL_VEL_STEERING;
   const bool fa_octa = P->num_motors == 8 && P->num_actions == 7 && P->controller == AGX_CTRL_FULLY_ACTUATED;
@@ -2434,8 +2432,7 @@ extern "C" int agx_post_step_position(const AgxRobotParams *P, const AgxEnvBuffe
   if (int e = check_reset(P, B, n, R)) return e;
   AGX_REQUIRE(target && obs && B->state && B->derived, "null buffer");
   const int block = pick_block(n);
-  const char *qe = getenv("AGX_ENV_STEP_QUAD");
-  if (block == 64 && P->num_motors == 4 && !(qe && qe[0] == '0')) {
+  if (block == 64 && P->num_motors == 4 && option_env_step_quad()) {
     if (R->u_state)
       hipLaunchKernelGGL(k_reset_masked_quad_obs_host_draws, dim3(blocks_for(n, 16)), dim3(64), 0, (hipStream_t)stream, *P, *B, n, *R,
                          target, obs);

@@ -717,7 +717,7 @@ static unsigned ray_launch_shape(int images, int width, int height, bool lidar, 
   const int tiles = ((width + tw - 1) / tw) * ((height + th - 1) / th), waves_per_wg = kRayThreads / 64;
   const int max_split = (tiles + waves_per_wg - 1) / waves_per_wg;
   int split = ray_split_policy(images, tiles, lidar);
-  if (const char *e = getenv("AGX_RAY_SPLIT")) split = atoi(e);  // tuning knob (profiles/raycast_split_probe.py)
+  if (const int forced = option_ray_split()) split = forced;  // tuning knob: agx_set_option("ray_split", n) (profiles/raycast_split_probe.py)
   split = split < 1 ? 1 : (split > max_split ? max_split : split);
   *split_out = split;
   return (((unsigned)images + 7u) / 8u) * 8u * (unsigned)split;

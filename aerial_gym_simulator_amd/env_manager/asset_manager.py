@@ -1,7 +1,6 @@
 """Obstacle pose randomisation at reset (aerial_gym/env_manager/asset_manager.py:51-71 and the
 half-obstacle resample of env_manager.py:283-295) in agx_reset_assets, followed by the scene
 rebuild of the reset envs (warp_env_manager.py:40-54): triangles, LBVH, collision OBBs."""
-import os
 
 import torch
 
@@ -82,7 +81,7 @@ class AssetManager:
         N, K = sc.num_envs, sc.num_assets
         lib, stream, p = env._lib, env._stream(), _lib.dptr
         st = self.env_asset_state_tensor
-        if not env.strict_rng and not sc.has_prims and os.environ.get("AGX_FUSED_ASSET_RESET", "1") != "0":
+        if not env.strict_rng and not sc.has_prims and env.env_args.get("fused_asset_reset", True):
             # obstacle poses, world-frame triangles, collision boxes and tree of the envs that reset: one call -- up to 2048 envs ONE
             # launch (the asset reset and the mask compaction are gone from the step), above, the three launches below
             _lib.check(

@@ -133,7 +133,8 @@ class EnvManager(BaseManager):
         # would make neighbouring ranks share scene seeds, segmentation ids and device-RNG streams.
         rank = int(self.env_args.get("shard_rank", 0))
         self.env_offset = int(self.env_args.get("env_offset", rank * N))
-        self.scene = SceneManager(env_cfg, N, dev, self.random_source, shard_rank=rank, env_offset=self.env_offset)
+        self.scene = SceneManager(env_cfg, N, dev, self.random_source, shard_rank=rank, env_offset=self.env_offset,
+                                  box_objects=bool(self.env_args.get("bvh_box_objects", True)))
         self.keep_in_env = self.scene.keep_in_env_num
         g["num_obstacles_in_env"] = self.scene.num_assets
         self.robot_manager = RobotManagerHIP(self.global_tensor_dict, self.cfg, self.robot_name, self.controller_name, dev)

@@ -28,7 +28,7 @@ _BOX_FACES = np.array(
 
 
 class SceneManager:
-    def __init__(self, env_cfg, num_envs, device, random_source, shard_rank=0, scene_seed_base=1000, env_offset=None):
+    def __init__(self, env_cfg, num_envs, device, random_source, shard_rank=0, scene_seed_base=1000, env_offset=None, box_objects=True):
         self.cfg, self.num_envs, self.device = env_cfg, num_envs, device
         self.shard_rank = shard_rank
         # this process owns global envs [env_offset, env_offset + N)  (SURVEY 8e); equal shards: rank * N
@@ -51,8 +51,9 @@ class SceneManager:
         # objects of 12 consecutive triangles (agx_bvh_build) + AGX_BVH_BOX_OBJECTS: where an object's 12 triangles ARE a box of
         # trimesh's topology -- the builder checks every vertex -- the tree ends at the object and the ray-cast kernels intersect
         # the box's frame, running the exact triangle test on the entered face only (same frames, bit for bit); chunks of a
-        # cylinder / sphere / mesh keep their triangle subtrees.  AGX_BVH_BOX_OBJECTS=0: triangle subtrees everywhere (A/B runs).
-        self.bvh_prims_per_object = 12 | (0x20000000 if os.environ.get("AGX_BVH_BOX_OBJECTS", "1") != "0" else 0)
+        # cylinder / sphere / mesh keep their triangle subtrees.  box_objects=False (EnvManager args={"bvh_box_objects": False}):
+        # triangle subtrees everywhere (A/B runs).
+        self.bvh_prims_per_object = 12 | (0x20000000 if box_objects else 0)
         # sharding: start of this rank's slice of the global asset counter
         semantic_offset = self.semantic_offset = env_offset * K  # this shard's slice of the global id counter
         if K == 0:

@@ -71,7 +71,7 @@ class StepGather:
     KERNEL_PUSH_MAX_ROW = 16  # floats: rows up to this size are stored at every destination by the observation kernel itself
 
     def __init__(self, num_envs_local, obs_dim, device, env=None, reward=None, group=None, backend="auto", ready="signal",
-                 kernel_push=None, rccl_library=None):
+                 kernel_push=None, rccl_library=None, push_selftest=True):
         """backend: "process_group" (torch.distributed collective), "rccl_thread" (the library's worker
         thread on its own RCCL communicator; HIP devices only) or "auto" (rccl_thread when the group runs
         on RCCL and every rank could set it up, else process_group).
@@ -85,6 +85,7 @@ class StepGather:
         launching kernels; the wide rows of the sensor tasks (84 / 340 floats) are produced element by element -- 4-byte
         stores across xGMI -- so they go through the copy kernel, whose launch is nothing next to a millisecond step."""
         self.group = group
+        self._want_push_selftest = bool(push_selftest)  # peer_push: a word and a flag through every mapping before the first post
         self._rccl_library = rccl_library  # tests only: path of the collective library `rccl_thread` binds (default: torch's RCCL)
         self.collective = dist.is_initialized()  # a world of one still goes through RCCL (bench debugging aid)
         self.world = dist.get_world_size(group) if self.collective else 1
@@ -207,8 +208,6 @@ class StepGather:
         handle = C.c_void_p()
         rc = lib.agx_exchange_create_push(dist.get_rank(self.group), self.world, index, self._count, C.byref(handle))
         err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
-        if os.environ.get("AGX_TEST_PUSH_SETUP_FAIL") == "1" and rc == 0:  # test hook: a platform that refuses the peer mappings
-            rc, err = 1, "injected set-up failure (AGX_TEST_PUSH_SETUP_FAIL)"
         mine = (C.c_char * 128)()
         if rc == 0:
             rc = lib.agx_exchange_push_export(handle, mine, 128)
@@ -223,7 +222,7 @@ class StepGather:
             rc = lib.agx_exchange_push_connect(handle, raw, len(raw))
             err = lib.agx_last_error().decode("utf-8", "replace") if rc else ""
             ok, _ = self._agree(rc == 0)
-            if ok and os.environ.get("AGX_PUSH_SELFTEST", "1") != "0":  # mapped everywhere: do stores through the mappings arrive?  (one word and one flag per pair of ranks)
+            if ok and self._want_push_selftest:  # mapped everywhere: do stores through the mappings arrive?  (one word and one flag per pair of ranks)
                 passed = C.c_int(0)
                 rc = lib.agx_exchange_push_selftest(handle, self.PUSH_SELFTEST_MS, C.byref(passed),
                                                     torch.cuda.current_stream(self.device).cuda_stream)
@@ -361,8 +360,6 @@ class StepGather:
         else:
             prev = wait_parity = parity
         send, recv = self._ptr[parity]
-        if os.environ.get("AGX_EXCHANGE_NO_WAIT") == "1":  # experiment: what the per-step wait on the stepping stream costs
-            wait_parity = -1
         if self._push:  # the rows gathered by the s-th post lie in slot (s - 1) % slots of the exchange's own buffer
             self._posts += 1
             new_slot = (self._posts - 1) % self.push_slots

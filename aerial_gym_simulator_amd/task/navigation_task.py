@@ -7,7 +7,6 @@ The reference encodes the depth image with a pre-trained VAE (dense conv net, ou
 simulation hot path); with `vae_config.use_vae = False` (default here) the 64
 latent slots carry an 8 x 8 min-pooled depth grid instead."""
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -32,6 +31,7 @@ class NavigationTask(BaseTask):
         super().__init__(task_config)
         cfg = self.task_config
         self.device = cfg.device
+        self._args = dict(cfg.args) if isinstance(cfg.args, dict) else {}  # a snapshot: the config object is shared between tasks
         self.sim_env = SimBuilder().build_env(
             sim_name=cfg.sim_name, env_name=cfg.env_name, robot_name=cfg.robot_name,
             controller_name=cfg.controller_name, args=cfg.args, device=self.device, num_envs=cfg.num_envs,
@@ -84,14 +84,16 @@ class NavigationTask(BaseTask):
         self._timeouts = torch.zeros(N, dtype=torch.bool, device=dev)
         self._counters = torch.zeros(3, dtype=torch.int32, device=dev)
         self._graphs, self._graph_action = None, None  # see _graph_mode()
-        import os
-
-        want = cfg.args.get("step_graph") if isinstance(cfg.args, dict) else None
-        self._graph_wanted = bool(want) if want is not None else os.environ.get("AGX_STEP_GRAPH", "0") == "1"
+        self._graph_wanted = bool(self._arg("step_graph", False))
         self.sim_env.step_graph_mode = self._graph_wanted  # (sharding.StepGather: no kernel-side push inside a replayed graph)
         self._min_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_min_ratio])
         self._max_ratio = (C.c_float * 3)(*[float(v) for v in cfg.target_max_ratio])
         self._fuse_with_env()
+
+    def _arg(self, key, default):
+        """switches of this task come through task_config.args as it was at construction (the dict that also reaches the
+        EnvManager), never through the process environment"""
+        return self._args.get(key, default)
 
     def _fuse_with_env(self):
         env = self.sim_env
@@ -107,8 +109,8 @@ class NavigationTask(BaseTask):
         for i in range(18):
             T.rp[i] = self._rp[i]
         # sync-free mode: successes / timeouts / curriculum counters of the step come out of the same epilogue (the arithmetic of
-        # agx_nav_bookkeeping on the launch's registers: one dispatch fewer per step).  AGX_FUSED_BOOKKEEPING=0: the launch of its own.
-        self._bookkeeping_fused = not env.strict_rng and os.environ.get("AGX_FUSED_BOOKKEEPING", "1") != "0"
+        # agx_nav_bookkeeping on the launch's registers: one dispatch fewer per step).  args={"fused_bookkeeping": False}: the launch of its own.
+        self._bookkeeping_fused = not env.strict_rng and bool(self._arg("fused_bookkeeping", True))
         if self._bookkeeping_fused:
             T.successes, T.timeouts, T.counters = _lib.dptr(self._successes), _lib.dptr(self._timeouts), _lib.dptr(self._counters)
             T.success_radius = 1.0
@@ -237,7 +239,7 @@ class NavigationTask(BaseTask):
         what explicit reset_idx() / render() calls use; both run the same device functions."""
         env = self.sim_env
         rm = env.robot_manager
-        wanted = os.environ.get("AGX_FUSED_ROBOT_SIDE", "1") != "0"
+        wanted = bool(self._arg("fused_robot_side", True))
         if not wanted or env.strict_rng or env._buffers is None or rm.imu_sensor is not None or env.post_obs is not None:
             self._fused_side = False
             return
@@ -331,7 +333,7 @@ class NavigationTask(BaseTask):
         self.num_task_steps += 1
         self._bookkeeping_host()
 
-    # ---- opt-in (args={"step_graph": True} / AGX_STEP_GRAPH=1): the step as a replayed hipGraph -----------------------
+    # ---- opt-in (args={"step_graph": True}): the step as a replayed hipGraph -----------------------
     # In the sync-free mode the step has no host synchronisation and fixed buffers, so it can be captured once per
     # (reset-flag parity, curriculum level[, action-ring slot]) and replayed: one launch per step instead of ~15.  What
     # changes from step to step travels through memory: the action (a static buffer), the step index

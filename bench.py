@@ -66,9 +66,11 @@ def parse():
 LEAN_AT_SCALE_ENVS = (1 << 21) + 256  # its own grid size: the PMC file keys kernels by name + grid, and the lean launch is the same kernel
 
 
-def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", lean=None):
+def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", lean=None, extra_args=None):
     """obstacles: "all" = every obstacle of the scene is in the env (BASELINE configs 3/4: 100 boxes + 6 walls);
-    "curriculum" = the task's own curriculum start (navigation_task_config.py: level 15 of 106)."""
+    "curriculum" = the task's own curriculum start (navigation_task_config.py: level 15 of 106).
+    extra_args: merged into the task's `args` dict (profiles/ scripts: {"step_graph": True}, {"bvh_box_objects": False}, ...)."""
+    extra = dict(extra_args or {})
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import navigation_task_config, position_setpoint_task_config
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -77,7 +79,7 @@ def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", l
         cfg = position_setpoint_task_config
         cfg.controller_name = "lee_position_control"
         cfg.device = device
-        cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
+        cfg.args = dict({"strict_rng": strict_rng, "shard_rank": rank}, **extra)
         if lean is not None:  # the lean step is opt-in (args={"lean_step": True}); None = the task's default = every tensor maintained
             cfg.args["lean_step"] = bool(lean)
         return task_registry.make_task("position_setpoint_task", seed=1 + rank, num_envs=num_envs, headless=True)
@@ -85,7 +87,7 @@ def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", l
         from aerial_gym_simulator_amd.config.task_config import lidar_navigation_task_config as lcfg
 
         lcfg.device = device
-        lcfg.args = {"strict_rng": strict_rng, "shard_rank": rank}
+        lcfg.args = dict({"strict_rng": strict_rng, "shard_rank": rank}, **extra)
         return task_registry.make_task("lidar_navigation_task", seed=1 + rank, num_envs=num_envs, headless=True)
     if workload == "lidar":  # BASELINE configs[3] as written: FULLY-ACTUATED octarotor (7-D command) + 32 x 512 LiDAR
         from aerial_gym_simulator_amd.config.task_config import fully_actuated_lidar_navigation_task_config as cfg
@@ -95,7 +97,7 @@ def make_task(workload, num_envs, device, strict_rng, rank=0, obstacles="all", l
         cfg._reference_curriculum = (cfg.curriculum.min_level, cfg.curriculum.max_level)
     cfg.curriculum.min_level, cfg.curriculum.max_level = (106, 107) if obstacles == "all" else cfg._reference_curriculum
     cfg.device = device
-    cfg.args = {"strict_rng": strict_rng, "shard_rank": rank}  # rank: own scenes, RNG stream and semantic-id range
+    cfg.args = dict({"strict_rng": strict_rng, "shard_rank": rank}, **extra)  # rank: own scenes, RNG stream and semantic-id range
     if workload == "lidar":
         return task_registry.make_task("navigation_task_fully_actuated_lidar", seed=1 + rank, num_envs=num_envs, headless=True)
     if workload == "lidar_velocity":  # the same robot and sensor under the Lee velocity controller (4-D command)

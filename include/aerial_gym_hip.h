@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AGX_ABI_VERSION 11
+#define AGX_ABI_VERSION 12
 #define AGX_MAX_MOTORS 8
 #define AGX_MAX_ACTIONS 8
 #define AGX_MAX_SUBSTEPS 32
@@ -212,6 +212,16 @@ int agx_abi_version(void);
  * the sources they see (`_build.source_hash()`): a stale library shipped next to newer sources is detected whatever its
  * file times say; bench.py stamps committed counter files with it.                                                     */
 const char *agx_build_id(void);
+
+/* Process-wide tuning / A-B options of the library (none changes a result: every setting is bit-identical, tests hold that).
+ * They replace the environment variables rounds 1-5 read inside the launch paths (AGX_ENV_STEP_QUAD, AGX_RAY_SPLIT): the
+ * library reads NO environment variable.
+ *   "env_step_quad"  1 (default): the four-lanes-per-env kernels where they apply; 0: one lane per env everywhere
+ *   "ray_split"      0 (default): workgroups per (env, sensor) image by the launch policy (csrc/agx_raycast.hip
+ *                    ray_split_policy); n > 0: that many (clamped to the image's tiles)
+ * agx_set_option returns AGX_E_ARG for an unknown name or a value out of range; agx_get_option reads the current value.  */
+int agx_set_option(const char *name, int value);
+int agx_get_option(const char *name, int *value);
 
 /* ---- dynamics -------------------------------------------------------------------
  * agx_dynamics_substeps: `k` physics sub-steps of every env, fused in one launch.

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for sp in 1 4 12; do
   for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQC_DCACHE_HITS SQC_DCACHE_MISSES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     tag=$(echo $set | cut -d' ' -f1)
-    AGX_RAY_SPLIT=$sp timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_s${sp}_$tag -o p -- python $GRAFT_REPO_ROOT/profiles/pmc_raycast.py depth > $O/pmc_s${sp}_$tag.log 2>&1
+    AGX_PROBE_RAY_SPLIT=$sp timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_s${sp}_$tag -o p -- python $GRAFT_REPO_ROOT/profiles/pmc_raycast.py depth > $O/pmc_s${sp}_$tag.log 2>&1
   done
 done
 python - <<'PY'

@@ -1,5 +1,5 @@
 """k_raycast: how many workgroups share one (env, sensor) image, with the XCD-aware workgroup mapping (csrc/agx_raycast.hip).
-AGX_RAY_SPLIT overrides the launch policy; frames must be bit-identical for every value.  The state is frozen (no env step
+agx_set_option("ray_split", n) overrides the launch policy; frames must be bit-identical for every value.  The state is frozen (no env step
 between measurements) and the candidates are timed round-robin, several rounds, so that clock drift hits all of them alike.
     python profiles/raycast_split_probe.py [depth|lidar] """
 import json
@@ -29,7 +29,9 @@ if os.environ.get("AGX_PROBE_SPLITS"):  # e.g. a build with another workgroup si
 
 
 def use(sp):
-    os.environ["AGX_RAY_SPLIT"] = str(sp)
+    from aerial_gym_simulator_amd import _lib
+
+    _lib.set_option("ray_split", sp)  # (rounds 4-5 ran this script with the AGX_RAY_SPLIT variable the library read then)
 
 
 ref, same = None, {}

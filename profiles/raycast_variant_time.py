@@ -1,5 +1,5 @@
 """Times the frame's ray-cast launch of BASELINE configs[2] / configs[3] for a list of library builds (AGX_LIB_PATH), with and
-without AGX_BVH_BOX_OBJECTS: `python profiles/raycast_variant_time.py lib1.so lib2.so ...` -> one line per (library, workload,
+without object nodes (args={"bvh_box_objects": ...}): `python profiles/raycast_variant_time.py lib1.so lib2.so ...` -> one line per (library, workload,
 box objects): launch us (best of 3 x 20 launches in the step's own state).  Each measurement is its own process."""
 import json
 import os
@@ -13,7 +13,7 @@ sys.path.insert(0, %r)
 import bench
 w = sys.argv[1]
 n = 4096 if w == "lidar" else 8192
-task = bench.make_task(w, n, "cuda:0", False)
+task = bench.make_task(w, n, "cuda:0", False, extra_args={"bvh_box_objects": sys.argv[2] == "1"})
 task.reset()
 A = task.task_config.action_space_dim
 g = torch.Generator(device="cuda:0").manual_seed(4321)
@@ -31,10 +31,10 @@ for lib in libs:
     lib, _, modes = lib.partition(":")  # "path.so:0" = triangle subtrees only (a build that does not know object nodes)
     for w in ("depth", "lidar"):
         for box in (modes or "10"):
-            env = dict(os.environ, AGX_BVH_BOX_OBJECTS=box)
+            env = dict(os.environ)
             if lib:
                 env["AGX_LIB_PATH"] = os.path.abspath(lib)
-            r = subprocess.run([sys.executable, "-c", CHILD, w], env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([sys.executable, "-c", CHILD, w, box], env=env, capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             out = json.loads(line[-1]) if line else {"error": r.stderr[-400:]}
             print(os.path.basename(lib) or "default", w, "box_objects", box, json.dumps(out), flush=True)

@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "one":
     import bench
 
     wl, n = sys.argv[2], int(sys.argv[3])
-    task = bench.make_task(wl, n, "cuda:0", False, obstacles="curriculum")
+    task = bench.make_task(wl, n, "cuda:0", False, obstacles="curriculum", extra_args={"step_graph": sys.argv[4] == "1"})
     task.reset()
     A = task.task_config.action_space_dim
     acts = [torch.rand(n, A, device="cuda:0") * 2 - 1 for _ in range(8)]
@@ -35,8 +35,7 @@ else:
     for wl in ("depth", "lidar_nav"):
         for n in (256, 512, 1024):
             for graph in ("0", "1"):
-                env = dict(os.environ, AGX_STEP_GRAPH=graph)
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", wl, str(n)], env=env, capture_output=True, text=True)
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "one", wl, str(n), graph], capture_output=True, text=True)
                 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
                 rows.append(line[-1] if line else json.dumps({"workload": wl, "num_envs": n, "graph": graph, "error": out.stderr[-400:]}))
                 print(rows[-1], flush=True)

@@ -162,6 +162,17 @@ def pytest_terminal_summary(terminalreporter):
 
 
 @pytest.fixture(autouse=True)
+def _library_options_back_to_default():
+    """tests flip the library's process-wide A/B options (agx_set_option): whatever a test leaves behind is undone"""
+    yield
+    from aerial_gym_simulator_amd import _lib
+
+    if _lib._lib is not None:
+        _lib.set_option("env_step_quad", 1)
+        _lib.set_option("ray_split", 0)
+
+
+@pytest.fixture(autouse=True)
 def _seed_everything(request):
     """Scene construction uses python `random` (asset shuffle, like the reference) and torch's global generator:
     seed them per test so a failure can be reproduced."""

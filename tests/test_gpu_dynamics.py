@@ -3,6 +3,7 @@ the same inputs, and vs the golden vectors of the reference.  Tolerance: fp32 st
 1e-5 per step (north_star); flags bit-exact."""
 import numpy as np
 import pytest
+from aerial_gym_simulator_amd import _lib as _agx_lib
 import torch
 from conftest import elem_err, err_where_reference_is_defined, golden_params, load_golden, max_abs, max_rel, rel_err
 
@@ -442,7 +443,7 @@ def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch)
     Lee velocity, control/__init__.py:94-96: two motors per lane; recorded disturbance draws included) have a
     four-lanes-per-env kernel (k_env_step_quad_position for one position-control sub-step, k_env_step_quad_loop<M, CTRL>
     otherwise): agx_env_step_kernel names it, and k sub-steps from the golden case's recorded states / actions / gains give
-    bit for bit the buffers of the one-lane kernel (AGX_ENV_STEP_QUAD=0)."""
+    bit for bit the buffers of the one-lane kernel (agx_set_option("env_step_quad", 0))."""
     import ctypes as C
 
     from gpu_harness import DynHarness
@@ -452,7 +453,7 @@ def test_four_lanes_per_env_kernels_cover_the_six_lee_laws(case, k, monkeypatch)
     n = g["state"].shape[1]
     outs = {}
     for quad in ("0", "1"):
-        monkeypatch.setenv("AGX_ENV_STEP_QUAD", quad)
+        _agx_lib.set_option("env_step_quad", int(quad))
         H = DynHarness(pd, n)
         H.set(kT=g["kT"], tau_inc=g["tau_inc"], tau_dec=g["tau_dec"])
         H.set_gains(g["Kp"], g["Kv"], g["KR"], g["Kw"])

@@ -37,7 +37,7 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
     a = StepGather(n, d, dev, backend=library_backend)
     b = StepGather(n, d, dev, backend="process_group")
     assert a.backend == library_backend and b.backend == "process_group"
-    if library_backend == "peer_push" and os.environ.get("AGX_PUSH_SELFTEST", "1") != "0":
+    if library_backend == "peer_push":
         assert a.push_selftest == "passed"  # a word and a flag went through every mapping before the first post
     assert StepGather(n, d, dev).backend == "peer_push"  # what "auto" picks on a HIP device (rccl_thread if it cannot be set up)
     g = torch.Generator(device=dev).manual_seed(3)
@@ -78,12 +78,14 @@ def test_library_exchange_matches_process_group(world_of_one, library_backend):
 
 
 def test_auto_falls_back_to_the_rccl_thread_when_peer_push_cannot_be_set_up(world_of_one, monkeypatch):
-    """A platform that refuses the peer mappings (injected: AGX_TEST_PUSH_SETUP_FAIL): every rank learns it before anything is
-    built (StepGather._agree), "auto" takes the RCCL worker thread instead, an explicit backend="peer_push" raises."""
+    """A platform that refuses the peer mappings (injected with a test double: the library object's agx_exchange_create_push is
+    replaced by a function that fails -- the product has no hook for it): every rank learns it before anything is built
+    (StepGather._agree), "auto" takes the RCCL worker thread instead, an explicit backend="peer_push" raises."""
+    from aerial_gym_simulator_amd import _lib
     from aerial_gym_simulator_amd.sharding import StepGather
 
     dev = torch.device("cuda:0")
-    monkeypatch.setenv("AGX_TEST_PUSH_SETUP_FAIL", "1")
+    monkeypatch.setattr(_lib.load(), "agx_exchange_create_push", lambda *a: 1)
     sg = StepGather(256, 13, dev)
     assert sg.backend == "rccl_thread"
     rows = torch.rand(256, 16, device=dev)

@@ -384,7 +384,7 @@ def test_replayed_step_graph_equals_eager_stepping(task_name, cfg_name):
                                                 ("lidar_navigation_task", "lidar_navigation_task_config")])
 def test_fused_robot_side_launch_equals_the_four_separate_launches(task_name, cfg_name, monkeypatch):
     """agx_nav_robot_side (robot reset + sensor mounts + target of the envs that reset + every sensor's pose, one launch) against
-    agx_reset_masked / agx_sensor_mount_reset / agx_nav_target_reset / agx_sensor_pose (AGX_FUSED_ROBOT_SIDE=0): same seed, same
+    agx_reset_masked / agx_sensor_mount_reset / agx_nav_target_reset / agx_sensor_pose (args={"fused_robot_side": False}): same seed, same
     actions -> bit-identical observations, rewards, flags, states, targets, mounts, sensor poses and images over 60 steps with
     episodes of 7 steps (resets on most steps)."""
     import aerial_gym_simulator_amd  # noqa: F401
@@ -396,10 +396,9 @@ def test_fused_robot_side_launch_equals_the_four_separate_launches(task_name, cf
     n = 40
     tasks = []
     try:
-        for fused in ("0", "1"):
-            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", fused)
+        for fused in (False, True):
             cfg.device, cfg.episode_len_steps = DEV, 7
-            cfg.args = {"rng_seed": 99}
+            cfg.args = {"rng_seed": 99, "fused_robot_side": fused}
             t = task_registry.make_task(task_name, seed=3, num_envs=n, headless=True)
             t.reset()
             tasks.append(t)
@@ -407,9 +406,7 @@ def test_fused_robot_side_launch_equals_the_four_separate_launches(task_name, cf
         g = torch.Generator(device=DEV).manual_seed(2)
         for step in range(60):
             a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
-            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", "0")
             out0 = separate.step(a)
-            monkeypatch.setenv("AGX_FUSED_ROBOT_SIDE", "1")
             out1 = fused.step(a)
             torch.cuda.synchronize()
             (o0, r0, te0, tr0, _), (o1, r1, te1, tr1, _) = out0, out1
@@ -432,7 +429,7 @@ def test_folded_step_launches_equal_the_separate_ones(n, monkeypatch):
     """round 5: the navigation step without three of its small launches -- the success / timeout / curriculum
     bookkeeping in the env-step launch's epilogue (AgxTaskArgs.successes ...) and the obstacle reset + mask compaction inside the
     geometry refresh (agx_scene_reset_refresh: ONE launch up to 2048 envs, the three launches above) -- against the separate
-    launches (AGX_FUSED_BOOKKEEPING=0, AGX_FUSED_ASSET_RESET=0): same seed, same actions -> bit-identical observations, rewards,
+    launches (args={"fused_bookkeeping": False, "fused_asset_reset": False}): same seed, same actions -> bit-identical observations, rewards,
     flags, bookkeeping, obstacle poses, triangles, trees and images, resets on most steps.  n = 2304: the large-batch form."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config import task_config as tc
@@ -442,11 +439,9 @@ def test_folded_step_launches_equal_the_separate_ones(n, monkeypatch):
     old = (cfg.episode_len_steps, cfg.args, cfg.device)
     tasks = []
     try:
-        for fused in ("0", "1"):
-            monkeypatch.setenv("AGX_FUSED_BOOKKEEPING", fused)
-            monkeypatch.setenv("AGX_FUSED_ASSET_RESET", fused)
+        for fused in (False, True):
             cfg.device, cfg.episode_len_steps = DEV, 7
-            cfg.args = {"rng_seed": 77}
+            cfg.args = {"rng_seed": 77, "fused_bookkeeping": fused, "fused_asset_reset": fused}
             t = task_registry.make_task("navigation_task", seed=3, num_envs=n, headless=True)
             t.reset()
             tasks.append(t)
@@ -456,9 +451,7 @@ def test_folded_step_launches_equal_the_separate_ones(n, monkeypatch):
         steps = 40 if n < 1000 else 12
         for step in range(steps):
             a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
-            for t, flag in ((separate, "0"), (fused, "1")):
-                monkeypatch.setenv("AGX_FUSED_BOOKKEEPING", flag)
-                monkeypatch.setenv("AGX_FUSED_ASSET_RESET", flag)
+            for t in (separate, fused):
                 t._out = t.step(a)
             torch.cuda.synchronize()
             (o0, r0, te0, tr0, i0), (o1, r1, te1, tr1, i1) = separate._out, fused._out

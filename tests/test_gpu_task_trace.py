@@ -4,6 +4,7 @@ reference reset code with the oracle's integrator in the loop (tests/golden/trac
 when it is fed the same random draws (strict_rng + replayed stream)."""
 import numpy as np
 import pytest
+from aerial_gym_simulator_amd import _lib as _agx_lib
 import torch
 from conftest import load_golden, rel_err
 
@@ -310,7 +311,7 @@ def test_four_lanes_per_env_kernel_is_bit_identical_to_the_one_lane_kernel(n, ra
     """k_env_step_quad_position (agx_quad_math.h: a 3-vector / quaternion per register, components in the lanes of a quad)
     against k_env_step<4, position>: the same IEEE operations in the same order, so every buffer the step touches is equal
     bit for bit -- over several episodes, with per-env (randomised) gains / motor constants too, and with a partial last
-    wave.  AGX_ENV_STEP_QUAD=0 selects the one-lane kernel."""
+    wave.  agx_set_option("env_step_quad", 0) selects the one-lane kernel."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
     from aerial_gym_simulator_amd.registry.task_registry import task_registry
@@ -332,9 +333,9 @@ def test_four_lanes_per_env_kernel_is_bit_identical_to_the_one_lane_kernel(n, ra
             a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
             if t % 17 == 3:
                 a = a * 30.0  # beyond the +-10 clip
-            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "0")
+            _agx_lib.set_option("env_step_quad", 0)
             one.step(a)
-            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "1")
+            _agx_lib.set_option("env_step_quad", 1)
             four.step(a)
             for k in ("robot_state_tensor", "robot_actions", "robot_prev_actions", "robot_euler_angles", "robot_body_linvel",
                       "robot_body_angvel", "robot_vehicle_orientation", "robot_vehicle_linvel"):
@@ -359,7 +360,7 @@ def test_four_lanes_per_env_kernel_is_bit_identical_to_the_one_lane_kernel(n, ra
 def test_four_lanes_per_env_substep_loop_is_bit_identical_to_the_one_lane_kernel(which, monkeypatch):
     """k_env_step_quad_loop<velocity | acceleration> (10 sub-steps, obstacles split over the lanes of the quad, device
     disturbance draws, navigation reward epilogue) against k_env_step<4, CTRL, false, true>: state, derived tensors,
-    motors, rewards, flags, position errors equal bit for bit over several episodes (AGX_ENV_STEP_QUAD=0 selects the
+    motors, rewards, flags, position errors equal bit for bit over several episodes (agx_set_option("env_step_quad", 0) selects the
     one-lane kernel)."""
     import aerial_gym_simulator_amd  # noqa: F401
     from aerial_gym_simulator_amd.config import task_config as tc
@@ -377,7 +378,7 @@ def test_four_lanes_per_env_substep_loop_is_bit_identical_to_the_one_lane_kernel
         import ctypes as C
 
         for t, want in ((one, "0"), (four, "1")):
-            monkeypatch.setenv("AGX_ENV_STEP_QUAD", want)
+            _agx_lib.set_option("env_step_quad", int(want))
             env = t.sim_env
             buf = C.create_string_buffer(128)
             env._lib.agx_env_step_kernel(env._params, env._buffers, n, env.num_physics_steps(), env.task_args, buf, 128)
@@ -387,9 +388,9 @@ def test_four_lanes_per_env_substep_loop_is_bit_identical_to_the_one_lane_kernel
         n_crash = 0
         for t in range(70):
             a = torch.rand(n, A, device=DEV, generator=g) * 2 - 1
-            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "0")
+            _agx_lib.set_option("env_step_quad", 0)
             o1 = one.step(a)
-            monkeypatch.setenv("AGX_ENV_STEP_QUAD", "1")
+            _agx_lib.set_option("env_step_quad", 1)
             four.step(a)
             n_crash += int(o1[2].sum())
             for k in ("robot_state_tensor", "robot_actions", "robot_prev_actions", "robot_euler_angles", "robot_body_linvel",

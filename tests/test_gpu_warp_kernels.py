@@ -117,9 +117,7 @@ def test_box_object_flag_on_boxes_of_another_face_order_keeps_their_triangle_sub
     not end the tree there.  No object node in the tree, and the frames stay the reference-executed golden's, bit for bit."""
     g = load("camera")
     S = _scene(g, box_objects=True)
-    NI = S.nodes.cpu().numpy().view(np.int32)
-    refs = NI[:, :, [3, 7]]
-    assert not ((refs >= 0) & ((refs & 0x40000000) != 0)).any()
+    assert object_node_count(S) == 0
     c = cfg_of(g, "depth_seg")
     px, seg = S.camera(int(c["width"]), int(c["height"]), g["depth_seg_kinv"], c["max_range"], int(g["depth_seg_cxy"][0]), int(g["depth_seg_cxy"][1]), 1,
                        g["depth_seg_sensor_position"], g["depth_seg_sensor_orientation"])
@@ -127,9 +125,23 @@ def test_box_object_flag_on_boxes_of_another_face_order_keeps_their_triangle_sub
 
 
 def object_node_count(S):
-    """object nodes referenced by the built trees (child word: bit 30 set on a non-negative reference; include/aerial_gym_hip.h)"""
-    refs = S.nodes.cpu().numpy().view(np.int32)[:, :, [3, 7]]
-    return int(((refs >= 0) & ((refs & 0x40000000) != 0)).sum())
+    """object nodes REACHED from the roots of the built trees (child reference >= 0 with AGX_BVH_OBJECT_REF, bit 30, set;
+    include/aerial_gym_hip.h).  A walk, not a scan: an object node's own record holds floats in the child slots."""
+    NI = S.nodes.cpu().numpy().view(np.int32)
+    count = 0
+    for e in range(NI.shape[0]):
+        stack = [0]
+        while stack:
+            i = stack.pop()
+            for slot in (3, 7):
+                c = int(NI[e, i, slot])
+                if c < 0:
+                    continue
+                if c & 0x40000000:
+                    count += 1
+                else:
+                    stack.append(c)
+    return count
 
 
 def box_scene_frame(S, g, tag, limits=None):
