@@ -589,6 +589,7 @@ class EnvManager(BaseManager):
     # ---- robot plug-in (robots/base_robot.py:10-63, robot_manager.py:486-489) -------------------------------------
     _robot_step_args = None
     _robot_substep = 0
+    _in_external_simulate = False
 
     def _robot_plugin_state(self):
         """per-body tensors, application mask and link-frame table of the robot plug-in path (built on first use)"""
@@ -606,13 +607,27 @@ class EnvManager(BaseManager):
             self._link_frames, known = link_frames(robot.cfg, int(F.shape[1]))
             self._unknown_bodies = [b for b, k in enumerate(known) if not k]
             self._net_wrench = torch.zeros(self.num_envs, 6, dtype=torch.float32, device=self.device)
-            # the integrating launch takes the wrench as it is: same constants, controller id "wrench"
-            import copy
-
-            self._params_body_wrench = copy.copy(self._params)
-            self._params_body_wrench.controller = _lib.CTRL_IDS["wrench"]
-            self._unknown_checked = False
+            # a wrench on a body whose pose the robot_model table does not know cannot be placed: every sub-step ORs "such a body
+            # carries a wrench" into this device flag (no synchronisation), read on the first step and every 32nd after it
+            self._unknown_wrench = torch.zeros((), dtype=torch.bool, device=self.device)
+            self._unknown_steps = 0
         return self._robot_step_args
+
+    def _body_wrench_params(self):
+        """the integrating launch of the plug-in path takes the net wrench as it is: the robot's CURRENT constants (robot.params
+        may have been edited since the last step), controller id 'wrench'"""
+        import copy
+
+        P = copy.copy(self._params)
+        P.controller = _lib.CTRL_IDS["wrench"]
+        return P
+
+    def _check_unknown_bodies(self, force=False):
+        self._unknown_steps += 1
+        if self._unknown_bodies and (force or self._unknown_steps == 1 or self._unknown_steps % 32 == 0) and bool(self._unknown_wrench):
+            raise NotImplementedError(
+                f"robot.step() wrote a wrench on bodies {self._unknown_bodies}, whose poses the config's robot_model does not "
+                "give: add them as robot_model.link_xyz / link_rpy = {body index: [x, y, z] / [r, p, y]}")
 
     def robot_step(self, action):
         """BaseMultirotor.step(action) of the reference (base_multirotor.py:296-307) as one launch, agx_robot_step: derived
@@ -627,6 +642,8 @@ class EnvManager(BaseManager):
             a = a.to(dtype=torch.float32).contiguous()
         if a.shape != (self.num_envs, self.num_robot_actions):
             raise ValueError("Action tensor does not have the correct number of environments")
+        if not self._in_external_simulate:  # BaseMultirotor.step called by hand: a call of its own (stream lookup, derived tensors)
+            self._new_call()
         R = self._robot_plugin_state()
         R.substep = int(self._robot_substep)
         _lib.check(self._lib.agx_robot_step(self._params, self._buffers, self.num_envs, _lib.dptr(a), _lib.C.byref(R), self._stream()),
@@ -644,6 +661,8 @@ class EnvManager(BaseManager):
         g, B, robot = self.global_tensor_dict, self._buffers, self.robot_manager.robot
         self._robot_plugin_state()
         F, T = g["robot_force_tensor"], g["robot_torque_tensor"]
+        P_wrench = self._body_wrench_params()
+        self._in_external_simulate = True
         try:
             for sub in range(max(k, 1)):
                 B.launch_flags = (1 if sub > 0 else 0) | (2 if sub < k - 1 else 0) | _lib.LAUNCH_BODY_WRENCH | (sub << 8)
@@ -652,22 +671,19 @@ class EnvManager(BaseManager):
                     g["robot_actions"][:] = a
                     self._robot_substep = sub
                     robot.step(g["robot_actions"])
-                    if not self._unknown_checked and self._unknown_bodies:
-                        # once: a wrench on a body whose pose the robot_model table does not know cannot be placed
-                        self._unknown_checked = True
-                        if bool((F[:, self._unknown_bodies] != 0).any()) or bool((T[:, self._unknown_bodies] != 0).any()):
-                            raise NotImplementedError(
-                                f"robot.step() wrote a wrench on bodies {self._unknown_bodies}, whose poses the config's robot_model does not "
-                                "give: add them as robot_model.link_xyz / link_rpy = {body index: [x, y, z] / [r, p, y]}")
+                    if self._unknown_bodies:
+                        self._unknown_wrench |= (F[:, self._unknown_bodies] != 0).any() | (T[:, self._unknown_bodies] != 0).any()
                     _lib.check(self._lib.agx_net_body_wrench(self.num_envs, _lib.C.byref(self._link_frames), _lib.dptr(F), _lib.dptr(T),
                                                              _lib.dptr(self._net_wrench), self._stream()), "agx_net_body_wrench")
                 else:
                     self._net_wrench.zero_()
-                _lib.check(self._lib.agx_env_step(self._params_body_wrench, B, self.num_envs, _lib.dptr(self._net_wrench), min(k, 1),
+                _lib.check(self._lib.agx_env_step(P_wrench, B, self.num_envs, _lib.dptr(self._net_wrench), min(k, 1),
                                                   self.task_args, self._stream()), "agx_env_step")
+            self._check_unknown_bodies()
         finally:
             B.launch_flags = 0
             self._robot_substep = 0
+            self._in_external_simulate = False
 
     @roctx.ranged("EnvManager.step")
     def step(self, actions, env_actions=None):

@@ -122,6 +122,8 @@ class SceneManager:
         sizes = list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
         return [[Prim("box", tuple(float(v) for v in sz), np.eye(4), "base_link", 0)] for sz in sizes]
 
+    MAX_TRIS_PER_ENV = 2944  # csrc/agx_scene.hip kBvhMaxTris (agx_bvh_build refuses more by message; this names the assets)
+
     def _init_general(self, slots, variants, nk, nf, N, scene_seed_base, env_offset):
         """Scenes with multi-primitive assets (several links, cylinders): every primitive is its own rigid piece
         (own triangles in its own frame, own collision box) tied to its asset by agx_prims_from_assets.  The
@@ -139,6 +141,12 @@ class SceneManager:
         tri_count = np.array([t for ts in tri_s for t in ts], int)
         tri_base = np.concatenate([[0], np.cumsum(tri_count)]).astype(int)
         T = self.num_tris = int(tri_base[-1])
+        if T > self.MAX_TRIS_PER_ENV:
+            per_slot = sorted(((sum(ts), getattr(slots[s], "__name__", type(slots[s]).__name__)) for s, ts in enumerate(tri_s)), reverse=True)[:5]
+            raise ValueError(
+                f"scene of {T} triangles per env exceeds the {self.MAX_TRIS_PER_ENV} the LDS-resident tree build takes "
+                f"(csrc/agx_scene.hip kBvhMaxTris); largest assets (triangles, type): {per_slot}.  A URDF sphere is 1280 triangles "
+                "(trimesh icosphere, 3 subdivisions) and a cylinder 128 (32 sections): use fewer of them, or box primitives")
         ids_per_slot = np.array([max(len(v) for v in vs) if getattr(t, "per_link_semantic", False) and t.semantic_id < 0 else 1
                                  for t, vs in zip(slots, variants)])
         semantic_offset = self.semantic_offset = env_offset * int(ids_per_slot.sum())

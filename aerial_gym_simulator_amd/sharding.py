@@ -278,6 +278,10 @@ class StepGather:
                 torch.cuda.synchronize(self.device)
                 self._env.unbind_peer_push()
                 self._kernel_push = False
+            if self.signal is not None and self._env is not None:
+                # an env that keeps stepping after its exchange was dropped must not keep signalling the parked handle every step
+                self._env.bind_step_rows(self.rows, self._env._step_rows[1], None)
+                self.signal = None
             self.gathered, self._push_mem = None, None
             _PARKED.append((self._lib, h))  # a peer's store_peer / store_peer4 may still be in flight: never unmapped from here
             return

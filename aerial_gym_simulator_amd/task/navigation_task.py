@@ -112,7 +112,9 @@ class NavigationTask(BaseTask):
         # agx_nav_bookkeeping on the launch's registers: one dispatch fewer per step).  args={"fused_bookkeeping": False}: the launch of its own.
         self._bookkeeping_fused = not env.strict_rng and bool(self._arg("fused_bookkeeping", True))
         if self._bookkeeping_fused:
-            T.successes, T.timeouts, T.counters = _lib.dptr(self._successes), _lib.dptr(self._timeouts), _lib.dptr(self._counters)
+            # (the pointers are handed over only around THIS task's own env.step, _device_step: an env.step() a caller issues on
+            # task.sim_env by hand must not move the curriculum counters -- they moved only in _bookkeeping_device before round 5)
+            self._bookkeeping_ptrs = (_lib.dptr(self._successes), _lib.dptr(self._timeouts), _lib.dptr(self._counters))
             T.success_radius = 1.0
         env.task_args = T
 
@@ -183,7 +185,7 @@ class NavigationTask(BaseTask):
             self.check_and_update_curriculum_level(successes, crashed, timeouts)
             return
         p = _lib.dptr
-        if not (getattr(self, "_bookkeeping_fused", False) and env.task_args is not None and env.task_args.successes):
+        if not (getattr(self, "_bookkeeping_fused", False) and env.task_args is not None):
             _lib.check(env._lib.agx_nav_bookkeeping(env._buffers, env.num_envs, p(self.target_soa), 1.0, p(self._successes),
                                                     p(self._timeouts), p(self._counters), env._stream()), "agx_nav_bookkeeping")
         self.infos["successes"], self.infos["timeouts"], self.infos["crashes"] = self._successes, self._timeouts, self.terminations
@@ -303,7 +305,15 @@ class NavigationTask(BaseTask):
         if env.task_args is not None:
             env.task_args.curriculum_progress = float(self.curriculum_progress_fraction)
             env.task_args.episode_len = int(self.task_config.episode_len_steps)
-        env.step(actions=transformed_action)
+        T = env.task_args
+        fused = self._bookkeeping_fused and T is not None
+        if fused:
+            T.successes, T.timeouts, T.counters = self._bookkeeping_ptrs
+        try:
+            env.step(actions=transformed_action)
+        finally:
+            if fused:
+                T.successes = T.timeouts = T.counters = None
         self.compute_rewards_and_crashes(self.obs_dict)
         if self.task_config.return_state_before_reset:
             return_tuple = self.get_return_tuple()
