@@ -16,7 +16,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaerialgym_hip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 
-SOURCES = ["agx_api.cpp", "agx_math_eval.hip", "agx_dynamics.hip", "agx_scene.hip", "agx_raycast.hip", "agx_lidar_nav.hip", "agx_imu.hip", "agx_task_glue.hip", "agx_exchange.hip"]
+SOURCES = ["agx_api.cpp", "agx_math_eval.hip", "agx_dynamics.hip", "agx_scene.hip", "agx_raycast.hip", "agx_lidar_nav.hip", "agx_imu.hip", "agx_task_glue.hip", "agx_exchange.hip", "agx_strict.hip"]
 # -ffp-contract=off: every + - * / sqrt is one IEEE operation (bit-exact predicates, see
 # DESIGN.md "numerics"); correctly rounded fp32 divide / sqrt is hipcc's default.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

@@ -230,6 +230,15 @@ class AgxPositionStepPlan(C.Structure):
     ]
 
 
+MAX_UNIFORM_SEGMENTS = 8
+
+
+class AgxStrictStepPlan(C.Structure):
+    _fields_ = [("plan", C.POINTER(AgxPositionStepPlan)), ("host_word", C.POINTER(C.c_uint32)), ("count", C.c_int32), ("timeout_ms", C.c_int32),
+                ("out", C.c_void_p * MAX_UNIFORM_SEGMENTS), ("numel", C.c_int64 * MAX_UNIFORM_SEGMENTS), ("seed", C.c_uint64),
+                ("offset", C.c_uint64), ("sm_count", C.c_int32), ("max_threads_per_sm", C.c_int32)]
+
+
 class AgxRobotStepArgs(C.Structure):
     _fields_ = [("force", C.c_void_p), ("torque", C.c_void_p), ("num_bodies", C.c_int32), ("substep", C.c_int32),
                 ("body_of_motor", C.c_int32 * MAX_MOTORS)]
@@ -272,6 +281,11 @@ _SIGNATURES = {
                                      C.POINTER(AgxNavRobotSideArgs), _P]),
     "agx_post_step_position": (C.c_int, [C.POINTER(AgxRobotParams), C.POINTER(AgxEnvBuffers), C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P]),
     "agx_position_task_step": (C.c_int, [C.POINTER(AgxPositionStepPlan), _P, _P]),
+    "agx_torch_uniform_fill": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint64), _P]),
+    "agx_host_word_create": (C.c_int, [C.POINTER(C.POINTER(C.c_uint32))]),
+    "agx_host_word_destroy": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "agx_position_task_step_strict": (C.c_int, [C.POINTER(AgxStrictStepPlan), _P, C.POINTER(C.c_int), C.POINTER(C.c_uint64), _P]),
     "agx_reset_assets": (C.c_int, [C.POINTER(AgxEnvBuffers), C.c_int, C.c_int, C.POINTER(AgxResetArgs), _P, _P, _P, _P, _P, C.c_int,
                                    C.c_int, _P, _P]),
     "agx_scene_transform": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),

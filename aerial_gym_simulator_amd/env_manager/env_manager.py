@@ -413,6 +413,54 @@ class EnvManager(BaseManager):
             rs.rand_into(u["kT"], tag="kT")
         self.robot_manager.draw_sensor_reset_randoms(env_ids)
 
+    def strict_draw_plan(self):
+        """Strict mode, plain case (no obstacles, sensors, per-env gains; the default torch generator): the tensors the per-step
+        reset draws, in the reference's call order (_draw_reset_randoms above), for ONE fused launch that reproduces those
+        `uniform_` calls (agx_torch_uniform_fill) -- or None where the calls must go through torch (a caller's random source /
+        generator, draws shaped by the reset set, or a torch whose kernels the restatement does not match: checked here, once,
+        against the real calls on a saved-and-restored generator state)."""
+        rs = self.random_source
+        sensor = self.robot_manager.warp_sensor
+        if (not self.strict_rng or type(rs) is not TorchRandomSource or rs.generator is not None or self._randomize_gains
+                or self.scene.num_assets > 0 or sensor is not None or self.robot_manager.imu_sensor is not None
+                or self.robot_manager.robot.cfg.disturbance.enable_disturbance):
+            return None
+        names = ["bounds_lo", "bounds_hi", "state", "tau_inc", "tau_dec", "thrust"]
+        if self.robot_manager.robot.cfg.control_allocator_config.motor_model_config.use_rps:
+            names.append("kT")
+        bufs = [self._u[k] for k in names]
+        index = torch.device(self.device).index
+        index = index if index is not None else torch.cuda.current_device()
+        gen = torch.cuda.default_generators[index]
+        props = torch.cuda.get_device_properties(index)
+        plan = {"tensors": bufs, "generator": gen, "sm_count": int(props.multi_processor_count),
+                "max_threads_per_sm": int(props.max_threads_per_multi_processor)}
+        # self-check: the fused launch against the dispatcher calls it stands for, on this torch, this device, these shapes
+        state = gen.get_state()
+        try:
+            seed, off = gen.initial_seed(), gen.get_offset()
+            real = []
+            for b in bufs:
+                real.append(torch.empty_like(b).uniform_(0.0, 1.0))
+            off_real = gen.get_offset()
+            mine = [torch.full_like(b, -1.0) for b in bufs]
+            C = _lib.C
+            outs = (C.c_void_p * len(bufs))(*[m.data_ptr() for m in mine])
+            numel = (C.c_int64 * len(bufs))(*[m.numel() for m in mine])
+            after = C.c_uint64(0)
+            _lib.check(self._lib.agx_torch_uniform_fill(len(bufs), outs, numel, seed & 0xFFFFFFFFFFFFFFFF, off, plan["sm_count"],
+                                                        plan["max_threads_per_sm"], C.byref(after), self._stream()), "agx_torch_uniform_fill")
+            ok = after.value == off_real and all(torch.equal(a, b) for a, b in zip(real, mine))
+        finally:
+            gen.set_state(state)
+        if not ok:
+            import warnings
+
+            warnings.warn("agx_torch_uniform_fill does not reproduce this torch build's uniform_ kernel: the strict step draws through "
+                          "torch's dispatcher (slower, same numbers)")
+            return None
+        return plan
+
     # A navigation task may hand over what follows the robot reset on the robot side of its step -- sensor mounts and target of
     # the envs that reset, the world pose of every sensor -- to run in the SAME launch (agx_nav_robot_side: one launch instead
     # of four dependent ones).  Only the per-step reset of task.step() takes it; an explicit reset_idx() stays as it was.

@@ -72,16 +72,16 @@ class PositionSetpointTask(BaseTask):
         T.reward = _lib.dptr(self.rewards)
         env.task_args = T
         env.post_obs = (_lib.dptr(self.target_soa), _lib.dptr(self.task_obs["observations"]))
-        self._plan = None
+        self._plan = self._strict = None
         e = env.cfg.env
-        simple = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and env.robot_manager.imu_sensor is None
-                  and not env.strict_rng
+        plain = (env.scene.num_assets == 0 and env.robot_manager.warp_sensor is None and env.robot_manager.imu_sensor is None
                   # host-evaluated controller / robot classes run between launches: the general path dispatches them
                   and not getattr(env.robot_manager.robot, "external_controller", False)
                   and not getattr(env.robot_manager.robot, "external_robot", False)
                   and not env.robot_manager.robot.cfg.disturbance.enable_disturbance
                   and e.num_physics_steps_per_env_step_std == 0 and not self.task_config.return_state_before_reset)
-        if simple:
+        draws = env.strict_draw_plan() if (plain and env.strict_rng) else None
+        if plain and (not env.strict_rng or draws is not None):
             # whole task.step() = one host call launching two kernels (agx_position_task_step)
             import ctypes as C
 
@@ -99,8 +99,44 @@ class PositionSetpointTask(BaseTask):
             self.task_obs["rewards"] = self.rewards
             self.task_obs["terminations"] = self.terminations
             self.task_obs["truncations"] = self.truncations
+            if env.strict_rng:
+                # reference-faithful RNG consumption, one host call per step: the two launches above with, between them, the
+                # reset flag published into a mapped host word the call spins on (no stream synchronisation) and -- only on a
+                # step with resets, like the reference's `if len(env_ids) > 0` -- the reset's seven rand_like draws as one launch
+                # that reproduces torch's own numbers (csrc/agx_strict.hip); the generator's offset is moved by what they consume
+                sp = _lib.AgxStrictStepPlan()
+                if getattr(self, "_strict_word", None) is not None:  # (fused again after a re-bind)
+                    env._lib.agx_host_word_destroy(self._strict_word)
+                word = C.POINTER(C.c_uint32)()
+                _lib.check(env._lib.agx_host_word_create(C.byref(word)), "agx_host_word_create")
+                self._strict_word = word
+                sp.plan, sp.host_word = C.pointer(plan), word
+                sp.count = len(draws["tensors"])
+                for j, t in enumerate(draws["tensors"]):
+                    sp.out[j], sp.numel[j] = t.data_ptr(), t.numel()
+                sp.sm_count, sp.max_threads_per_sm = draws["sm_count"], draws["max_threads_per_sm"]
+                self._strict = sp
+                self._strict_ref = C.byref(sp)
+                self._strict_gen = draws["generator"]
+                self._strict_drew, self._strict_after = C.c_int(0), C.c_uint64(0)
+                self._strict_out = (C.byref(self._strict_drew), C.byref(self._strict_after))
+                self._strict_fn = env._lib.agx_position_task_step_strict
+                self._plan_fn = self._strict_step
+
+    def _strict_step(self, plan_ref, actions_ptr, stream):
+        """agx_position_task_step in the strict mode (same signature): generator state in, offset out"""
+        sp, gen = self._strict, self._strict_gen
+        self.sim_env.num_physics_steps()  # (the reference draws random.gauss(mean, std) every step, std = 0 included: same consumption)
+        sp.seed, sp.offset = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, gen.get_offset()
+        rc = self._strict_fn(self._strict_ref, actions_ptr, self._strict_out[0], self._strict_out[1], stream)
+        if rc == 0 and self._strict_drew.value:
+            gen.set_offset(self._strict_after.value)
+        return rc
 
     def close(self):
+        if getattr(self, "_strict_word", None) is not None:
+            self.sim_env._lib.agx_host_word_destroy(self._strict_word)
+            self._strict_word = None
         self.sim_env.delete_env()
 
     def reset(self):

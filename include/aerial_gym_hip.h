@@ -530,6 +530,41 @@ typedef struct AgxPositionStepPlan {
 } AgxPositionStepPlan;
 int agx_position_task_step(const AgxPositionStepPlan *plan, const float *actions_in, void *stream);
 
+/* ---- the same step in the reference-faithful RNG mode (args={"strict_rng": True}) -------------------------------------
+ * The reference consumes torch's generator only on steps on which some env resets (`if len(env_ids) > 0` behind a
+ * nonzero(): env_manager.py:364-375), with one rand_like per reset quantity (IGE_env_manager.py:513-519,
+ * base_multirotor.py:177-205, motor_model.py:140-154).  Keeping that contract costs the host one bit per step.
+ *
+ * agx_torch_uniform_fill: the numbers `Tensor.uniform_(0, 1)` produces for `count` dense float32 tensors called one after
+ * another on a device generator whose state is (seed, offset) -- torch 2.10 / ROCm 7: ATen/native/cuda/DistributionTemplates.h
+ * (launch policy, thread -> element mapping, bound reversal) over rocrand's Philox4x32-10 (csrc/agx_strict.hip cites the
+ * lines) -- in ONE launch.  sm_count / max_threads_per_sm: the device properties torch's launch policy reads
+ * (multiProcessorCount, maxThreadsPerMultiProcessor).  *offset_after = the generator offset after those calls
+ * (Generator.set_offset).  Pinned bit for bit against the real calls by tests/test_gpu_strict_fast.py.
+ *
+ * agx_host_word_create: one 32-bit word of mapped, coherent host memory (hipHostMalloc) that kernels store to and the host
+ * polls; agx_position_task_step_strict: agx_position_task_step with, between its two launches, a one-lane kernel that
+ * publishes (sequence << 1 | reset_flag[parity]) into that word, a host spin until it arrives (no stream synchronisation),
+ * and -- only when the flag is set -- the uniform fill of the reset's draw tensors (plan->reset->u_*).  *drew = the flag;
+ * *offset_after = the generator offset the caller must set (unchanged when nothing was drawn).                              */
+#define AGX_MAX_UNIFORM_SEGMENTS 8
+int agx_torch_uniform_fill(int count, float *const *out, const int64_t *numel, uint64_t seed, uint64_t offset, int sm_count,
+                           int max_threads_per_sm, uint64_t *offset_after, void *stream);
+int agx_host_word_create(uint32_t **word);
+int agx_host_word_destroy(uint32_t *word);
+typedef struct AgxStrictStepPlan {
+  const AgxPositionStepPlan *plan;
+  uint32_t *host_word;                       /* agx_host_word_create */
+  int32_t count;                             /* draw tensors, in the reference's call order */
+  int32_t timeout_ms;                        /* 0: 10 s */
+  float *out[AGX_MAX_UNIFORM_SEGMENTS];
+  int64_t numel[AGX_MAX_UNIFORM_SEGMENTS];
+  uint64_t seed, offset;                     /* the generator's state before this step (Generator.initial_seed / get_offset) */
+  int32_t sm_count, max_threads_per_sm;
+} AgxStrictStepPlan;
+int agx_position_task_step_strict(const AgxStrictStepPlan *plan, const float *actions_in, int *drew, uint64_t *offset_after,
+                                  void *stream);
+
 /* Obstacle pose randomisation of the reset envs: AssetManager.reset_idx
  * (asset_manager.py:51-71) incl. the half-obstacle resample of env_manager.py:283-295.
  * u1/u2 [N][K][13] and u_sel [N] are the uniform draws (first / second rand_like and the

@@ -43,14 +43,14 @@ def test_struct_layouts_match_header():
     """sizeof of the ctypes mirrors == sizeof in C (compiled with gcc from the header)."""
     from aerial_gym_simulator_amd import _lib
 
-    src = '#include <stdio.h>\n#include "aerial_gym_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(AgxRobotParams), sizeof(AgxEnvBuffers), sizeof(AgxResetArgs));printf("%zu %zu %zu %zu\\n", sizeof(AgxTaskArgs), sizeof(AgxRangeLimits), sizeof(AgxPositionStepPlan), sizeof(AgxImuArgs));printf("%zu %zu %zu\\n", sizeof(AgxNavRobotSideArgs), sizeof(AgxRobotStepArgs), sizeof(AgxLinkFrames));return 0;}'
+    src = '#include <stdio.h>\n#include "aerial_gym_hip.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(AgxRobotParams), sizeof(AgxEnvBuffers), sizeof(AgxResetArgs));printf("%zu %zu %zu %zu\\n", sizeof(AgxTaskArgs), sizeof(AgxRangeLimits), sizeof(AgxPositionStepPlan), sizeof(AgxImuArgs));printf("%zu %zu %zu\\n", sizeof(AgxNavRobotSideArgs), sizeof(AgxRobotStepArgs), sizeof(AgxLinkFrames));printf("%zu\\n", sizeof(AgxStrictStepPlan));return 0;}'
     exe = "/tmp/agx_sizeof"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
     sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_lib.AgxRobotParams), ctypes.sizeof(_lib.AgxEnvBuffers), ctypes.sizeof(_lib.AgxResetArgs),
                      ctypes.sizeof(_lib.AgxTaskArgs), ctypes.sizeof(_lib.AgxRangeLimits), ctypes.sizeof(_lib.AgxPositionStepPlan),
                      ctypes.sizeof(_lib.AgxImuArgs), ctypes.sizeof(_lib.AgxNavRobotSideArgs), ctypes.sizeof(_lib.AgxRobotStepArgs),
-                     ctypes.sizeof(_lib.AgxLinkFrames)]
+                     ctypes.sizeof(_lib.AgxLinkFrames), ctypes.sizeof(_lib.AgxStrictStepPlan)]
 
 
 def test_product_never_touches_the_oracle():
