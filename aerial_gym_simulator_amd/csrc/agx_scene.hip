@@ -74,6 +74,14 @@ AGX_DEV void box_from_asset(int env, int k, int n, int na, const float *__restri
 
 // ------------------------------------------------------------------------------------ LBVH
 constexpr float kBvhLargeFraction = 0.75f;
+#ifdef AGX_SCENE_PHASE_CLOCK  // profiles/scene_phase_probe_r06.py: where a dirty env's refresh spends its time (100 MHz wall clock)
+__device__ unsigned long long g_phase_clock[16];
+#define AGX_PHASE(k) do { if (threadIdx.x == 0) g_phase_clock[k] = wall_clock64(); } while (0)
+#define AGX_PHASE_LAST(k) do { if (threadIdx.x == kBvhThreads - 1) g_phase_clock[k] = wall_clock64(); } while (0)
+#else
+#define AGX_PHASE(k) do { } while (0)
+#define AGX_PHASE_LAST(k) do { } while (0)
+#endif
 #ifdef AGX_BVH_EXPERIMENT  // profiles/bvh_sah_experiment.py: object sort codes supplied by the host
 __device__ const uint32_t *g_obj_codes = nullptr;
 #endif
@@ -263,6 +271,282 @@ AGX_DEV void box_object_record(const float *__restrict__ tris, int obj, float *r
   rec[12] = F.cen.x; rec[13] = F.cen.y; rec[14] = F.cen.z; rec[15] = __int_as_float(obj * 12);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// OBJECT-LEVEL BUILD (round 6).  With AGX_BVH_BOX_OBJECTS only 2K - 1 records of the triangle-level tree are ever reached on a box
+// scene (K - 1 internal nodes over the objects, K object nodes) -- yet it Morton-sorted all 12 K triangles and built 12 K - 1 nodes
+// through ~25 workgroup barriers (55-60 us for ONE env).  Here the tree is built over the K OBJECTS:
+//   phase 1 (all waves)   per (object, face): the bounds of the face's two triangles -> LDS, and whether they are where
+//                         trimesh.creation.box has them in the object's box (box_frame / box_triangle_ok, the same verdicts as the
+//                         triangle-level build's three steps)
+//   -- one workgroup barrier --
+//   phase 2 (waves 0-3)   a lane per object: AABB, sort centre, Morton code (the triangle-level build's object key, bit for bit); rank
+//                         sort of the K keys; Karras radix tree over them; boxes bottom-up; the K - 1 internal records with both child
+//                         boxes inline.  Five workgroup barriers (one wave doing all of it needs none but runs every dependent LDS
+//                         round trip of two objects in sequence: 15 us against 8, profiles/r06_scene_refresh_phases.txt).
+//   phase 3 (waves 4-7)   per object, concurrently: its OBJECT NODE record (a recognised box), or -- parked beyond the curriculum level
+//                         at -1000 m where float32 no longer resolves a box, or simply not a box -- a fixed five-node subtree over its
+//                         six triangle pairs (two-triangle leaves), so that every triangle stays reachable.
+// Record layout: internal node i of the object tree at index i (root 0); object o owns indices K - 1 + 5 o .. + 4: its object record
+// at the first, or its subtree (root at the fifth).  2 <= K <= 256.  The tree is a pure accelerator (closest hit over ALL triangles,
+// ties by index): frames are bit-identical whatever tree is built, which is what the test suites hold.
+constexpr int kObjMax = 256;
+__host__ __device__ constexpr int obj_lds_bytes_c(int nt) { return kObjMax * (8 + 8 + 24 + 24 + 8 + 8 + 4 + 8 + 4 + 1 + 6) + (nt / 2) * 24 + 64; }
+
+AGX_DEV void obj_leaf_pair_box(const float *__restrict__ tb, int fa, int fb, float (&o)[6]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[c] = fminf(tb[6 * fa + c], tb[6 * fb + c]) - kBoxEps;
+    o[3 + c] = fmaxf(tb[6 * fa + 3 + c], tb[6 * fb + 3 + c]) + kBoxEps;
+  }
+}
+AGX_DEV void obj_store_node(float *__restrict__ o, const float (&a)[6], const float (&b)[6], int rl, int rr, int sl, int sr) {
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(rl);
+  o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(rr);
+  o[8] = b[0]; o[9] = b[1]; o[10] = b[2]; o[11] = __int_as_float(sl);
+  o[12] = b[3]; o[13] = b[4]; o[14] = b[5]; o[15] = __int_as_float(sr);
+}
+AGX_DEV void box_union(const float (&a)[6], const float (&b)[6], float (&o)[6]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { o[c] = fminf(a[c], b[c]); o[3 + c] = fmaxf(a[3 + c], b[3 + c]); }
+}
+
+// the six faces of trimesh's box by triangle pair: -x (0, 2)  +x (10, 11)  -y (1, 5)  +y (7, 9)  -z (3, 8)  +z (4, 6)
+AGX_DEV constexpr int pair_a(int fc) { return (int)((0x4371A0u >> (4 * fc)) & 15u); }  // nibble fc of 0x4371A0 / 0x6895B2 (the ray-cast kernel's face table)
+AGX_DEV constexpr int pair_b(int fc) { return (int)((0x6895B2u >> (4 * fc)) & 15u); }
+
+AGX_DEV void bvh_build_objects_env(int env, int nt, const float *__restrict__ tri_world, float *__restrict__ nodes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int K = nt / 12, tid = threadIdx.x, lane = tid & 63;
+  unsigned long long *okey = reinterpret_cast<unsigned long long *>(smem);              // [kObjMax] code . object
+  unsigned long long *skey = okey + kObjMax;                                            // [kObjMax] the same, sorted
+  float *oaabb = reinterpret_cast<float *>(skey + kObjMax);                             // [kObjMax][6] object AABBs
+  float *nbox = oaabb + kObjMax * 6;                                                    // [kObjMax][6] internal nodes' boxes
+  int *parent = reinterpret_cast<int *>(nbox + kObjMax * 6);                            // [2 kObjMax] internal i at i, sorted leaf p at K - 1 + p
+  int *child = parent + 2 * kObjMax;                                                    // [kObjMax][2] (a leaf child c is K - 1 + p)
+  int *counter = child + 2 * kObjMax;                                                   // [kObjMax]
+  int *boxoff = counter + kObjMax;                                                      // [kObjMax][2]
+  float *red = reinterpret_cast<float *>(boxoff + 2 * kObjMax);                         // [4][6] the waves' bounds of the sort centres (+ pad)
+  uint8_t *objok = reinterpret_cast<uint8_t *>(red + kObjMax);                          // [kObjMax] a recognised box
+  uint8_t *fok = objok + kObjMax;                                                       // [6 kObjMax] this face's two triangles are where the box has them
+  float *pb = reinterpret_cast<float *>(fok + 6 * kObjMax);                             // [6 K][6] bounds of the face pairs
+  const float *tris = tri_world + (size_t)env * nt * 9;
+  float *out = nodes + (size_t)env * (nt - 1) * 16;
+
+  // ---- phase 1: a thread per (object, face): the two triangles trimesh.creation.box puts on that face
+  for (int t = tid; t < 6 * K; t += kBvhThreads) {
+    const int obj = t / 6, fc = t - obj * 6;
+    const int qa = (int)((0x4371A0u >> (4 * fc)) & 15u), qb = (int)((0x6895B2u >> (4 * fc)) & 15u);  // kPairA / kPairB as nibbles
+    const float *to = tris + (size_t)obj * 12 * 9;
+    float a[9], b[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a[k] = to[9 * qa + k]; b[k] = to[9 * qb + k]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pb[6 * t + c] = fminf(fminf(fminf(a[c], a[3 + c]), a[6 + c]), fminf(fminf(b[c], b[3 + c]), b[6 + c]));
+      pb[6 * t + 3 + c] = fmaxf(fmaxf(fmaxf(a[c], a[3 + c]), a[6 + c]), fmaxf(fmaxf(b[c], b[3 + c]), b[6 + c]));
+    }
+    bool ok = !tri_parked(to);
+    if (ok) {
+      BoxFrame F;
+      uint32_t ids = 0u, ids2 = 0u;
+      ok = box_frame(to, F) && box_triangle_ok(F, a, qa, ids) && box_triangle_ok(F, b, qb, ids2) && __popc(ids | ids2) == 4;
+    }
+    fok[t] = (ok ? 1 : 0) | (tri_parked(to) ? 2 : 0);  // (face 0 holds triangle 0, whose first vertex decides "parked")
+  }
+  __syncthreads();
+  AGX_PHASE(4);
+
+  constexpr int kTreeThreads = kObjMax;  // waves 0-3: one object / sorted position / tree node per lane; waves 4-7: phase 3
+  if (tid >= kTreeThreads) {
+    // ---- phase 3 (waves 4-7): the records the objects own
+    for (int o = tid - kTreeThreads; o < K; o += kBvhThreads - kTreeThreads) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) ok = ok && (fok[6 * o + j] & 1) != 0;
+      const int base = K - 1 + 5 * o, g0 = 12 * o;
+      float *rec = out + (size_t)base * 16;
+      if (ok) {
+        box_object_record(tris, o, rec);
+        continue;
+      }
+      // six two-triangle leaves (the face pairs of trimesh's box; for anything else just six pairs), five nodes over them
+      float p[6][6], a[6], b[6], c2[6], d[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[j][c] = pb[6 * (6 * o + j) + c] - kBoxEps; p[j][3 + c] = pb[6 * (6 * o + j) + 3 + c] + kBoxEps; }
+      obj_store_node(rec, p[0], p[1], ~(g0 + pair_a(0)), ~(g0 + pair_a(1)), g0 + pair_b(0), g0 + pair_b(1));
+      obj_store_node(rec + 16, p[2], p[3], ~(g0 + pair_a(2)), ~(g0 + pair_a(3)), g0 + pair_b(2), g0 + pair_b(3));
+      obj_store_node(rec + 32, p[4], p[5], ~(g0 + pair_a(4)), ~(g0 + pair_a(5)), g0 + pair_b(4), g0 + pair_b(5));
+      box_union(p[0], p[1], a);
+      box_union(p[2], p[3], b);
+      obj_store_node(rec + 48, a, b, base + 0, base + 1, -1, -1);
+      box_union(a, b, d);
+      box_union(p[4], p[5], c2);
+      obj_store_node(rec + 64, d, c2, base + 3, base + 2, -1, -1);
+    }
+    AGX_PHASE_LAST(8);
+  }
+
+  // ---- phase 2 (waves 0-3, lane = object, then sorted position, then node): the tree over the objects.  Every wave of the
+  // workgroup takes part in the five barriers between its steps.
+  const int o = tid;
+  const bool has_obj = tid < K;
+  float cen[3] = {0.0f, 0.0f, 0.0f}, big = -1.0f;
+  {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (has_obj) {
+      float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        ok = ok && (fok[6 * o + j] & 1) != 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          alo[c] = fminf(alo[c], pb[6 * (6 * o + j) + c]);
+          ahi[c] = fmaxf(ahi[c], pb[6 * (6 * o + j) + 3 + c]);
+        }
+      }
+      objok[o] = ok ? 1 : 0;
+      const bool parked = (fok[6 * o] & 2) != 0;
+      float bg = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        oaabb[6 * o + c] = alo[c] - kBoxEps;      // (grown once, here: every box above is a union of these)
+        oaabb[6 * o + 3 + c] = ahi[c] + kBoxEps;
+        cen[c] = 0.5f * (alo[c] + ahi[c]);
+        bg = fmaxf(bg, ahi[c] - alo[c]);
+        if (!parked) { lo[c] = fminf(lo[c], cen[c]); hi[c] = fmaxf(hi[c], cen[c]); }
+      }
+      big = parked ? -1.0f : bg;
+    }
+    if (tid < kTreeThreads) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float a = lo[c], b = hi[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          a = fminf(a, __shfl_xor(a, off));
+          b = fmaxf(b, __shfl_xor(b, off));
+        }
+        if (lane == 0) { red[6 * (tid >> 6) + c] = a; red[6 * (tid >> 6) + 3 + c] = b; }
+      }
+    }
+  }
+  __syncthreads();
+  AGX_PHASE(5);
+  if (has_obj) {
+    float blo[3], inv[3], max_ext = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = INFINITY, b = -INFINITY;
+#pragma unroll
+      for (int wv = 0; wv < kTreeThreads / 64; ++wv) { a = fminf(a, red[6 * wv + c]); b = fmaxf(b, red[6 * wv + 3 + c]); }
+      blo[c] = a;
+      const float ext = b - a;
+      inv[c] = (ext > 0.0f && ext < INFINITY) ? 1023.0f / ext : 0.0f;
+      max_ext = c == 0 ? ext : fmaxf(max_ext, ext);
+    }
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float qv = fminf(fmaxf((cen[c] - blo[c]) * inv[c], 0.0f), 1023.0f);
+      code |= expand_bits10((uint32_t)qv) << (2 - c);
+    }
+    const bool parked = big < 0.0f;
+    if (big > kBvhLargeFraction * max_ext) code |= 1u << 30;  // wall slabs: their own subtree under the root
+    if (parked) code = 0xFFFFFFFEu;                            // one subtree at the end of the order, culled at its root
+    okey[o] = ((unsigned long long)(parked ? code : (code & ~7u)) << 32) | (unsigned long long)(uint32_t)o;
+  }
+  __syncthreads();
+  if (has_obj) {  // rank sort: the keys are unique (the object index is the low word)
+    const unsigned long long mine = okey[o];
+    int rank = 0;
+#pragma unroll 8
+    for (int g = 0; g < K; ++g) rank += okey[g] < mine ? 1 : 0;  // (the same address in every lane: a broadcast read)
+    skey[rank] = mine;
+  }
+  __syncthreads();
+  AGX_PHASE(6);
+  // Karras 2012 over the K sorted keys: children, parents, where the children's boxes lie
+  const int n_int = K - 1;
+  if (tid < n_int) {
+    const int i = tid;
+    const int d = (delta_keys(skey, K, i, i + 1) - delta_keys(skey, K, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta_keys(skey, K, i, i - d);
+    int lmax = 2;
+    while (delta_keys(skey, K, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+      if (delta_keys(skey, K, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta_keys(skey, K, i, j);
+    int s = 0, t = l;
+    do {
+      t = (t + 1) >> 1;
+      if (delta_keys(skey, K, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int left = (min(i, j) == gamma) ? (n_int + gamma) : gamma;
+    const int right = (max(i, j) == gamma + 1) ? (n_int + gamma + 1) : (gamma + 1);
+    child[2 * i] = left;
+    child[2 * i + 1] = right;
+    parent[left] = i;
+    parent[right] = i;
+    counter[i] = 0;
+    // float offsets from oaabb (nbox follows it): the bottom-up pass reads the boxes without going through the key table
+    boxoff[2 * i] = left >= n_int ? 6 * (int)(uint32_t)(skey[left - n_int] & 0xFFFFFFFFull) : 6 * (kObjMax + left);
+    boxoff[2 * i + 1] = right >= n_int ? 6 * (int)(uint32_t)(skey[right - n_int] & 0xFFFFFFFFull) : 6 * (kObjMax + right);
+  }
+  if (tid == 0) parent[0] = -1;
+  __syncthreads();
+  AGX_PHASE(9);
+  // bottom-up: the second arriver at a node merges its children's boxes
+  if (has_obj) {
+    int node = parent[n_int + tid];
+    while (node >= 0) {
+      __threadfence_block();  // release: this thread's box is written before the arrival
+      const int arrived = atomicAdd(&counter[node], 1);
+      const int o0 = boxoff[2 * node], o1 = boxoff[2 * node + 1], up = parent[node];
+      if (arrived == 0) break;
+      __threadfence_block();  // acquire: the sibling's box is read after the arrival
+      float a[6], b[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { a[k] = oaabb[o0 + k]; b[k] = oaabb[o1 + k]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        nbox[6 * node + c] = fminf(a[c], b[c]);
+        nbox[6 * node + 3 + c] = fmaxf(a[3 + c], b[3 + c]);
+      }
+      node = up;
+    }
+  }
+  __syncthreads();
+  AGX_PHASE(10);
+  // emit the K - 1 internal records, both child boxes inline
+  if (tid < n_int) {
+    const int i = tid;
+    float bx[2][6];
+    int ref[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int c = child[2 * i + side];
+      if (c >= n_int) {
+        const int ob = (int)(uint32_t)(skey[c - n_int] & 0xFFFFFFFFull);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bx[side][k] = oaabb[6 * ob + k];
+        ref[side] = objok[ob] ? ((K - 1 + 5 * ob) | AGX_BVH_OBJECT_REF) : (K - 1 + 5 * ob + 4);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bx[side][k] = nbox[6 * c + k];
+        ref[side] = c;
+      }
+    }
+    obj_store_node(out + (size_t)i * 16, bx[0], bx[1], ref[0], ref[1], -1, -1);
+  }
+  AGX_PHASE(7);
+}
+
 // Node record written to HBM (16 floats):
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
@@ -271,6 +555,10 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
   const bool box_objects = (ppo & AGX_BVH_BOX_OBJECTS) != 0;
   ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
+  if (box_objects && !force_full_sort && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax) {  // (wave-uniform: launch arguments only)
+    bvh_build_objects_env(env, nt, tri_world, nodes);
+    return;
+  }
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
@@ -692,15 +980,19 @@ struct SceneResetArgs {
 AGX_DEV void scene_refresh_env(int env, int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
                                const int32_t *__restrict__ tri_asset, float *asset_state, const float *__restrict__ half_extents,
                                float *tri_world, float *__restrict__ boxes, float *__restrict__ nodes, const SceneResetArgs &S) {
+  AGX_PHASE(0);
   if (S.enabled) {  // AssetManager.reset_idx for this env first: the poses the triangles are about to be moved to
     for (int a = threadIdx.x; a < na; a += kBvhThreads)
       reset_asset_one(S.B, S.R, env, a, na, nullptr, nullptr, nullptr, S.min_ratio, S.max_ratio, S.num_obstacles, S.num_keep, asset_state);
     __syncthreads();  // (workgroup scope: the poses are read back by this workgroup only)
   }
+  AGX_PHASE(1);
   for (int f = threadIdx.x; f < nt; f += kBvhThreads) transform_triangle(env, f, nt, na, tri_local, tri_asset, asset_state, tri_world);
+  AGX_PHASE(2);
   if (boxes)
     for (int k = threadIdx.x; k < na; k += kBvhThreads) box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
   __syncthreads();  // the env's triangles are in memory (workgroup scope) before the build reads them
+  AGX_PHASE(3);
   bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
 }
 
@@ -734,7 +1026,16 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt,
 
 static size_t bvh_lds_bytes(int nt, int npad) {
   const size_t box_floats = (size_t)(nt - 1) * 6 > (size_t)6 * kBvhThreads ? (size_t)(nt - 1) * 6 : (size_t)6 * kBvhThreads;
-  return (size_t)npad * 8 + box_floats * 4 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 + 64;
+  const size_t tri_level = (size_t)npad * 8 + box_floats * 4 + (size_t)(2 * nt - 1) * 4 + (size_t)(nt - 1) * 8 + (size_t)(nt - 1) * 4 + 64;
+  const size_t obj_level = (size_t)obj_lds_bytes_c(nt);
+  return tri_level > obj_level ? tri_level : obj_level;
+}
+// what a launch that is KNOWN to take the object-level build needs (the triangle-level build's 72 KB for 1272 triangles allow two
+// workgroups per CU; 41 KB allow three)
+static size_t bvh_lds_bytes_for(int nt, int npad, int prims_per_object) {
+  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
+  const bool object_level = (prims_per_object & AGX_BVH_BOX_OBJECTS) && !(prims_per_object & AGX_BVH_FULL_SORT) && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax;
+  return object_level ? (size_t)obj_lds_bytes_c(nt) : bvh_lds_bytes(nt, npad);
 }
 
 }  // namespace agx
@@ -762,6 +1063,11 @@ extern "C" int agx_boxes_from_assets(int n, int na, const float *asset_state, co
 
 extern "C" size_t agx_bvh_nodes_bytes(int n, int nt) { return nt > 1 ? (size_t)n * (nt - 1) * 16 * sizeof(float) : 0; }
 
+#ifdef AGX_SCENE_PHASE_CLOCK
+extern "C" int agx_debug_phase_clock(unsigned long long *out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clock), sizeof(unsigned long long) * 16);
+}
+#endif
 #ifdef AGX_BVH_EXPERIMENT
 extern "C" int agx_debug_set_obj_codes(const uint32_t *codes) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_obj_codes), &codes, sizeof(codes));
@@ -796,7 +1102,7 @@ static int bvh_launch_shape(int nt, int prims_per_object, int *npad_out, size_t 
               "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;
   while (npad < nt) npad <<= 1;
-  const size_t lds = bvh_lds_bytes(nt, npad);
+  const size_t lds = bvh_lds_bytes_for(nt, npad, prims_per_object);
   if (!*attr_set) {
     // the kernel also owns 4 bytes of static LDS: the dynamic maximum must leave room for them
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);

@@ -23,6 +23,9 @@ logger = CustomLogger("navigation_task")
 
 
 class NavigationTask(BaseTask):
+    _bookkeeping_fused = False  # (set by _fuse_with_env; subclasses that hand the env no task arguments leave it off)
+    _bookkeeping_ptrs = None
+
     def __init__(self, task_config, seed=None, num_envs=None, headless=None, device=None, use_warp=None):
         for name, val in (("seed", seed), ("num_envs", num_envs), ("headless", headless), ("device", device),
                           ("use_warp", use_warp)):

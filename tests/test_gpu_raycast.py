@@ -624,12 +624,71 @@ def test_bvh_object_level_order_equals_the_full_key_sort(orc):
             sc["asset_state"][:, 1, 0:7] = sc["asset_state"][:, 0, 0:7]  # the second box sits on the first
         S = Scene(sc)
         assert S.ppo & 0xFFFF == 12
+        S.ppo &= ~0x20000000  # the TRIANGLE-level build (with AGX_BVH_BOX_OBJECTS box scenes take the object-level build: its own test)
         S.build()
         a = S.nodes.clone()
         S.nodes.zero_()
         S.ppo |= FULL
         S.build()
         assert torch.equal(a.view(torch.int32), S.nodes.view(torch.int32)), (n, k, walls, twin)
+
+
+def _walk_tree(nodes, NI, tris_e, e, nt):
+    """-> (times each triangle is reached, object nodes, internal nodes visited); checks every child box on the way"""
+    OBJ = 0x40000000
+    seen = np.zeros(nt, int)
+    stack, visited, objects = [0], 0, 0
+    while stack:
+        i = stack.pop()
+        visited += 1
+        assert 0 <= i < nt - 1
+        for cslot, sslot, lo, hi in ((3, 11, slice(0, 3), slice(4, 7)), (7, 15, slice(8, 11), slice(12, 15))):
+            c, s2 = int(NI[e, i, cslot]), int(NI[e, i, sslot])
+            blo, bhi = nodes[e, i, lo], nodes[e, i, hi]
+            if c < 0:
+                for f in [~c] + ([s2] if s2 >= 0 else []):
+                    seen[f] += 1
+                    assert (tris_e[f] >= blo - 1e-6).all() and (tris_e[f] <= bhi + 1e-6).all()
+            elif c & OBJ:
+                f0 = int(NI[e, c & ~OBJ, 15])
+                v = tris_e[f0:f0 + 12].reshape(-1, 3)
+                assert (v >= blo - 1e-6).all() and (v <= bhi + 1e-6).all()
+                seen[f0:f0 + 12] += 1
+                objects += 1
+            else:
+                stack.append(c)
+    return seen, objects, visited
+
+
+def test_object_level_build_with_parked_and_non_box_objects(orc):
+    """The object-level build (round 6: the tree over the K objects, csrc/agx_scene.hip bvh_build_objects_env) on a scene that is
+    not all boxes in view: half of the obstacles parked at -1000 m (the curriculum's doing: float32 no longer resolves a box there),
+    one obstacle deformed (a moved vertex: not a box).  Those keep every triangle reachable through a five-node subtree, the
+    rest are object nodes; K - 1 internal nodes over them.  And the frames are the triangle-level tree's, bit for bit."""
+    n, k = 3, 20
+    sc = random_box_scene(n, k, seed=21, walls=False)
+    sc["asset_state"][:, 10:, 0:3] = -1000.0
+    sc["tri_local"] = sc["tri_local"].copy()
+    sc["tri_local"][:, 12 * 3, 0:3] *= 1.3  # vertex 0 of triangle 0 of object 3
+    frames = []
+    for box_objects in (True, False):
+        S = Scene(sc)
+        S.ppo = 12 | (0x20000000 if box_objects else 0)
+        S.build()
+        if box_objects:
+            nodes = S.nodes.cpu().numpy()
+            tris = S.tri_world.cpu().numpy().reshape(n, -1, 3, 3)
+            for e in range(n):
+                seen, objects, visited = _walk_tree(nodes, nodes.view(np.int32), tris[e], e, S.nt)
+                assert seen.min() == 1 and seen.max() == 1
+                assert objects == 9 and visited == (k - 1) + 5 * (k - 9)
+        _, _, _, _, pos, quat = _poses(orc, n, sc, 5)
+        kinv, cx, cy = orc.camera_kinv(64, 48, 87.0)
+        frames.append(S.camera(64, 48, kinv, 10.0, cx, cy, 1, pos, quat))
+        frames.append(S.camera(64, 48, kinv, 3000.0, cx, cy, 0, pos, quat))  # a far plane beyond the parked obstacles
+    assert np.array_equal(frames[0][0].view(np.uint32), frames[2][0].view(np.uint32)) and np.array_equal(frames[0][1], frames[2][1])
+    assert np.array_equal(frames[1][0].view(np.uint32), frames[3][0].view(np.uint32)) and np.array_equal(frames[1][1], frames[3][1])
+    assert (frames[0][1] >= 0).any()
 
 
 def test_bvh_structure_covers_every_triangle_once(orc):
