@@ -297,13 +297,27 @@ AGX_DEV uint32_t box_face_candidates(const Ray &r, float4 n0, float4 n1, float4 
   // two slabs.  The six verdicts are packed into ONE register before the first triangle test: nothing of the box-frame arithmetic
   // stays live across the exact tests (they take the kernel's whole register budget).
   uint32_t cbits = 0u;
-#define AGX_BOX_FACE(BIT, TF) cbits |= (live & ((fabsf((TF)-t_first) <= two_eps) | (fabsf((TF)-t_alt) <= two_eps))) ? (1u << (BIT)) : 0u;
-  AGX_BOX_FACE(0, tm0)
-  AGX_BOX_FACE(1, tp0)
-  AGX_BOX_FACE(2, tm1)
-  AGX_BOX_FACE(3, tp1)
-  AGX_BOX_FACE(4, tm2)
-  AGX_BOX_FACE(5, tp2)
+#define AGX_BOX_FACE(BIT, TF, TREF) cbits |= (live & (fabsf((TF) - (TREF)) <= two_eps)) ? (1u << (BIT)) : 0u;
+  AGX_BOX_FACE(0, tm0, t_first)
+  AGX_BOX_FACE(1, tp0, t_first)
+  AGX_BOX_FACE(2, tm1, t_first)
+  AGX_BOX_FACE(3, tp1, t_first)
+  AGX_BOX_FACE(4, tm2, t_first)
+  AGX_BOX_FACE(5, tp2, t_first)
+#ifndef AGX_RAY_BOX_ALT_ALWAYS
+  // t_alt differs from t_first only for an origin within the tolerance of the surface (|t_enter| <= 2 eps and t_enter >= -eps): some
+  // lane of the packet in that position is rare (a sensor touching an obstacle, stereo occlusion rays at close range) -- the six
+  // comparisons against the exit are made only then (the same candidate sets; round 5 made them for every visit)
+  if (vote(live & (t_alt != t_first)))
+#endif
+  {
+    AGX_BOX_FACE(0, tm0, t_alt)
+    AGX_BOX_FACE(1, tp0, t_alt)
+    AGX_BOX_FACE(2, tm1, t_alt)
+    AGX_BOX_FACE(3, tp1, t_alt)
+    AGX_BOX_FACE(4, tm2, t_alt)
+    AGX_BOX_FACE(5, tp2, t_alt)
+  }
 #undef AGX_BOX_FACE
   return cbits;  // bit k: face k (-x +x -y +y -z +z) may hold this ray's result; its triangles: nibble k of 0x4371A0 / 0x6895B2
 }
