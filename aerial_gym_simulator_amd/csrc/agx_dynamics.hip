@@ -1626,14 +1626,17 @@ __global__ void __launch_bounds__(256) k_reward_navigation(AgxEnvBuffers B, int 
 }
 
 // navigation_task.py:369-393; one wave per env so the depth min-pool is a coalesced sweep
-AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target,
-                                const float *__restrict__ u_vec, const float *__restrict__ u_euler,
-                                const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw, int obs_dim,
-                                float *__restrict__ obs, float *__restrict__ min_pixel) {
+// (part, nparts): the env's work split over `nparts` waves -- the state part goes to the last one, the cell rows cy = part,
+// part + nparts, ... of the min-pool to each; the minimum over the image comes back as this wave's share (the caller reduces).
+AGX_DEV float obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const float *__restrict__ target,
+                                 const float *__restrict__ u_vec, const float *__restrict__ u_euler,
+                                 const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw, int obs_dim,
+                                 float *__restrict__ obs, float *__restrict__ min_pixel, int part = 0, int nparts = 1) {
   const int lane = threadIdx.x & 63;
   float *o = obs + (size_t)i * obs_dim;
   float *row = B.step_rows[B.flag_parity] ? B.step_rows[B.flag_parity] + (size_t)i * (obs_dim + 3) : nullptr;
-  if (lane == 0) {
+  float imin = INFINITY;  // NavigationTask.post_image_reward_addition on the same sweep (min_pixel != NULL, ns == 1)
+  if (lane == 0 && part == nparts - 1) {
     V3 p = V3{AGX_AT(B.state, 0), AGX_AT(B.state, 1), AGX_AT(B.state, 2)};
     Q4 qveh = Q4{AGX_AT(B.derived, 3), AGX_AT(B.derived, 4), AGX_AT(B.derived, 5), AGX_AT(B.derived, 6)};
     V3 tgt = V3{AGX_AT(target, 0), AGX_AT(target, 1), AGX_AT(target, 2)};
@@ -1673,8 +1676,7 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     const int Wv = vec4 ? W >> 2 : W;                    // columns the sweep sees
     const int cw = ((W + gw - 1) / gw) >> (vec4 ? 2 : 0);  // cell width in such columns
     const bool pow2 = (cw & (cw - 1)) == 0 && cw < 64;
-    float imin = INFINITY;  // NavigationTask.post_image_reward_addition on the same sweep (min_pixel != NULL, ns == 1)
-    for (int cy = 0; cy < gh; ++cy) {
+    for (int cy = part; cy < gh; cy += nparts) {
       const int y0 = cy * ch, y1 = min(y0 + ch, H);
       float cell = INFINITY;  // lane c < gw: cell (cy, c)
       for (int x0 = 0; x0 < Wv && y0 < y1; x0 += 64) {
@@ -1738,9 +1740,29 @@ AGX_DEV void obs_navigation_env(const AgxEnvBuffers &B, int n, int i, const floa
     }
     if (min_pixel) {
       for (int off = 32; off > 0; off >>= 1) imin = fminf(imin, __shfl_xor(imin, off));
-      if (lane == 0) min_pixel[i] = imin;
+      if (lane == 0 && nparts == 1) min_pixel[i] = imin;
     }
   }
+  return imin;
+}
+// Small batches (the 256 .. 2048 envs an RL run uses): one WORKGROUP per env, its four waves take every fourth cell row of the
+// min-pool each and the last one the state part as well -- the one-wave-per-env form runs the eight cell rows' loads as eight
+// memory round trips in sequence and the Philox draws of the state part in front of them (13 us at 256 envs; this one: 5).
+// min is exact and order-free: the same bits.
+__global__ void __launch_bounds__(256) k_obs_navigation_split(AgxEnvBuffers B, int n, const float *__restrict__ target,
+                                                               const float *__restrict__ u_vec, const float *__restrict__ u_euler,
+                                                               const float *__restrict__ pixels, int ns, int H, int W, int gh, int gw,
+                                                               int obs_dim, float *__restrict__ obs, float *__restrict__ min_pixel) {
+  __shared__ float wave_min[4];
+  const int i = blockIdx.x, w = threadIdx.x >> 6;
+  push_wait_for_slot(B);
+  const float imin = obs_navigation_env(B, n, i, target, u_vec, u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel, w, 4);
+  if (min_pixel && pixels) {
+    if ((threadIdx.x & 63) == 0) wave_min[w] = imin;
+    __syncthreads();
+    if (threadIdx.x == 0) min_pixel[i] = fminf(fminf(wave_min[0], wave_min[1]), fminf(wave_min[2], wave_min[3]));
+  }
+  step_rows_signal(B);
 }
 __global__ void __launch_bounds__(256) k_obs_navigation(AgxEnvBuffers B, int n, const float *__restrict__ target,
                                                          const float *__restrict__ u_vec, const float *__restrict__ u_euler,
@@ -2384,8 +2406,12 @@ extern "C" int agx_obs_navigation(const AgxEnvBuffers *B, int n, const float *ta
   AGX_REQUIRE((u_vec == nullptr) == (u_euler == nullptr), "u_vec and u_euler: both tensors or both NULL (device generator)");
   AGX_REQUIRE(obs_dim >= 17, "obs_dim must be >= 17");
   AGX_REQUIRE(!pixels || (ns > 0 && H > 0 && W > 0 && gh > 0 && gw > 0), "bad image sizes");
-  hipLaunchKernelGGL(k_obs_navigation, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec,
-                     u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel);
+  if (pixels && n <= 2048 && gh >= 4)
+    hipLaunchKernelGGL(k_obs_navigation_split, dim3(n), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec, u_euler, pixels, ns, H,
+                       W, gh, gw, obs_dim, obs, min_pixel);
+  else
+    hipLaunchKernelGGL(k_obs_navigation, dim3(blocks_for(n, 4)), dim3(256), 0, (hipStream_t)stream, *B, n, target, u_vec,
+                       u_euler, pixels, ns, H, W, gh, gw, obs_dim, obs, min_pixel);
   return check_launch("agx_obs_navigation");
 }
 
