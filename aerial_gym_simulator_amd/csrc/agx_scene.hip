@@ -370,20 +370,23 @@ AGX_DEV void bvh_build_objects_env(int env, int nt, const float *__restrict__ tr
         continue;
       }
       // six two-triangle leaves (the face pairs of trimesh's box; for anything else just six pairs), five nodes over them
-      float p[6][6], a[6], b[6], c2[6], d[6];
+      // (one pair of faces at a time: two boxes in, one node out, their union kept -- 36 live floats at once spilled)
+      float un[3][6];
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
+      for (int j = 0; j < 3; ++j) {
+        float p0[6], p1[6];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { p[j][c] = pb[6 * (6 * o + j) + c] - kBoxEps; p[j][3 + c] = pb[6 * (6 * o + j) + 3 + c] + kBoxEps; }
-      obj_store_node(rec, p[0], p[1], ~(g0 + pair_a(0)), ~(g0 + pair_a(1)), g0 + pair_b(0), g0 + pair_b(1));
-      obj_store_node(rec + 16, p[2], p[3], ~(g0 + pair_a(2)), ~(g0 + pair_a(3)), g0 + pair_b(2), g0 + pair_b(3));
-      obj_store_node(rec + 32, p[4], p[5], ~(g0 + pair_a(4)), ~(g0 + pair_a(5)), g0 + pair_b(4), g0 + pair_b(5));
-      box_union(p[0], p[1], a);
-      box_union(p[2], p[3], b);
-      obj_store_node(rec + 48, a, b, base + 0, base + 1, -1, -1);
-      box_union(a, b, d);
-      box_union(p[4], p[5], c2);
-      obj_store_node(rec + 64, d, c2, base + 3, base + 2, -1, -1);
+        for (int c = 0; c < 3; ++c) {
+          p0[c] = pb[6 * (6 * o + 2 * j) + c] - kBoxEps; p0[3 + c] = pb[6 * (6 * o + 2 * j) + 3 + c] + kBoxEps;
+          p1[c] = pb[6 * (6 * o + 2 * j + 1) + c] - kBoxEps; p1[3 + c] = pb[6 * (6 * o + 2 * j + 1) + 3 + c] + kBoxEps;
+        }
+        obj_store_node(rec + 16 * j, p0, p1, ~(g0 + pair_a(2 * j)), ~(g0 + pair_a(2 * j + 1)), g0 + pair_b(2 * j), g0 + pair_b(2 * j + 1));
+        box_union(p0, p1, un[j]);
+      }
+      obj_store_node(rec + 48, un[0], un[1], base + 0, base + 1, -1, -1);
+      float d[6];
+      box_union(un[0], un[1], d);
+      obj_store_node(rec + 64, d, un[2], base + 3, base + 2, -1, -1);
     }
     AGX_PHASE_LAST(8);
   }
@@ -551,14 +554,17 @@ AGX_DEV void bvh_build_objects_env(int env, int nt, const float *__restrict__ tr
 //   [0..2] lo_left  [3] child_left (int bits)   [4..6] hi_left  [7] child_right (int bits)
 //   [8..10] lo_right [11] second_left (int)     [12..14] hi_right [15] second_right (int)
 // child >= 0: internal node index, child < 0: leaf holding triangle ~child and, if second >= 0, that triangle too.
+// OBJ: the launch is known to take the object-level build (object_level_build() on the host: launch arguments only) -- each kernel
+// instance carries ONE builder (both inlined in one kernel spilled loop-carried values to scratch)
+template <bool OBJ>
 AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__restrict__ tri_world, float *__restrict__ nodes) {
-  const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
-  const bool box_objects = (ppo & AGX_BVH_BOX_OBJECTS) != 0;
-  ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
-  if (box_objects && !force_full_sort && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax) {  // (wave-uniform: launch arguments only)
+  if (OBJ) {
     bvh_build_objects_env(env, nt, tri_world, nodes);
     return;
   }
+  const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
+  const bool box_objects = (ppo & AGX_BVH_BOX_OBJECTS) != 0;
+  ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
@@ -944,11 +950,12 @@ __global__ void __launch_bounds__(1024) k_compact_mask(int n, const uint8_t *__r
   }
 }
 
+template <bool OBJ>
 __global__ void __launch_bounds__(kBvhThreads, 4) k_bvh_build(int n, int nt, int npad, int ppo, const float *__restrict__ tri_world,
                                                             int32_t *__restrict__ work, float *__restrict__ nodes) {
   if (!work) {  // every env
     for (int env = blockIdx.x; env < n; env += gridDim.x) {
-      bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
+      bvh_build_env<OBJ>(env, nt, npad, ppo, tri_world, nodes);
       __syncthreads();  // LDS is reused by the next env
     }
     return;
@@ -961,7 +968,7 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_bvh_build(int n, int nt, int
     const int idx = next;
     __syncthreads();  // everybody has read `next` before thread 0 overwrites it; also fences LDS reuse
     if (idx >= count) break;
-    bvh_build_env(work[2 + idx], nt, npad, ppo, tri_world, nodes);
+    bvh_build_env<OBJ>(work[2 + idx], nt, npad, ppo, tri_world, nodes);
   }
 }
 
@@ -977,6 +984,7 @@ struct SceneResetArgs {
   const float *min_ratio, *max_ratio;
 };
 
+template <bool OBJ>
 AGX_DEV void scene_refresh_env(int env, int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
                                const int32_t *__restrict__ tri_asset, float *asset_state, const float *__restrict__ half_extents,
                                float *tri_world, float *__restrict__ boxes, float *__restrict__ nodes, const SceneResetArgs &S) {
@@ -993,9 +1001,10 @@ AGX_DEV void scene_refresh_env(int env, int n, int nt, int npad, int ppo, int na
     for (int k = threadIdx.x; k < na; k += kBvhThreads) box_from_asset(env, k, n, na, asset_state, half_extents, boxes);
   __syncthreads();  // the env's triangles are in memory (workgroup scope) before the build reads them
   AGX_PHASE(3);
-  bvh_build_env(env, nt, npad, ppo, tri_world, nodes);
+  bvh_build_env<OBJ>(env, nt, npad, ppo, tri_world, nodes);
 }
 
+template <bool OBJ>
 __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt, int npad, int ppo, int na, const float *__restrict__ tri_local,
                                                                 const int32_t *__restrict__ tri_asset,
                                                                 float *asset_state,
@@ -1009,7 +1018,7 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt,
     const int env = blockIdx.x;
     if (S.enabled && S.B.reset_flag[S.B.flag_parity] == 0) return;
     if (!mask[env]) return;
-    scene_refresh_env(env, n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
+    scene_refresh_env<OBJ>(env, n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
     return;
   }
   __shared__ int next;
@@ -1020,7 +1029,7 @@ __global__ void __launch_bounds__(kBvhThreads, 4) k_scene_refresh(int n, int nt,
     const int idx = next;
     __syncthreads();  // everybody has read `next` before thread 0 overwrites it; also fences LDS reuse
     if (idx >= count) break;
-    scene_refresh_env(work[2 + idx], n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
+    scene_refresh_env<OBJ>(work[2 + idx], n, nt, npad, ppo, na, tri_local, tri_asset, asset_state, half_extents, tri_world, boxes, nodes, S);
   }
 }
 
@@ -1032,10 +1041,12 @@ static size_t bvh_lds_bytes(int nt, int npad) {
 }
 // what a launch that is KNOWN to take the object-level build needs (the triangle-level build's 72 KB for 1272 triangles allow two
 // workgroups per CU; 41 KB allow three)
-static size_t bvh_lds_bytes_for(int nt, int npad, int prims_per_object) {
+static bool object_level_build(int nt, int prims_per_object) {
   const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
-  const bool object_level = (prims_per_object & AGX_BVH_BOX_OBJECTS) && !(prims_per_object & AGX_BVH_FULL_SORT) && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax;
-  return object_level ? (size_t)obj_lds_bytes_c(nt) : bvh_lds_bytes(nt, npad);
+  return (prims_per_object & AGX_BVH_BOX_OBJECTS) && !(prims_per_object & AGX_BVH_FULL_SORT) && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax;
+}
+static size_t bvh_lds_bytes_for(int nt, int npad, int prims_per_object) {
+  return object_level_build(nt, prims_per_object) ? (size_t)obj_lds_bytes_c(nt) : bvh_lds_bytes(nt, npad);
 }
 
 }  // namespace agx
@@ -1128,20 +1139,22 @@ constexpr int kDirectRefreshEnvs = 2048;  // up to here a workgroup per env (cle
 static int scene_refresh_launch(int n, int nt, int na, const float *tri_local, const int32_t *tri_asset, float *asset_state,
                                 const float *half_extents, int prims_per_object, const uint8_t *mask, float *tri_world, float *boxes,
                                 float *nodes, int32_t *work, const SceneResetArgs *reset, void *stream) {
-  static bool attr_set = false;
+  static bool attr_set[2] = {false, false};
+  const bool obj = object_level_build(nt, prims_per_object);
+  auto kernel = obj ? k_scene_refresh<true> : k_scene_refresh<false>;
   int npad = 0;
   size_t lds = 0;
-  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_scene_refresh), &attr_set)) return e;
+  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(kernel), &attr_set[obj])) return e;
   SceneResetArgs S{};
   if (reset) S = *reset;
   if (n <= kDirectRefreshEnvs) {
-    hipLaunchKernelGGL(k_scene_refresh, dim3(n), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
+    hipLaunchKernelGGL(kernel, dim3(n), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
                        tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes, mask, S);
     return check_launch("agx_scene_refresh");
   }
   hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
-  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
-  hipLaunchKernelGGL(k_scene_refresh, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
+  const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272 triangle-level, 41 KB object-level)
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad, prims_per_object, na, tri_local,
                      tri_asset, asset_state, half_extents, tri_world, boxes, work, nodes, (const uint8_t *)nullptr, S);
   return check_launch("agx_scene_refresh");
 }
@@ -1189,13 +1202,15 @@ extern "C" int agx_bvh_build(int n, int nt, int prims_per_object, const float *t
   AGX_REQUIRE(n > 0, "bad num_envs");
   AGX_REQUIRE(tri_world && nodes, "null buffer");
   AGX_REQUIRE(!mask || work, "a masked rebuild needs the work buffer (int32[num_envs + 2])");
-  static bool attr_set = false;
+  static bool attr_set[2] = {false, false};
+  const bool obj = object_level_build(nt, prims_per_object);
+  auto kernel = obj ? k_bvh_build<true> : k_bvh_build<false>;
   int npad = 0;
   size_t lds = 0;
-  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(k_bvh_build), &attr_set)) return e;
+  if (int e = bvh_launch_shape(nt, prims_per_object, &npad, &lds, reinterpret_cast<const void *>(kernel), &attr_set[obj])) return e;
   if (mask) hipLaunchKernelGGL(k_compact_mask, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, mask, work);
   const int grid = n < 512 ? n : 512;  // two resident workgroups per CU (LDS bound: 72 KB each for T = 1272)
-  hipLaunchKernelGGL(k_bvh_build, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad,
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBvhThreads), lds, (hipStream_t)stream, n, nt, npad,
                      prims_per_object, tri_world, mask ? work : nullptr, nodes);  // (with the AGX_BVH_FULL_SORT bit, if set)
   return check_launch("agx_bvh_build");
 }
