@@ -868,6 +868,34 @@ def emit_line(out, fd=None):
         os.write(fd, line.encode())
 
 
+def usable_cpus():
+    """hardware threads this process may really use: the affinity mask, capped by the cgroup's CPU quota (a GPU box reports 256
+    logical CPUs to os.cpu_count() whatever the container is allowed: 256 OpenMP threads on a few cores ran the port 10x slower
+    in one round-6 run than in the next)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_omp_threads(n):
+    """thread count of the oracle's OpenMP loops from now on (libgomp's omp_set_num_threads); False if it cannot be set"""
+    import ctypes as C
+
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
 def cpu_baseline_dynamics(num_envs, budget_s=12.0):
     """The CPU oracle (a C port of the reference's per-env step, oracle/) timed on this box's
     host cores on the same workload: 8192 envs, position task, Lee position control, k=1."""
@@ -896,20 +924,36 @@ def cpu_baseline_dynamics(num_envs, budget_s=12.0):
     d = draws()
     for i in range(5):
         env.step(actions[i % 8], d)
+    # the thread count that is fastest HERE: all usable CPUs, or fewer where hyper-threads / a quota make that slower (1 s each)
+    usable = usable_cpus()
+    cores, tried = int(os.environ.get("OMP_NUM_THREADS", usable)), {}
+    if "OMP_NUM_THREADS" not in os.environ:
+        for cand in sorted({usable, max(1, usable // 2), min(usable, 32), min(usable, 8)}, reverse=True):
+            if not set_omp_threads(cand):
+                break
+            env.step(actions[0], d)
+            n_probe, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:
+                env.step(actions[n_probe % 8], d)
+                n_probe += 1
+            tried[cand] = n_probe / (time.perf_counter() - t0)
+        if tried:
+            cores = max(tried, key=tried.get)
+            set_omp_threads(cores)
     steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
+    while time.perf_counter() - t0 < budget_s - len(tried):
         for i in range(20):
             env.step(actions[i % 8], d)
         steps += 20
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {
         "value": n * steps / dt,
         "unit": "env-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{steps} env steps of {n} envs ({dt:.1f} s): oracle C port of the per-env step (OpenMP over envs), "
-                  "same task/config as the GPU run",
+        "sample": f"{steps} env steps of {n} envs ({dt:.1f} s): oracle C port of the per-env step (OpenMP over envs, {cores} threads: "
+                  f"the fastest of {sorted(tried)} tried for 1 s each; os.cpu_count() = {os.cpu_count()}), same task/config as the GPU run",
+        "threads_tried_steps_per_s": {str(k): round(v, 1) for k, v in tried.items()},
     }
 
 
@@ -927,6 +971,9 @@ def cpu_baseline_raycast(task, budget_s=8.0, sample_envs=512):
     tris, seg, pos, quat = npy(sc.tri_world), npy(sc.tri_seg), npy(sen.sensor_position), npy(sen.sensor_orientation)
     cfg = sen.cfg
     kinv, cx, cy = orc.camera_kinv(cfg.width, cfg.height, cfg.horizontal_fov_deg)
+    cores = usable_cpus()
+    if "OMP_NUM_THREADS" not in os.environ:
+        set_omp_threads(cores)
     orc.raycast_camera(cfg.width, cfg.height, kinv, cfg.max_range, cx, cy, "depth", pos, quat, tris, seg, use_bvh=True)  # warm-up
     frames, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
@@ -934,7 +981,7 @@ def cpu_baseline_raycast(task, budget_s=8.0, sample_envs=512):
         frames += 1
     dt = time.perf_counter() - t0
     rays = frames * m * cfg.num_sensors * cfg.width * cfg.height
-    return {"value": frames * m / dt, "unit": "env-frames/s", "rays_per_s": rays / dt, "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)),
+    return {"value": frames * m / dt, "unit": "env-frames/s", "rays_per_s": rays / dt, "cores": int(os.environ.get("OMP_NUM_THREADS", 0)) or cores,
             "kind": "port", "sample": f"{frames} frames of {m} envs ({dt:.1f} s): oracle C port of the depth+seg camera kernel, BVH build "
                                       "included in every frame (OpenMP over envs), scenes and poses of the GPU run"}
 
