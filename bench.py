@@ -57,6 +57,9 @@ def parse():
                     help="no timing: build every exchange backend (process_group, peer_push, rccl_thread) on the N ranks, run "
                          "--selftest-steps checksum-verified exchange steps on each and print ONE JSON verdict line per backend")
     ap.add_argument("--selftest-steps", type=int, default=1000)
+    ap.add_argument("--preflight-steps", type=int, default=200,
+                    help="N > 1: checksum-verified exchange steps per backend BEFORE anything is timed (0 = skip); the verdicts go to "
+                         "stderr and into the line's exchange.preflight")
     args = ap.parse_args()
     if args.num_envs is None:
         args.num_envs = 4096 if args.workload in ("lidar", "lidar_velocity") else 8192
@@ -808,6 +811,8 @@ def compact_line(out, detail_path=None):
     if isinstance(ex, dict):
         brief = _pick(ex, ("ms_per_step_with_exchange", "ms_per_step_without_exchange", "all_gather_us_synchronised", "bytes_per_rank",
                            "communicator_ranks", "backend_of_first_leg"))
+        if isinstance(ex.get("preflight"), list):
+            brief["preflight"] = [{k: (str(v)[:200] if isinstance(v, (dict, str)) else v) for k, v in p.items()} for p in ex["preflight"][:4]]
         for b in ("process_group", "peer_push", "rccl_thread"):
             if isinstance(ex.get(b), dict):
                 brief[b] = _pick(ex[b], ("value", "ms_per_step", "plus_depth_value", "ranks_seen", "failed_in"))
@@ -1040,19 +1045,30 @@ def sensor_leg(args, workload, num_envs, device, rank, world, use_dist, primary_
     return leg
 
 
-def exchange_selftest(args, world, rank, device, limit_s=60.0):
+def exchange_selftest(args, world, rank, device, limit_s=60.0, preflight=None):
     """`--exchange-selftest-only`: first contact with an N-GPU node made cheap.  Per backend: the communicator / IPC mappings are
     built, `--selftest-steps` real env steps run with the per-step exchange, every rank checksums the rows it SENT and every
     slice it RECEIVED (bit patterns summed as integers: exact, order-independent), the sent checksums travel over the process
     group and are compared step by step -- the checks of tests/exchange_world2_worker.py.  One JSON line per backend on rank 0's
     stdout: which leg failed, in which stage, and which (receiver, sender) pair first disagreed at which step.  Nothing is timed
-    for the record; a leg that does not come back within `limit_s` prints what it has and ends the process."""
+    for the record; a leg that does not come back within `limit_s` prints what it has and ends the process.
+    `preflight` (a list): the same checks as the FIRST thing a timed N > 1 run does (round 6: whatever command a multi-GPU lease
+    runs first, the verdicts come first) -- `--preflight-steps` steps per backend, verdicts on stderr and appended to the list
+    (they end up in the line's `exchange.preflight`); a leg that hangs still ends the process, with a parseable line on stdout
+    that names it; a leg that fails is reported and the timed legs run anyway (each is watched by its own watchdog)."""
     import threading
 
     import torch.distributed as dist
     from aerial_gym_simulator_amd.sharding import StepGather
 
-    steps, N = int(args.selftest_steps), args.num_envs
+    steps, N = int(args.preflight_steps if preflight is not None else args.selftest_steps), args.num_envs
+
+    def emit(res):
+        if preflight is None:
+            emit_line(res)
+        else:
+            print("[bench preflight] " + json.dumps(res)[:1500], file=sys.stderr, flush=True)
+
     for backend in ("process_group", "peer_push", "rccl_thread"):
         res = {"selftest": "exchange", "backend": backend, "world": world, "steps": steps, "num_envs_per_rank": N, "ok": False}
         stage = ["build"]
@@ -1060,7 +1076,9 @@ def exchange_selftest(args, world, rank, device, limit_s=60.0):
         def give_up(res=res, stage=stage):
             res["error"] = f"no completion within {limit_s:.0f} s (rank {rank} was in stage '{stage[0]}')"
             if rank == 0:
-                emit_line(res)
+                # (preflight: the ONE stdout line of the run is this verdict -- the timed legs never started)
+                emit_line(res if preflight is None else {"metric": "env-steps/sec (not measured: the exchange preflight hung)", "value": None,
+                                                         "n_gpus": world, "error": res["error"], "exchange": {"preflight": preflight + [res]}})
             os._exit(3)
 
         dog = threading.Timer(limit_s, give_up)
@@ -1123,9 +1141,16 @@ def exchange_selftest(args, world, rank, device, limit_s=60.0):
         dog.cancel()
         res.update(ok=all(r["ok"] for r in per_rank), per_rank=per_rank, seconds=time.perf_counter() - t0)
         if rank == 0:
-            emit_line(res)
+            emit(res)
+        if preflight is not None:
+            bad = [r for r in per_rank if not r["ok"]]
+            preflight.append({"backend": backend, "ok": res["ok"], "steps": steps, "seconds": round(res["seconds"], 2),
+                              "first_failure": ({k: bad[0].get(k) for k in ("rank", "error", "failed_in", "first_bad_step_by_sender")} if bad else None)})
         if any("error" in r and r.get("failed_in") not in ("setup",) for r in per_rank):
             # something half-built may be left behind (a communicator some rank never joined): no further legs, no teardown
+            if preflight is not None and rank == 0:
+                emit_line({"metric": "env-steps/sec (not measured: the exchange preflight failed)", "value": None, "n_gpus": world,
+                           "error": f"exchange preflight: backend {backend} failed", "exchange": {"preflight": preflight}})
             sys.stdout.flush()
             os._exit(0 if rank != 0 else 4)
 
@@ -1233,6 +1258,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    preflight = None
+    if use_dist and args.preflight_steps > 0 and (world > 1 or os.environ.get("AGX_BENCH_PREFLIGHT") == "1"):
+        # first contact with an N-GPU node: which backend, which stage, which rank pair -- before the first timed step
+        preflight = []
+        exchange_selftest(args, world, rank, device, preflight=preflight)
+        import torch.distributed as dist
+
+        dist.barrier()
     task = make_task(args.workload, args.num_envs, device, args.strict_rng, rank)
     task.reset()
     N, A = task.num_envs, task.task_config.action_space_dim
@@ -1344,6 +1377,8 @@ def main():
         exchange["communicator_ranks"] = exchange["ranks_seen"] = gather_buf.comm_info()[1]  # checked against WORLD_SIZE above
         exchange["backend_of_first_leg"] = gather_buf.backend
         exchange["rank0_devices"] = diag
+        if preflight is not None:
+            exchange["preflight"] = preflight
         out["exchange"] = exchange
     if rank == 0 and args.workload != "dynamics":
         kt = kernel_time_raycast(task)

@@ -86,6 +86,23 @@ def test_exchange_selftest_only_prints_one_verdict_per_backend():
         assert pr["own_slice_ok"] and pr["first_bad_step_by_sender"] == {} and pr["resets"] > 300 * 2  # ~4 truncations per step at 2048 envs
 
 
+@pytest.mark.gpu
+def test_sharded_run_starts_with_the_exchange_preflight():
+    """whatever command a multi-GPU lease runs first, the exchange verdicts come first.  A timed run with more
+    than one rank (here: the sharded code path in a world of one, AGX_BENCH_FORCE_DIST + AGX_BENCH_PREFLIGHT) runs
+    `--preflight-steps` checksum-verified exchange steps per backend before anything is timed: verdicts on stderr, their summary in
+    the ONE stdout line (`exchange.preflight`), the timed legs after it."""
+    r = run_bench(["--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-depth", "--no-lidar", "--no-strict",
+                   "--preflight-steps", "60"], {"AGX_BENCH_FORCE_DIST": "1", "AGX_BENCH_PREFLIGHT": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (line,) = json_lines(r.stdout)
+    pre = line["exchange"]["preflight"]
+    assert [p["backend"] for p in pre] == ["process_group", "peer_push", "rccl_thread"]
+    assert all(p["ok"] is True and p["steps"] == 60 and p["first_failure"] is None for p in pre), pre
+    assert r.stderr.count("[bench preflight]") == 3
+    assert line["value"] > 1e6 and len(r.stdout) < 8192
+
+
 def _bench_module():
     sys.path.insert(0, ROOT)
     import bench
