@@ -1262,7 +1262,7 @@ def main():
     if use_dist and args.preflight_steps > 0 and (world > 1 or os.environ.get("AGX_BENCH_PREFLIGHT") == "1"):
         # first contact with an N-GPU node: which backend, which stage, which rank pair -- before the first timed step
         preflight = []
-        exchange_selftest(args, world, rank, device, preflight=preflight)
+        exchange_selftest(args, world, rank, device, limit_s=180.0, preflight=preflight)  # (a first RCCL communicator can take tens of seconds)
         import torch.distributed as dist
 
         dist.barrier()
