@@ -382,7 +382,7 @@ def cpu_baseline_reference():
             return dict({k: d[k] for k in keys}, measured_here=True)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] the reference tree is present but could not be timed ({type(e).__name__}: {e})", file=sys.stderr)
-    for name in ("r05_cpu_baseline_reference.json", "r04_cpu_baseline_reference.json", "r03_cpu_baseline_reference.json"):
+    for name in ("r06_cpu_baseline_reference.json", "r05_cpu_baseline_reference.json", "r04_cpu_baseline_reference.json", "r03_cpu_baseline_reference.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             return dict({k: d[k] for k in keys}, measured_here=False, source="profiles/" + name)
@@ -431,7 +431,7 @@ def live_parity(device):
     return {"case": "tests/golden/step_quad_position.npz (reference BaseMultirotor.step outputs, 6 sub-steps x 64 envs)",
             "max_err_vs_reference": out, "bit_exact_vs_reference_with_correctly_rounded_functions": bool(exact), "unit": "|err| / max(1, |x|) per component (thrust: / 2 N full scale)",
             "gates": "tests/ (pytest -m gpu): bit-exact vs the CPU oracle, <= 1e-5 vs the reference (every state component), bit-exact vs the reference with correctly rounded elementary functions; "
-                     "measured maxima of the last full run: profiles/r05_parity_report.json"}
+                     "measured maxima of the last full run: profiles/r06_parity_report.json"}
 
 
 def kernel_time_dynamics(task, actions, reps=400):
