@@ -292,13 +292,6 @@ AGX_DEV void box_object_record(const float *__restrict__ tris, int obj, float *r
 constexpr int kObjMax = 256;
 __host__ __device__ constexpr int obj_lds_bytes_c(int nt) { return kObjMax * (8 + 8 + 24 + 24 + 8 + 8 + 4 + 8 + 4 + 1 + 6) + (nt / 2) * 24 + 64; }
 
-AGX_DEV void obj_leaf_pair_box(const float *__restrict__ tb, int fa, int fb, float (&o)[6]) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    o[c] = fminf(tb[6 * fa + c], tb[6 * fb + c]) - kBoxEps;
-    o[3 + c] = fmaxf(tb[6 * fa + 3 + c], tb[6 * fb + 3 + c]) + kBoxEps;
-  }
-}
 AGX_DEV void obj_store_node(float *__restrict__ o, const float (&a)[6], const float (&b)[6], int rl, int rr, int sl, int sr) {
   o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = __int_as_float(rl);
   o[4] = a[3]; o[5] = a[4]; o[6] = a[5]; o[7] = __int_as_float(rr);
