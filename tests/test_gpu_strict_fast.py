@@ -98,3 +98,53 @@ def test_strict_fast_step_equals_the_general_strict_path(n):
             same = torch.equal(a.view(torch.int32), b.view(torch.int32)) if a.is_floating_point() else torch.equal(a, b)
             assert same, (t, name)
         assert f[5] == s[5], (t, "generator offset", f[5], s[5])
+
+
+def test_a_torch_whose_uniform_kernel_differs_falls_back_to_the_dispatcher(monkeypatch):
+    """EnvManager.strict_draw_plan checks the fused draw launch against the real `uniform_` calls once, on a saved-and-restored
+    generator state; when they disagree (here: a test double of agx_torch_uniform_fill that fills zeros -- what an upgrade of torch
+    that changes its kernel would look like) the task warns, takes the general strict path (dispatcher calls, `.item()`), and steps
+    exactly like it: same numbers as a run that never had the fast path."""
+    from aerial_gym_simulator_amd import _lib
+
+    lib = _lib.load()
+    real = lib.agx_torch_uniform_fill
+
+    def zeros(count, outs, numel, seed, offset, sm, mt, after, stream):
+        after._obj.value = offset + 4 * count  # (the right offset, the wrong numbers: the buffers stay as they are)
+        return 0
+
+    monkeypatch.setattr(lib, "agx_torch_uniform_fill", zeros)
+    with pytest.warns(UserWarning, match="does not reproduce this torch build"):
+        slow, resets = _run_with_plan_check(expect_fast=False)
+    monkeypatch.setattr(lib, "agx_torch_uniform_fill", real)
+    ref, resets_ref = _run(100, 60, 20, general=True)
+    assert resets == resets_ref and len(slow) == len(ref)
+    for t, (a, b) in enumerate(zip(slow, ref)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[5] == b[5], t
+
+
+def _run_with_plan_check(expect_fast):
+    import aerial_gym_simulator_amd  # noqa: F401
+    from aerial_gym_simulator_amd.config.task_config import position_setpoint_task_config as cfg
+    from aerial_gym_simulator_amd.registry.task_registry import task_registry
+
+    n, steps, episode_len = 100, 60, 20
+    old = (cfg.device, cfg.controller_name, cfg.episode_len_steps, cfg.args)
+    cfg.device, cfg.controller_name, cfg.episode_len_steps, cfg.args = DEV, "lee_position_control", episode_len, {"strict_rng": True}
+    try:
+        task = task_registry.make_task("position_setpoint_task", seed=11, num_envs=n, headless=True)
+        assert (task._strict is not None) == expect_fast and task._plan is None
+        task.reset()
+        steps_t = task.sim_env.global_tensor_dict["sim_steps"]
+        steps_t[:] = (torch.arange(n, device=DEV, dtype=torch.int32) % 4) * (episode_len // 4)
+        gen = torch.cuda.default_generators[0]
+        g = torch.Generator(device=DEV).manual_seed(5)
+        rec = []
+        for _ in range(steps):
+            a = torch.rand(n, 4, device=DEV, generator=g) * 2 - 1
+            obs, rew, term, trunc, _ = task.step(a)
+            rec.append((obs["observations"].clone(), rew.clone(), term.clone(), trunc.clone(), None, gen.get_offset()))
+        return rec, int(task.sim_env.global_tensor_dict["episode_count"].sum()) - n
+    finally:
+        cfg.device, cfg.controller_name, cfg.episode_len_steps, cfg.args = old
