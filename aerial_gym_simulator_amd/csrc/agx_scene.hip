@@ -557,7 +557,7 @@ AGX_DEV void bvh_build_env(int env, int nt, int npad, int ppo, const float *__re
   }
   const bool force_full_sort = (ppo & AGX_BVH_FULL_SORT) != 0;
   const bool box_objects = (ppo & AGX_BVH_BOX_OBJECTS) != 0;
-  ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
+  ppo &= ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS | AGX_BVH_OBJECT_TREE);
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);         // [npad]
   // Only the INTERNAL nodes' boxes live in LDS: a leaf's box is three min / max over its triangle, recomputed where it is
@@ -1035,8 +1035,9 @@ static size_t bvh_lds_bytes(int nt, int npad) {
 // what a launch that is KNOWN to take the object-level build needs (the triangle-level build's 72 KB for 1272 triangles allow two
 // workgroups per CU; 41 KB allow three)
 static bool object_level_build(int nt, int prims_per_object) {
-  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);
-  return (prims_per_object & AGX_BVH_BOX_OBJECTS) && !(prims_per_object & AGX_BVH_FULL_SORT) && ppo == 12 && nt >= 24 && nt / 12 <= kObjMax;
+  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS | AGX_BVH_OBJECT_TREE);
+  return (prims_per_object & AGX_BVH_OBJECT_TREE) && (prims_per_object & AGX_BVH_BOX_OBJECTS) && !(prims_per_object & AGX_BVH_FULL_SORT) && ppo == 12 &&
+         nt >= 24 && nt / 12 <= kObjMax;
 }
 static size_t bvh_lds_bytes_for(int nt, int npad, int prims_per_object) {
   return object_level_build(nt, prims_per_object) ? (size_t)obj_lds_bytes_c(nt) : bvh_lds_bytes(nt, npad);
@@ -1100,8 +1101,9 @@ extern "C" int agx_assets_integrate(int n, int num_assets, float *asset_state, c
 // argument checks and launch shape shared by the two LBVH builders; `kernel`'s dynamic LDS limit is raised once (*attr_set)
 static int bvh_launch_shape(int nt, int prims_per_object, int *npad_out, size_t *lds_out, const void *kernel, bool *attr_set) {
   AGX_REQUIRE(nt >= 2 && nt <= kBvhMaxTris, "num_tris %d outside [2, %d] (LDS-resident LBVH build)", nt, kBvhMaxTris);
-  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS);  // (flags: include/aerial_gym_hip.h)
+  const int ppo = prims_per_object & ~(AGX_BVH_FULL_SORT | AGX_BVH_BOX_OBJECTS | AGX_BVH_OBJECT_TREE);  // (flags: include/aerial_gym_hip.h)
   AGX_REQUIRE(!(prims_per_object & AGX_BVH_BOX_OBJECTS) || ppo == 12, "AGX_BVH_BOX_OBJECTS goes with objects of 12 triangles");
+  AGX_REQUIRE(!(prims_per_object & AGX_BVH_OBJECT_TREE) || (prims_per_object & AGX_BVH_BOX_OBJECTS), "AGX_BVH_OBJECT_TREE goes with AGX_BVH_BOX_OBJECTS");
   AGX_REQUIRE(ppo == 0 || (ppo >= 9 && nt % ppo == 0),
               "prims_per_object must be 0 or >= 9 (8 floats of LDS scratch per object) and divide num_tris");
   int npad = 1;

@@ -53,7 +53,7 @@ class SceneManager:
         # the box's frame, running the exact triangle test on the entered face only (same frames, bit for bit); chunks of a
         # cylinder / sphere / mesh keep their triangle subtrees.  box_objects=False (EnvManager args={"bvh_box_objects": False}):
         # triangle subtrees everywhere (A/B runs).
-        self.bvh_prims_per_object = 12 | (0x20000000 if box_objects else 0)
+        self._box_objects = bool(box_objects)
         # sharding: start of this rank's slice of the global asset counter
         semantic_offset = self.semantic_offset = env_offset * K  # this shard's slice of the global id counter
         if K == 0:
@@ -121,6 +121,16 @@ class SceneManager:
                                     "resources/models/environment_assets/<set> directory)")
         sizes = list(acfg.box_sizes) if acfg.box_sizes else [[0.0, 0.0, 0.0]]
         return [[Prim("box", tuple(float(v) for v in sz), np.eye(4), "base_link", 0)] for sz in sizes]
+
+    @property
+    def bvh_prims_per_object(self):
+        """agx_bvh_build's prims_per_object: chunks of 12 triangles | AGX_BVH_BOX_OBJECTS | -- where every object IS a box (no URDF
+        with curved / mesh links in the scene) -- AGX_BVH_OBJECT_TREE: the tree is built over the objects (csrc/agx_scene.hip).  The
+        quick subtrees that build gives non-box chunks traverse 7-9 % slower than their LBVH subtrees (profiles/forest_probe_r06.py):
+        scenes with primitives keep the triangle-level build, object nodes for their boxes included."""
+        if not self._box_objects:
+            return 12
+        return 12 | 0x20000000 | (0 if self.has_prims else 0x10000000)
 
     MAX_TRIS_PER_ENV = 2944  # csrc/agx_scene.hip kBvhMaxTris (agx_bvh_build refuses more by message; this names the assets)
 

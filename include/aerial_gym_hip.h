@@ -627,12 +627,15 @@ int agx_assets_integrate(int num_envs, int num_assets, float *asset_state, const
  * and run the exact triangle test only on the face(s) a ray can enter through: the closest hit over the triangles the exact test
  * accepts -- the result's definition -- is unchanged, the five in-object nodes and most face tests are gone.  An object whose
  * triangles do not make an orthogonal box (or whose keys interleave with another object's) keeps its triangle subtree.
- * Round 6: with this flag (and 2 <= T / 12 <= 256, no AGX_BVH_FULL_SORT) the tree is BUILT over the K = T / 12 objects instead of
- * over the triangles: records 0 .. K - 2 are the radix tree over the objects' Morton keys (root 0), records K - 1 + 5 o .. + 4 belong
- * to object o -- its object node at the first of them, or, for an object that is not a recognised box (parked beyond the curriculum
- * level at -1000 m, or simply not a box), a five-node subtree over its six triangle pairs with its root at the fifth.  Consumers
- * follow child references only; nothing depends on the numbering.                                                              */
+ * AGX_BVH_OBJECT_TREE (round 6; with AGX_BVH_BOX_OBJECTS, 2 <= T / 12 <= 256, no AGX_BVH_FULL_SORT): the tree is BUILT over the
+ * K = T / 12 objects instead of over the triangles: records 0 .. K - 2 are the radix tree over the objects' Morton keys (root 0),
+ * records K - 1 + 5 o .. + 4 belong to object o -- its object node at the first of them, or, for an object that is not a recognised
+ * box (parked beyond the curriculum level at -1000 m, or simply not a box), a five-node subtree over its six triangle pairs with its
+ * root at the fifth.  Consumers follow child references only; nothing depends on the numbering.  For scenes whose objects ARE boxes
+ * (one dirty env: 24 us instead of 55-60); the quick subtrees of non-box chunks (cylinders, spheres, meshes) traverse 7-9 % slower
+ * than their LBVH subtrees (profiles/forest_probe_r06.py), so callers leave the flag off for such scenes.                       */
 #define AGX_BVH_BOX_OBJECTS 0x20000000
+#define AGX_BVH_OBJECT_TREE 0x10000000
 #define AGX_BVH_OBJECT_REF 0x40000000   /* bit 30 of a non-negative child reference: the child is an object node */
 size_t agx_bvh_nodes_bytes(int num_envs, int num_tris);
 int agx_bvh_build(int num_envs, int num_tris, int prims_per_object, const float *tri_world,

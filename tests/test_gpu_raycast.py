@@ -33,7 +33,7 @@ class Scene:
         # AGX_BVH_BOX_OBJECTS (the product's default): the tree ends at every object the builder recognises as a trimesh box;
         # AGX_TEST_BOX_OBJECTS=0 runs this file on triangle subtrees only.  Either way every frame is compared bit for bit.
         if self.ppo and os.environ.get("AGX_TEST_BOX_OBJECTS", "1") != "0":
-            self.ppo |= 0x20000000
+            self.ppo |= 0x30000000  # AGX_BVH_BOX_OBJECTS | AGX_BVH_OBJECT_TREE: what SceneManager passes for box scenes
         self.stream = _lib.current_stream(DEV)
 
     def build(self, mask=None):
@@ -624,7 +624,7 @@ def test_bvh_object_level_order_equals_the_full_key_sort(orc):
             sc["asset_state"][:, 1, 0:7] = sc["asset_state"][:, 0, 0:7]  # the second box sits on the first
         S = Scene(sc)
         assert S.ppo & 0xFFFF == 12
-        S.ppo &= ~0x20000000  # the TRIANGLE-level build (with AGX_BVH_BOX_OBJECTS box scenes take the object-level build: its own test)
+        S.ppo &= ~0x10000000  # the TRIANGLE-level build, object nodes kept (what scenes with non-box primitives use)
         S.build()
         a = S.nodes.clone()
         S.nodes.zero_()
@@ -673,7 +673,7 @@ def test_object_level_build_with_parked_and_non_box_objects(orc):
     frames = []
     for box_objects in (True, False):
         S = Scene(sc)
-        S.ppo = 12 | (0x20000000 if box_objects else 0)
+        S.ppo = 12 | (0x30000000 if box_objects else 0)
         S.build()
         if box_objects:
             nodes = S.nodes.cpu().numpy()
@@ -696,9 +696,12 @@ def test_bvh_structure_covers_every_triangle_once(orc):
     leaves, OBJECT NODES under AGX_BVH_BOX_OBJECTS), every child box contains its triangles, and folded nodes are
     unreachable.  An object node's record is the frame of its box: every vertex of its 12 triangles is a corner of it."""
     OBJ = 0x40000000
-    for n, k, walls in ((1, 1, False), (2, 7, False), (3, 100, True)):
+    for n, k, walls, tree in ((1, 1, False, 0x30000000), (2, 7, False, 0x30000000), (3, 100, True, 0x30000000), (2, 7, False, 0x20000000),
+                              (3, 100, True, 0x20000000)):  # the tree over the objects / over the triangles with object nodes
         sc = random_box_scene(n, k, seed=4, walls=walls)
         S = Scene(sc)
+        if S.ppo & 0x20000000:
+            S.ppo = (S.ppo & 0xFFFF) | tree
         S.build()
         box_objects = bool(S.ppo & 0x20000000)
         nodes = S.nodes.cpu().numpy()

@@ -28,7 +28,9 @@ def _scene(g, box_objects=False):
     ident[:, :, 6] = 1.0
     sc = dict(tri_local=tw, tri_asset=np.zeros(nt, np.int32), asset_state=ident, tri_seg=g["tri_seg"], half=np.ones((n, 1, 3), np.float32))
     S = Scene(sc)
-    S.ppo = (S.ppo & 0xFFFF) | (0x20000000 if box_objects else 0)
+    # True: AGX_BVH_BOX_OBJECTS | AGX_BVH_OBJECT_TREE (box scenes as SceneManager builds them); "triangle_level": object nodes in the
+    # triangle-level tree (scenes with non-box primitives); False: triangle subtrees only
+    S.ppo = (S.ppo & 0xFFFF) | {True: 0x30000000, "triangle_level": 0x20000000, False: 0}[box_objects]
     S.build()
     S.tri_world.copy_(torch.from_numpy(tw).to(DEV))  # exactly the fixture's bits (the identity transform may flip a -0)
     S.L.check(S.lib.agx_bvh_build(S.n, S.nt, S.ppo, S.L.dptr(S.tri_world), None, S.L.dptr(S.nodes), S.L.dptr(S.work), S.stream))
@@ -159,7 +161,7 @@ def box_scene_frame(S, g, tag, limits=None):
                     *pose, **kw), mode <= 1
 
 
-@pytest.mark.parametrize("box_objects", [True, False])
+@pytest.mark.parametrize("box_objects", [True, "triangle_level", False])
 @pytest.mark.parametrize("tag", cases("boxes"))
 def test_object_node_traversal_vs_reference_source(scenes, tag, box_objects):
     """the traversal that ships by default (AGX_BVH_BOX_OBJECTS: the tree ends at a recognised box, its faces are
@@ -172,7 +174,7 @@ def test_object_node_traversal_vs_reference_source(scenes, tag, box_objects):
         scenes[key] = (g, _scene(g, box_objects=box_objects))
     g, S = scenes[key]
     n_boxes = g["tri_world"].shape[0] * g["tri_world"].shape[1] // 12
-    assert object_node_count(S) == (n_boxes if box_objects else 0)
+    assert object_node_count(S) == (n_boxes if box_objects else 0)  # (both tree forms end at every box)
     (px, seg), scalar = box_scene_frame(S, g, tag)
     fused = box_scene_frame(S, g, tag, limits=limits_of(g, tag))[0][0] if scalar and limits_of(g, tag) is not None else None
     _check(S, g, tag, px, seg, fused)
