@@ -827,6 +827,8 @@ def compact_line(out, detail_path=None):
     if isinstance(out.get("strict_rng"), dict) and "error" in out["strict_rng"]:
         line["strict_rng_error"] = str(out["strict_rng"]["error"])[:160]
     line.update(_pick(out, ("build_id", "binary_matches_sources")))
+    if "error" in out:  # (a run that could not be timed: the preflight verdict line)
+        line["error"] = str(out["error"])[:300]
     if detail_path:
         line["detail"] = detail_path
     line = _r(line)

@@ -142,3 +142,19 @@ def test_stdout_line_guard_drops_secondary_objects_never_the_contract():
     line = bench.compact_line(full, "bench_detail.json")
     assert len(json.dumps(line)) < bench.LINE_LIMIT
     assert "dropped_for_size" in line and "roofline" in line and "cpu_baseline" in line and "value" in line
+
+
+def test_a_failed_preflight_still_prints_one_parseable_line():
+    """the line bench.py prints when the exchange preflight of an N > 1 run hangs or fails (no timing happened): small, parseable,
+    names the failing leg"""
+    bench = _bench_module()
+    pre = [{"backend": "process_group", "ok": True, "steps": 200, "seconds": 1.2, "first_failure": None},
+           {"backend": "peer_push", "ok": False, "steps": 200, "seconds": 60.0,
+            "first_failure": {"rank": 3, "error": "RuntimeError: " + "x" * 900, "failed_in": "run", "first_bad_step_by_sender": {"5": 17}}}]
+    out = {"metric": "env-steps/sec (not measured: the exchange preflight failed)", "value": None, "n_gpus": 8,
+           "error": "exchange preflight: backend peer_push failed", "exchange": {"preflight": pre}}
+    line = json.dumps(bench.compact_line(out, None))
+    d = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT and d["value"] is None and d["n_gpus"] == 8 and "peer_push" in d["error"]
+    assert [p["backend"] for p in d["exchange"]["preflight"]] == ["process_group", "peer_push"]
+    assert d["exchange"]["preflight"][1]["ok"] is False and "rank" in d["exchange"]["preflight"][1]["first_failure"]
