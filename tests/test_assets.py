@@ -193,6 +193,15 @@ def test_multi_primitive_scene_layout():
     assert np.array_equal(t0[:12], t0[12:24]) and np.array_equal(t0[:12], t0[120:132])  # a box in a 132-triangle slot: its 12 triangles repeated
     sem = d["prim_sem"]
     assert sem[0, 0] == 13 and sem[0, 1] == 100 and set(np.diff(sem[0, 1:4])) <= {0, 1}  # floor id, then per-link ids from 100
+    # the tree form the scene asks the builder for (include/aerial_gym_hip.h): chunks of 12 triangles + object nodes for the boxes, and
+    # -- only where EVERY object is a box -- the tree built over the objects (AGX_BVH_OBJECT_TREE: cylinder chunks traverse slower
+    # through its quick subtrees, profiles/r06_scene_refresh_phases.txt)
+    from aerial_gym_simulator_amd.config.env_config import EnvWithObstaclesCfg
+
+    assert sc.bvh_prims_per_object == 12 | 0x20000000
+    boxes_only = SceneManager(EnvWithObstaclesCfg, 2, "cpu", None)
+    assert not boxes_only.has_prims and boxes_only.bvh_prims_per_object == 12 | 0x20000000 | 0x10000000
+    assert SceneManager(EnvWithObstaclesCfg, 2, "cpu", None, box_objects=False).bvh_prims_per_object == 12
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_ASSETS), reason="reference tree not present (GPU box)")
